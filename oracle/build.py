@@ -1,0 +1,134 @@
+"""Build recipes for the test oracle.  TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+  build_oracle()  gcc  oracle/soc_oracle.c -> oracle/_build/liborc_soc.so, liborc_libm.so
+  build_ref()     clang -x cl on the reference kernels WHERE THEY LIE in /root/reference
+                  + oracle/ref_shim.cpp  -> oracle/_ref/ref_<tag>.so   (one per geometry,
+                  because the reference bakes geometry in with -D macros, ASOC.py:344-362)
+
+Nothing from /root/reference is copied: the .c/.cl files are only named on the compiler
+command line.  oracle/_ref/ is git-ignored and exists only where /root/reference exists
+(this container); the GPU box receives the prebuilt .so files with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REFERENCE = "/root/reference"
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+BUILD_DIR = os.path.join(HERE, "_build")
+REF_DIR = os.path.join(HERE, "_ref")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def build_oracle(force=False):
+    """Compile both math modes of the CPU restatement.  Returns {mode: path}."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    srcs = [os.path.join(HERE, "soc_oracle.c"), os.path.join(HERE, "soc_oracle_index.inc"),
+            os.path.join(REPO, "soc_amd", "csrc", "soc_math.h")]
+    out = {}
+    for mode, flag in (("soc", []), ("libm", ["-DSOC_ORACLE_LIBM"])):
+        so = os.path.join(BUILD_DIR, "liborc_%s.so" % mode)
+        out[mode] = so
+        if not force and _newer(so, srcs):
+            continue
+        cmd = ["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+               "-fno-fast-math", "-mfma", "-msse4.1", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] \
+            + flag + ["-o", so, srcs[0], "-lm"]
+        subprocess.check_call(cmd)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Reference builds
+# --------------------------------------------------------------------------------------
+
+def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
+             USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
+             GL=0.01):
+    """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
+    AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
+    d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=0, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
+             CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS), WITH_ABU=WITH_ABU, ROI_MAP=0, MAX_SPLIT=4300,
+             SELEM=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0,
+             AXY="%.5ff" % (NX * NY / AREA), AXZ="%.5ff" % (NX * NZ / AREA), AYZ="%.5ff" % (NY * NZ / AREA),
+             LEVELS=LEVELS, LENGTH="%.5ef" % (GL * 3.08567758e18), DO_SPLIT=0, POLSTAT=0,
+             SW_A="0.000e+00f", SW_B="0.000e+00f", STEP_WEIGHT=-1, DIR_WEIGHT=-1, DW_A="0.000e+00f",
+             LEVEL_THRESHOLD=0, POLRED=0, p00="0.2000f", MINLOS="-1.000e+00f", MAXLOS="1.000e+10f",
+             FFS=1, NODIR=1, USE_EMWEIGHT=USE_EMWEIGHT, SAVE_INTENSITY=SAVE_INTENSITY,
+             NOABSORBED=NOABSORBED, INTERPOLATE=0, ADHOC="1.00000e+00f", HPBG_WEIGHTED=0,
+             WITH_MSF=WITH_MSF, NDUST=NDUST, OPT_IS_HALF=0, POL_RHO_WEIGHT=0, MAP_INTERPOLATION=0,
+             MIRROR=MIRROR, CR_HEATING=0, CR_HEATING_RATE="0.000e+00f", NVIDIA=0, NSIDE=128)
+    return ["-D%s=%s" % (k, v) for k, v in d.items()]
+
+
+def build_ref(tag, force=False, **model):
+    """Compile kernel_ASOC.c for one model + the shim -> oracle/_ref/ref_<tag>.so.
+    Returns the path, or None when /root/reference is absent (GPU box)."""
+    so = os.path.join(REF_DIR, "ref_%s.so" % tag)
+    ksrc = os.path.join(REFERENCE, "kernel_ASOC.c")
+    if not os.path.exists(ksrc):
+        return so if os.path.exists(so) else None
+    os.makedirs(REF_DIR, exist_ok=True)
+    shim = os.path.join(HERE, "ref_shim.cpp")
+    stamp = so + ".defs"
+    defs = ref_defs(**model)
+    if (not force and _newer(so, [shim, os.path.abspath(__file__), ksrc]) and os.path.exists(stamp)
+            and open(stamp).read() == " ".join(defs)):
+        return so
+    kobj = os.path.join(REF_DIR, "k_%s.o" % tag)
+    sobj = os.path.join(REF_DIR, "shim_%s.o" % tag)
+    common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
+    subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
+                           "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", shim, "-o", sobj])
+    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    os.remove(kobj)
+    os.remove(sobj)
+    with open(stamp, "w") as fp:
+        fp.write(" ".join(defs))
+    return so
+
+
+def ref_models():
+    """Every reference build the tests, the golden generator and bench.py's cpu_baseline use."""
+    sys.path.insert(0, REPO)
+    from soc_amd import synth
+    oct8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    oct104 = synth.octree_cloud(104, levels=3, frac=0.002, seed=11)
+    m = {
+        "c8":      dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512),
+        "c8int":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NOABSORBED=0),
+        "c8abu":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ABU=1),
+        "r654":    dict(NX=6, NY=5, NZ=4, LEVELS=1, CELLS=120),
+        "c16":     dict(NX=16, NY=16, NZ=16, LEVELS=1, CELLS=4096),
+        "c32":     dict(NX=32, NY=32, NZ=32, LEVELS=1, CELLS=32768),
+        "oct4":    dict(NX=4, NY=4, NZ=4, LEVELS=3, CELLS=80),
+        "oct8":    dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
+        "oct8emw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=1),
+        "oct104":  dict(NX=104, NY=104, NZ=104, LEVELS=oct104.LEVELS, CELLS=oct104.CELLS),
+        "c128":    dict(NX=128, NY=128, NZ=128, LEVELS=1, CELLS=128 ** 3),
+    }
+    for k in (1, 2, 4, 5):
+        m["c8ps%d" % k] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=k, NO_PS=2)
+    m["c8ps0"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=0, NO_PS=2)
+    return m
+
+
+def build_all_refs(force=False):
+    out = {}
+    for tag, model in ref_models().items():
+        out[tag] = build_ref(tag, force=force, **model)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_oracle(force="--force" in sys.argv))
+    print(build_all_refs(force="--force" in sys.argv))

@@ -1,0 +1,329 @@
+"""ctypes access to the CPU oracle (oracle/soc_oracle.c) and to the x86 builds of the
+reference kernels (oracle/_ref).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by soc_amd/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_F = C.POINTER(C.c_float)
+_I = C.POINTER(C.c_int)
+_U = C.POINTER(C.c_uint32)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_F)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+class OrcModel(C.Structure):
+    _fields_ = [
+        ("NX", C.c_int), ("NY", C.c_int), ("NZ", C.c_int), ("LEVELS", C.c_int), ("CELLS", C.c_int),
+        ("BINS", C.c_int), ("PS_METHOD", C.c_int), ("NO_PS", C.c_int),
+        ("WITH_ABU", C.c_int), ("WITH_INT", C.c_int), ("USE_EMWEIGHT", C.c_int), ("DOUBLE_INDEX", C.c_int),
+        ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
+        ("DENS", _F), ("CSC", _F), ("OPT", _F),
+        ("SOURCE", C.c_int), ("PACKETS", C.c_int), ("BATCH", C.c_int), ("GLOBAL", C.c_int),
+        ("SEED", C.c_float), ("ABS", C.c_float), ("SCA", C.c_float), ("BG", C.c_float), ("TW", C.c_float),
+        ("PSPOS", _F), ("PS", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F),
+        ("EMIT", _F), ("EMWEI", _F), ("TABS", _F), ("INT", _F),
+        ("threaded", C.c_int),
+    ]
+
+
+class RefArgs(C.Structure):
+    _fields_ = [
+        ("SOURCE", C.c_int), ("PACKETS", C.c_int), ("BATCH", C.c_int), ("GLOBAL", C.c_int),
+        ("SEED", C.c_float), ("BG", C.c_float), ("TW", C.c_float),
+        ("ABS", _F), ("SCA", _F), ("PSPOS", _F), ("PS", _F),
+        ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
+        ("DENS", _F), ("EMIT", _F), ("TABS", _F), ("DSC", _F), ("CSC", _F), ("XAB", _F), ("EMWEI", _F),
+        ("INT", _F), ("INTX", _F), ("INTY", _F), ("INTZ", _F), ("OPT", _F), ("ABU", _F),
+        ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("EMINDEX", _I),
+    ]
+
+
+def double_index(NX, LEVELS):
+    """kernel_ASOC_aux.c:25-37: Index() switches to double when NX > DIMLIM."""
+    return int(NX > (399 if LEVELS < 3 else 100))
+
+
+class Job:
+    """Everything one kernel launch needs, as numpy arrays (shared by Oracle and Ref)."""
+
+    def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
+                 GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
+                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None):
+        self.cloud = cloud
+        self.CSC = np.ascontiguousarray(CSC, np.float32)
+        self.DSC = np.ascontiguousarray(DSC if DSC is not None else np.ones_like(self.CSC), np.float32)
+        self.BINS = len(self.CSC)
+        self.ABS, self.SCA = np.float32(ABS), np.float32(SCA)
+        self.SOURCE, self.BATCH = int(SOURCE), int(BATCH)
+        self.SEED, self.BG, self.TW = np.float32(SEED), np.float32(BG), np.float32(TW)
+        self.GLOBAL = int(GLOBAL if GLOBAL is not None else 8 * cloud.AREA)
+        self.PACKETS = int(PACKETS)
+        self.PS_METHOD = int(PS_METHOD)
+        if PSPOS is None:
+            PSPOS = np.zeros((1, 3), np.float32)
+            PS = np.zeros(1, np.float32)
+        PSPOS = np.asarray(PSPOS, np.float32).reshape(-1, 3)
+        self.NO_PS = len(PSPOS)
+        self.PSPOS = np.zeros((self.NO_PS, 4), np.float32)     # cl float3 = 16 bytes
+        self.PSPOS[:, :3] = PSPOS
+        self.PS = np.ascontiguousarray(PS, np.float32)
+        if XPS is None:
+            XPS = (np.zeros(self.NO_PS, np.int32), np.zeros(3 * self.NO_PS, np.int32),
+                   np.ones(3 * self.NO_PS, np.float32))
+        self.XPS_NSIDE, self.XPS_SIDE, self.XPS_AREA = (np.ascontiguousarray(XPS[0], np.int32),
+                                                        np.ascontiguousarray(XPS[1], np.int32),
+                                                        np.ascontiguousarray(XPS[2], np.float32))
+        self.OPT = None if OPT is None else np.ascontiguousarray(OPT, np.float32)
+        self.EMIT = np.ascontiguousarray(EMIT if EMIT is not None else np.zeros(cloud.CELLS), np.float32)
+        self.EMWEI = np.ascontiguousarray(EMWEI if EMWEI is not None else np.ones(cloud.CELLS), np.float32)
+        self.USE_EMWEIGHT = int(USE_EMWEIGHT)
+        self.WITH_INT = int(WITH_INT)
+        self.LCELLS = np.ascontiguousarray(cloud.LCELLS, np.int32)
+        self.OFF = np.ascontiguousarray(cloud.OFF, np.int32)
+        self.DENS = np.ascontiguousarray(cloud.DENS, np.float32)
+        self.PAR = None
+
+
+class Oracle:
+    """The CPU restatement.  mode = 'soc' (shared math header) or 'libm'."""
+
+    def __init__(self, mode="soc"):
+        libs = _build.build_oracle()
+        self.mode = mode
+        self.lib = C.CDLL(libs[mode])
+        L = self.lib
+        L.orc_seed_base.restype = C.c_uint64
+        L.orc_seed_base.argtypes = [C.c_float]
+        L.orc_seed.argtypes = [C.c_float, C.c_uint64, _U, _U]
+        L.orc_draws.argtypes = [_U, _U, C.c_int, _U, _F]
+        L.orc_parents.argtypes = [C.POINTER(OrcModel), _I]
+        L.orc_trace.restype = C.c_int
+        L.orc_trace.argtypes = [C.POINTER(OrcModel), _F, _F, C.c_int, _I, _I, _F, _F]
+        L.orc_scatter.argtypes = [_F, _F, C.c_int, _U, _U]
+        L.orc_deflect.argtypes = [_F, C.c_float, C.c_float]
+        L.orc_sim.restype = C.c_long
+        L.orc_sim.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_math_eval.argtypes = [C.c_int, _F, _F, C.c_long]
+        L.orc_indexg.argtypes = [C.POINTER(OrcModel), _F, _I, _I]
+        assert L.orc_math_mode() == (1 if mode == "soc" else 0)
+
+    # ---- RNG ----
+    def seed(self, SEED, gid):
+        x, c = C.c_uint32(), C.c_uint32()
+        self.lib.orc_seed(np.float32(SEED), int(gid), C.byref(x), C.byref(c))
+        return x.value, c.value
+
+    def seed_base(self, SEED):
+        return int(self.lib.orc_seed_base(np.float32(SEED)))
+
+    def draws(self, x, c, n):
+        xx, cc = C.c_uint32(x), C.c_uint32(c)
+        u = np.zeros(n, np.uint32)
+        r = np.zeros(n, np.float32)
+        self.lib.orc_draws(C.byref(xx), C.byref(cc), n, u.ctypes.data_as(_U), _fp(r))
+        return u, r, (xx.value, cc.value)
+
+    # ---- model plumbing ----
+    def _model(self, job):
+        cl = job.cloud
+        m = OrcModel()
+        m.NX, m.NY, m.NZ, m.LEVELS, m.CELLS = cl.NX, cl.NY, cl.NZ, cl.LEVELS, cl.CELLS
+        m.BINS, m.PS_METHOD, m.NO_PS = job.BINS, job.PS_METHOD, max(1, job.NO_PS)
+        m.WITH_ABU = int(job.OPT is not None)
+        m.WITH_INT, m.USE_EMWEIGHT = job.WITH_INT, job.USE_EMWEIGHT
+        m.DOUBLE_INDEX = double_index(cl.NX, cl.LEVELS)
+        m.LCELLS, m.OFF, m.DENS = _ip(job.LCELLS), _ip(job.OFF), _fp(job.DENS)
+        if job.PAR is None:
+            job.PAR = np.zeros(max(1, cl.CELLS - cl.NX * cl.NY * cl.NZ), np.int32)
+            m.PAR = _ip(job.PAR)
+            self.lib.orc_parents(C.byref(m), _ip(job.PAR))
+        m.PAR = _ip(job.PAR)
+        m.CSC, m.OPT = _fp(job.CSC), _fp(job.OPT)
+        m.SOURCE, m.PACKETS, m.BATCH, m.GLOBAL = job.SOURCE, job.PACKETS, job.BATCH, job.GLOBAL
+        m.SEED, m.ABS, m.SCA, m.BG, m.TW = job.SEED, job.ABS, job.SCA, job.BG, job.TW
+        m.PSPOS, m.PS = _fp(job.PSPOS), _fp(job.PS)
+        m.XPS_NSIDE, m.XPS_SIDE, m.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
+        m.EMIT, m.EMWEI = _fp(job.EMIT), _fp(job.EMWEI)
+        return m
+
+    def parents(self, job):
+        self._model(job)
+        return job.PAR
+
+    def trace(self, job, pos, direction, maxsteps=100000):
+        m = self._model(job)
+        pos = np.ascontiguousarray(pos, np.float32)
+        d = np.ascontiguousarray(direction, np.float32)
+        lev = np.zeros(maxsteps, np.int32)
+        ind = np.zeros(maxsteps, np.int32)
+        ds = np.zeros(maxsteps, np.float32)
+        end = np.zeros(3, np.float32)
+        n = self.lib.orc_trace(C.byref(m), _fp(pos), _fp(d), maxsteps, _ip(lev), _ip(ind), _fp(ds), _fp(end))
+        return lev[:n].copy(), ind[:n].copy(), ds[:n].copy(), end
+
+    def indexg(self, job, pos):
+        m = self._model(job)
+        p = np.ascontiguousarray(pos, np.float32).copy()
+        lev, ind = C.c_int(0), C.c_int(-1)
+        self.lib.orc_indexg(C.byref(m), _fp(p), C.byref(lev), C.byref(ind))
+        return p, lev.value, ind.value
+
+    def scatter(self, direction, CSC, x, c):
+        d = np.ascontiguousarray(direction, np.float32).copy()
+        CSC = np.ascontiguousarray(CSC, np.float32)
+        xx, cc = C.c_uint32(x), C.c_uint32(c)
+        self.lib.orc_scatter(_fp(d), _fp(CSC), len(CSC), C.byref(xx), C.byref(cc))
+        return d, (xx.value, cc.value)
+
+    def deflect(self, direction, cos_theta, phi):
+        d = np.ascontiguousarray(direction, np.float32).copy()
+        self.lib.orc_deflect(_fp(d), np.float32(cos_theta), np.float32(phi))
+        return d
+
+    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None):
+        """Run work items [gid0,gid1) of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
+        Returns (TABS, INT, tally_events)."""
+        m = self._model(job)
+        cells = job.cloud.CELLS
+        TABS = np.zeros(cells, np.float32) if TABS is None else TABS
+        INT = np.zeros(cells, np.float32) if INT is None else INT
+        m.TABS, m.INT = _fp(TABS), _fp(INT)
+        gid1 = job.GLOBAL if gid1 is None else gid1
+        n = self.lib.orc_sim(C.byref(m), kind, gid0, gid1, nthreads)
+        return TABS, INT, int(n)
+
+    def math(self, fn, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6)[fn]
+        self.lib.orc_math_eval(code, _fp(x), _fp(y), x.size)
+        return y
+
+
+class Ref:
+    """One x86 build of the reference kernels (geometry baked in): oracle/_ref/ref_<tag>.so."""
+
+    def __init__(self, tag):
+        models = _build.ref_models()
+        self.tag = tag
+        self.model = models[tag]
+        path = _build.build_ref(tag, **self.model)
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("reference build %s not available" % tag)
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.ref_sim.argtypes = [C.POINTER(RefArgs), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_parents.argtypes = [_F, _I, _I, _I]
+        L.ref_seed.argtypes = [C.c_float, C.c_ulong, _U, _U]
+        L.ref_draws.argtypes = [_U, _U, C.c_int, _U]
+        L.ref_trace.restype = C.c_int
+        L.ref_trace.argtypes = [_F, _F, C.c_int, _F, _I, _I, _I, _I, _F, _F]
+        L.ref_scatter.argtypes = [_F, _F, _U, _U]
+        L.ref_deflect.argtypes = [_F, C.c_float, C.c_float]
+        L.ref_indexg.argtypes = [_F, _I, _I, _F, _I]
+
+    @staticmethod
+    def available(tag):
+        try:
+            Ref(tag)
+            return True
+        except (FileNotFoundError, OSError, KeyError):
+            return False
+
+    def _check(self, job):
+        cl, m = job.cloud, self.model
+        assert (cl.NX, cl.NY, cl.NZ, cl.LEVELS, cl.CELLS) == (m["NX"], m["NY"], m["NZ"], m["LEVELS"], m["CELLS"]), \
+            "job geometry does not match reference build %s" % self.tag
+        assert job.BINS == m.get("BINS", 2500)
+        assert job.PS_METHOD == m.get("PS_METHOD", 0)
+        assert int(job.OPT is not None) == m.get("WITH_ABU", 0)
+        assert job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
+        assert job.WITH_INT == int(m.get("NOABSORBED", 1) == 0 or m.get("SAVE_INTENSITY", 0) in (1, 2))
+        assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1))
+
+    def seed(self, SEED, gid):
+        x, c = C.c_uint32(), C.c_uint32()
+        self.lib.ref_seed(np.float32(SEED), int(gid), C.byref(x), C.byref(c))
+        return x.value, c.value
+
+    def draws(self, x, c, n):
+        xx, cc = C.c_uint32(x), C.c_uint32(c)
+        u = np.zeros(n, np.uint32)
+        self.lib.ref_draws(C.byref(xx), C.byref(cc), n, u.ctypes.data_as(_U))
+        return u, (xx.value, cc.value)
+
+    def parents(self, job):
+        self._check(job)
+        cl = job.cloud
+        PAR = np.zeros(max(1, cl.CELLS - cl.NX * cl.NY * cl.NZ), np.int32)
+        self.lib.ref_parents(_fp(job.DENS), _ip(job.LCELLS), _ip(job.OFF), _ip(PAR))
+        return PAR
+
+    def trace(self, job, pos, direction, maxsteps=100000):
+        self._check(job)
+        PAR = self.parents(job)
+        pos = np.ascontiguousarray(pos, np.float32)
+        d = np.ascontiguousarray(direction, np.float32)
+        lev = np.zeros(maxsteps, np.int32)
+        ind = np.zeros(maxsteps, np.int32)
+        ds = np.zeros(maxsteps, np.float32)
+        end = np.zeros(3, np.float32)
+        n = self.lib.ref_trace(_fp(pos), _fp(d), maxsteps, _fp(job.DENS), _ip(job.OFF), _ip(PAR),
+                               _ip(lev), _ip(ind), _fp(ds), _fp(end))
+        return lev[:n].copy(), ind[:n].copy(), ds[:n].copy(), end
+
+    def indexg(self, job, pos):
+        p = np.ascontiguousarray(pos, np.float32).copy()
+        lev, ind = C.c_int(0), C.c_int(-1)
+        self.lib.ref_indexg(_fp(p), C.byref(lev), C.byref(ind), _fp(job.DENS), _ip(job.OFF))
+        return p, lev.value, ind.value
+
+    def scatter(self, direction, CSC, x, c):
+        assert len(CSC) == self.model.get("BINS", 2500)
+        d = np.ascontiguousarray(direction, np.float32).copy()
+        CSC = np.ascontiguousarray(CSC, np.float32)
+        xx, cc = C.c_uint32(x), C.c_uint32(c)
+        self.lib.ref_scatter(_fp(d), _fp(CSC), C.byref(xx), C.byref(cc))
+        return d, (xx.value, cc.value)
+
+    def deflect(self, direction, cos_theta, phi):
+        d = np.ascontiguousarray(direction, np.float32).copy()
+        self.lib.ref_deflect(_fp(d), np.float32(cos_theta), np.float32(phi))
+        return d
+
+    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None):
+        self._check(job)
+        cells = job.cloud.CELLS
+        PAR = self.parents(job)
+        TABS = np.zeros(cells, np.float32) if TABS is None else TABS
+        INT = np.zeros(cells, np.float32) if INT is None else INT
+        dummy = np.zeros(4, np.float32)
+        idummy = np.zeros(4, np.int32)
+        ABS = np.asarray([job.ABS], np.float32)
+        SCA = np.asarray([job.SCA], np.float32)
+        a = RefArgs()
+        a.SOURCE, a.PACKETS, a.BATCH, a.GLOBAL = job.SOURCE, job.PACKETS, job.BATCH, job.GLOBAL
+        a.SEED, a.BG, a.TW = job.SEED, job.BG, job.TW
+        a.ABS, a.SCA, a.PSPOS, a.PS = _fp(ABS), _fp(SCA), _fp(job.PSPOS), _fp(job.PS)
+        a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
+        a.DENS, a.EMIT, a.TABS = _fp(job.DENS), _fp(job.EMIT), _fp(TABS)
+        a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(job.CSC), _fp(dummy), _fp(job.EMWEI)
+        a.INT, a.INTX, a.INTY, a.INTZ = _fp(INT), _fp(dummy), _fp(dummy), _fp(dummy)
+        a.OPT = _fp(job.OPT) if job.OPT is not None else _fp(dummy)
+        a.ABU = _fp(dummy)
+        a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
+        a.EMINDEX = _ip(idummy)
+        gid1 = job.GLOBAL if gid1 is None else gid1
+        self.lib.ref_sim(C.byref(a), kind, gid0, gid1, nthreads)
+        return TABS, INT

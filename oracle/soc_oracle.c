@@ -1,0 +1,797 @@
+/*
+ * soc_oracle.c -- CPU restatement of SOC's photon-packet path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (soc_amd/, libsoc_hip.so) never links, imports or calls it.
+ *
+ * What it restates (file:line in /root/reference):
+ *   MWC64X RNG + stream seeding ........ mwc64x_rng.cl:12-48, skip_mwc.cl:9-76
+ *   Rand ............................... kernel_ASOC_aux.c:127
+ *   IndexG / Index / GetStep ........... kernel_ASOC_aux.c:131-165, 198-278, 282-315
+ *   Deflect / Scatter .................. kernel_ASOC_aux.c:499-561
+ *   Surface ............................ kernel_ASOC_aux.c:912-940
+ *   Parents ............................ kernel_ASOC_aux.c:688-718
+ *   SimRAM_PB (SOURCE 0/1, PS_METHOD 0,1,2,4,5) ... kernel_ASOC.c:15-824
+ *   SimRAM_CL (USE_EMWEIGHT 0/1, no ALI) ........... kernel_ASOC.c:1223-1689
+ * Geometry and feature switches that the reference bakes in with -D macros
+ * (ASOC.py:344-362) are run-time fields of orc_model here.
+ *
+ * Arithmetic: every floating-point expression keeps the reference's operand order and
+ * is compiled with -ffp-contract=off.  Two builds of this one source exist:
+ *   -DSOC_ORACLE_LIBM  : transcendentals from glibc libm.  Pinned bit-for-bit against the
+ *                        reference kernels compiled for x86 (oracle/_ref, same libm).
+ *   (default, "soc")   : transcendentals from soc_amd/csrc/soc_math.h, the header the HIP
+ *                        kernels use, so that CPU and gfx950 follow identical trajectories.
+ * The two builds differ in nothing but those function bodies.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef SOC_ORACLE_LIBM
+#  define M_EXP(x)   expf(x)
+#  define M_LOG(x)   logf(x)
+#  define M_SIN(x)   sinf(x)
+#  define M_COS(x)   cosf(x)
+#  define M_ACOS(x)  acosf(x)
+#  define M_SQRT(x)  sqrtf(x)
+#  define M_FMOD1(x) fmodf((x), 1.0f)
+#  define M_FMOD1D(x) fmod((x), 1.0)
+#  define M_LDEXP_DN(x, l) ldexpf((x), -(l))
+#  define M_LDEXP_UP(x, l) ldexpf((x), (l))
+#  define M_FLOOR(x) floorf(x)
+static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
+#else
+#  include "../soc_amd/csrc/soc_math.h"
+#  define M_EXP(x)   soc_expf(x)
+#  define M_LOG(x)   soc_logf(x)
+#  define M_SIN(x)   soc_sinf(x)
+#  define M_COS(x)   soc_cosf(x)
+#  define M_ACOS(x)  soc_acosf(x)
+#  define M_SQRT(x)  soc_sqrtf(x)
+#  define M_FMOD1(x) soc_fmod1f(x)
+#  define M_FMOD1D(x) soc_fmod1d(x)
+#  define M_LDEXP_DN(x, l) soc_scale_down((x), (l))
+#  define M_LDEXP_UP(x, l) soc_scale_up((x), (l))
+#  define M_FLOOR(x) soc_floorf(x)
+static inline void M_SINCOS(float x, float *s, float *c) { soc_sincosf(x, s, c); }
+#endif
+
+/* constants: kernel_ASOC_aux.c:5-9, 99-114 */
+#define TWOPI    6.28318531f
+#define TAULIM   5.0e-4f
+#define PI_F     3.1415926535897f
+static const float PEPS = 1.0e-4f;
+static const float DEPS = 5.0e-5f;
+
+typedef struct { float x, y, z; } f3;
+typedef struct { uint32_t x, c; } rng_t;
+
+/* ---- model / launch description (mirrors the -D list of ASOC.py:344-362 + kernel args) ---- */
+typedef struct {
+    int NX, NY, NZ, LEVELS, CELLS;
+    int BINS, PS_METHOD, NO_PS;       /* NO_PS as passed with -D: max(1, number of sources) */
+    int WITH_ABU;                     /* OPT[CELLS,2] instead of scalar ABS/SCA           */
+    int WITH_INT;                     /* SAVE_INTENSITY in (1,2) or NOABSORBED==0         */
+    int USE_EMWEIGHT;                 /* 0 or 1 (SimRAM_CL)                               */
+    int DOUBLE_INDEX;                 /* NX > DIMLIM, kernel_ASOC_aux.c:25-37,207-211     */
+    const int   *LCELLS, *OFF, *PAR;
+    const float *DENS;
+    const float *CSC;                 /* [BINS] row of the current frequency              */
+    const float *OPT;                 /* [2*CELLS] or NULL                                */
+    /* kernel arguments */
+    int   SOURCE, PACKETS, BATCH, GLOBAL;
+    float SEED, ABS, SCA, BG, TW;
+    const float *PSPOS;               /* 4 floats per source (OpenCL float3 = 16 bytes)   */
+    const float *PS;
+    const int   *XPS_NSIDE, *XPS_SIDE;
+    const float *XPS_AREA;
+    const float *EMIT, *EMWEI;
+    float *TABS, *INT;
+    int   threaded;                   /* !=0: tallies use atomic adds (OpenMP build)      */
+} orc_model;
+
+/* ================================ RNG ================================================== */
+
+#define MWC64X_A 4294883355U
+#define MWC64X_M 18446383549859758079UL
+#define MWC_BASEID 4077358422479273989UL
+
+static uint64_t AddMod64(uint64_t a, uint64_t b, uint64_t M)
+{
+    uint64_t v = a + b;
+    if ((v >= M) || (v < a)) v = v - M;
+    return v;
+}
+static uint64_t MulMod64(uint64_t a, uint64_t b, uint64_t M)
+{
+    uint64_t r = 0;
+    while (a != 0) {
+        if (a & 1) r = AddMod64(r, b, M);
+        b = AddMod64(b, b, M);
+        a = a >> 1;
+    }
+    return r;
+}
+static uint64_t PowMod64(uint64_t a, uint64_t e, uint64_t M)
+{
+    uint64_t sqr = a, acc = 1;
+    while (e != 0) {
+        if (e & 1) acc = MulMod64(acc, sqr, M);
+        sqr = MulMod64(sqr, sqr, M);
+        e = e >> 1;
+    }
+    return acc;
+}
+/* MWC64X_SeedStreams with vecSize=1, vecOffset=0 (mwc64x_rng.cl:35-40, skip_mwc.cl:64-76) */
+static void SeedStreams(rng_t *s, uint64_t gid, uint64_t baseOffset, uint64_t perStreamOffset)
+{
+    uint64_t dist = baseOffset + gid * perStreamOffset;
+    uint64_t m = PowMod64(MWC64X_A, dist, MWC64X_M);
+    uint64_t x = MulMod64(MWC_BASEID, m, MWC64X_M);
+    s->x = (uint32_t)(x / MWC64X_A);
+    s->c = (uint32_t)(x % MWC64X_A);
+}
+static uint32_t NextUint(rng_t *s)
+{
+    uint32_t res = s->x ^ s->c;
+    uint32_t X = s->x, C = s->c;
+    uint32_t Xn = MWC64X_A * X + C;
+    uint32_t carry = (uint32_t)(Xn < C);
+    uint32_t Cn = (uint32_t)(((uint64_t)MWC64X_A * X) >> 32) + carry;   /* mad_hi(A, X, carry) */
+    s->x = Xn;
+    s->c = Cn;
+    return res;
+}
+static inline float Rand(rng_t *s) { return NextUint(s) / 4294967295.0f; }
+
+/* kernel_ASOC.c:74-77 */
+static uint64_t seed_base(float SEED)
+{
+    return (unsigned long)(fmodf(SEED * 7.0f * PI_F, 1.0f) * 4294967296L);
+}
+static void seed_workitem(rng_t *s, float SEED, uint64_t gid)
+{
+    SeedStreams(s, gid, seed_base(SEED), 274877906944UL);
+}
+
+/* ================================ traversal ============================================ */
+
+static void IndexG(const orc_model *M, f3 *pos, int *level, int *ind)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const float *DENS = M->DENS;
+    const int *OFF = M->OFF;
+    *ind = -1;
+    if ((pos->x <= 0.0f) || (pos->y <= 0.0f) || (pos->z <= 0.0f)) return;
+    if ((pos->x >= NX) || (pos->y >= NY) || (pos->z >= NZ)) return;
+    *level = 0;
+    *ind = (int)M_FLOOR(pos->z) * NX * NY + (int)M_FLOOR(pos->y) * NX + (int)M_FLOOR(pos->x);
+    if (DENS[*ind] > 0.0f) return;
+    while (1) {
+        pos->x = 2.0f * M_FMOD1(pos->x);
+        pos->y = 2.0f * M_FMOD1(pos->y);
+        pos->z = 2.0f * M_FMOD1(pos->z);
+        float link = -DENS[OFF[*level] + (*ind)];
+        int   li;
+        memcpy(&li, &link, 4);
+        *ind = li;
+        (*level)++;
+        *ind += 4 * (int)M_FLOOR(pos->z) + 2 * (int)M_FLOOR(pos->y) + (int)M_FLOOR(pos->x);
+        if (DENS[OFF[*level] + (*ind)] > 0.0f) return;
+    }
+}
+
+/* Index(): float and double position variants, kernel_ASOC_aux.c:198-278 */
+#define REAL float
+#define RFLOOR(x) M_FLOOR(x)
+#define RFMOD1(x) M_FMOD1(x)
+#define INDEX_NAME Index_f
+#include "soc_oracle_index.inc"
+#undef REAL
+#undef RFLOOR
+#undef RFMOD1
+#undef INDEX_NAME
+
+#define REAL double
+#define RFLOOR(x) floor(x)
+#define RFMOD1(x) M_FMOD1D(x)
+#define INDEX_NAME Index_d
+#include "soc_oracle_index.inc"
+#undef REAL
+#undef RFLOOR
+#undef RFMOD1
+#undef INDEX_NAME
+
+static inline void Index(const orc_model *M, f3 *pos, int *level, int *ind)
+{
+    if (M->DOUBLE_INDEX) Index_d(M, pos, level, ind);
+    else                 Index_f(M, pos, level, ind);
+}
+
+/* kernel_ASOC_aux.c:282-315, float branch (NX <= 9999) */
+static float GetStep(const orc_model *M, f3 *POS, const f3 *DIR, int *level, int *ind)
+{
+    float dx, dy, dz;
+    dx = (DIR->x > 0.0f) ? ((1.0f + PEPS - M_FMOD1(POS->x)) / DIR->x) : ((-PEPS - M_FMOD1(POS->x)) / DIR->x);
+    dy = (DIR->y > 0.0f) ? ((1.0f + PEPS - M_FMOD1(POS->y)) / DIR->y) : ((-PEPS - M_FMOD1(POS->y)) / DIR->y);
+    dz = (DIR->z > 0.0f) ? ((1.0f + PEPS - M_FMOD1(POS->z)) / DIR->z) : ((-PEPS - M_FMOD1(POS->z)) / DIR->z);
+    dx = fminf(dx, fminf(dy, dz));
+    POS->x += dx * DIR->x;
+    POS->y += dx * DIR->y;
+    POS->z += dx * DIR->z;
+    dx = M_LDEXP_DN(dx, *level);
+    Index(M, POS, level, ind);
+    return dx;
+}
+
+static inline void normalize3(f3 *v)
+{
+    /* OpenCL normalize(): device-defined; fixed here (and in oracle/ref_shim.cpp, and in the
+       HIP kernel) as v * (1/sqrt(x*x+y*y+z*z)) */
+    float s = 1.0f / M_SQRT(v->x * v->x + v->y * v->y + v->z * v->z);
+    v->x = v->x * s;
+    v->y = v->y * s;
+    v->z = v->z * s;
+}
+
+/* kernel_ASOC_aux.c:499-533 */
+static void Deflect(f3 *DIR, const float COS_THETA, const float phi)
+{
+    float cx, cy, cz, ox, oy, oz, theta0, phi0, cos_theta, sin_theta, sin_phi, cos_phi;
+    cx = DIR->x;  cy = DIR->y;  cz = DIR->z;
+    sin_theta = M_SQRT(1.0f - COS_THETA * COS_THETA);
+    M_SINCOS(phi, &sin_phi, &cos_phi);
+    ox = sin_theta * cos_phi;
+    oy = sin_theta * sin_phi;
+    oz = COS_THETA;
+    theta0 = M_ACOS(cz / M_SQRT(cx * cx + cy * cy + cz * cz + DEPS));
+    phi0   = M_ACOS(cx / M_SQRT(cx * cx + cy * cy + DEPS));
+    if (DIR->y < 0.0f) phi0 = (TWOPI - phi0);
+    theta0 = -theta0;
+    phi0   = -phi0;
+    M_SINCOS(theta0, &sin_theta, &cos_theta);
+    M_SINCOS(phi0, &sin_phi, &cos_phi);
+    DIR->x = +ox * cos_theta * cos_phi + oy * sin_phi - oz * sin_theta * cos_phi;
+    DIR->y = -ox * cos_theta * sin_phi + oy * cos_phi + oz * sin_theta * sin_phi;
+    DIR->z = +ox * sin_theta + oz * cos_theta;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+/* kernel_ASOC_aux.c:540-561 (HG_TEST==0) */
+static void Scatter(f3 *DIR, const float *CSC, int BINS, rng_t *rng)
+{
+    float cos_theta = CSC[clampi((int)M_FLOOR(Rand(rng) * BINS), 0, BINS - 1)];
+    float phi = TWOPI * Rand(rng);
+    Deflect(DIR, cos_theta, phi);
+    if (fabsf(DIR->x) < DEPS) DIR->x = DEPS;
+    if (fabsf(DIR->y) < DEPS) DIR->y = DEPS;
+    if (fabsf(DIR->z) < DEPS) DIR->z = DEPS;
+    normalize3(DIR);
+}
+
+/* kernel_ASOC_aux.c:912-940 */
+static void Surface(const orc_model *M, f3 *POS, f3 *DIR)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    float dx, dy, dz;
+    if (DIR->x > 0.0f) {
+        if (POS->x < 0.0f) dx = (PEPS - POS->x) / DIR->x;
+        else               dx = -1.0e10f;
+    } else {
+        if (POS->x > NX)   dx = (NX - PEPS - POS->x) / DIR->x;
+        else               dx = -1.0e10f;
+    }
+    if (DIR->y > 0.0f) {
+        if (POS->y < 0.0f) dy = (PEPS - POS->y) / DIR->y;
+        else               dy = -1.0e10f;
+    } else {
+        if (POS->y > NY)   dy = (NY - PEPS - POS->y) / DIR->y;
+        else               dy = -1.0e10f;
+    }
+    if (DIR->z > 0.0f) {
+        if (POS->z < 0.0f) dz = (PEPS - POS->z) / DIR->z;
+        else               dz = -1.0e10f;
+    } else {
+        if (POS->z > NZ)   dz = (NZ - PEPS - POS->z) / DIR->z;
+        else               dz = -1.0e10f;
+    }
+    dx = fmaxf(dx, fmaxf(dy, dz));
+    POS->x += dx * DIR->x;
+    POS->y += dx * DIR->y;
+    POS->z += dx * DIR->z;
+}
+
+static inline void tally(const orc_model *M, float *buf, int oind, float v)
+{
+    if (M->threaded) {
+#pragma omp atomic
+        buf[oind] += v;
+    } else {
+        buf[oind] += v;
+    }
+}
+
+/* The part of SimRAM_PB / SimRAM_CL that follows packet creation: kernel_ASOC.c:508-820
+ * (PB) and :1409-1676 (CL).  cl_order selects the CL kernel's placement of the
+ * scatterings>20 test (before the scatter tally, kernel_ASOC.c:1545-1551) instead of the
+ * PB placement (after Scatter(), :802-804).  Returns the number of tally events. */
+static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS,
+                        int level, int ind, int cl_order)
+{
+    const float *DENS = M->DENS;
+    const int *OFF = M->OFF;
+    int   oind = 0, ind0 = -1, level0 = 0, scatterings, steps;
+    float ds, free_path, tau, dtau, delta, tauA, dx;
+    f3    POS0 = POS;
+    long  nt = 0;
+
+    if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+    if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+    if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+    normalize3(&DIR);
+    scatterings = 0;
+    tau = 0.0f;
+    free_path = -M_LOG(Rand(rng));
+    steps = 0;
+
+    while (ind >= 0) {
+        tau = 0.0f;
+        while (ind >= 0) {
+            oind   = OFF[level] + ind;
+            ind0   = ind;
+            level0 = level;
+            POS0   = POS;
+            ds     = GetStep(M, &POS, &DIR, &level, &ind);
+            if (M->WITH_ABU) {
+                tauA = ds * DENS[oind] * M->OPT[2 * (long)oind];
+                dtau = ds * DENS[oind] * M->OPT[2 * (long)oind + 1];
+            } else {
+                tauA = ds * DENS[oind] * M->ABS;
+                dtau = ds * DENS[oind] * M->SCA;
+            }
+            if (free_path < (tau + dtau)) {
+                ind = ind0;
+                break;
+            }
+            delta = (tauA > TAULIM) ? (PHOTONS * (1.0f - M_EXP(-tauA))) : (PHOTONS * tauA * (1.0f - 0.5f * tauA));
+            tally(M, M->TABS, oind, delta * M->TW * 1.0f);
+            if (M->WITH_INT) tally(M, M->INT, oind, delta);
+            nt++;
+            PHOTONS *= M_EXP(-tauA);
+            tau += dtau;
+            if (!cl_order) {
+                /* failed-step guard exists only in SimRAM_PB (kernel_ASOC.c:649-683) */
+                if ((level == level0) && (ind == ind0)) {
+                    POS.x += PEPS * DIR.x;
+                    POS.y += PEPS * DIR.y;
+                    POS.z += PEPS * DIR.z;
+                    steps += 1;
+                }
+            }
+        }
+        if (ind < 0) break;
+        /* scatter */
+        scatterings++;
+        if (cl_order && (scatterings > 20)) { ind = -1; continue; }
+        dtau = free_path - tau;
+        if (M->WITH_ABU) {
+            dx   = dtau / (M->OPT[2 * (long)oind + 1] * DENS[oind]);
+            tauA = dx * DENS[oind] * M->OPT[2 * (long)oind];
+        } else {
+            dx   = dtau / (M->SCA * DENS[oind]);
+            tauA = dx * DENS[oind] * M->ABS;
+        }
+        delta = (tauA > TAULIM) ? (PHOTONS * (1.0f - M_EXP(-tauA))) : (PHOTONS * tauA * (1.0f - 0.5f * tauA));
+        tally(M, M->TABS, oind, delta * M->TW * 1.0f);
+        if (M->WITH_INT) tally(M, M->INT, oind, delta);
+        nt++;
+        dx = M_LDEXP_UP(dx, level0);
+        dx = fmaxf(0.0f, dx - 2.0f * PEPS);
+        POS.x = POS0.x + dx * DIR.x;
+        POS.y = POS0.y + dx * DIR.y;
+        POS.z = POS0.z + dx * DIR.z;
+        PHOTONS *= M_EXP(-tauA);
+        free_path = -M_LOG(Rand(rng));
+        ind   = ind0;
+        level = level0;
+        Scatter(&DIR, M->CSC, M->BINS, rng);
+        if (!cl_order && (scatterings > 20)) { ind = -1; continue; }
+    }
+    (void)steps;
+    return nt;
+}
+
+/* ================================ SimRAM_PB ============================================ */
+
+/* One work item of SimRAM_PB (kernel_ASOC.c:15-824).  Returns tally events. */
+static long sim_pb_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
+    const int SOURCE = M->SOURCE, BATCH = M->BATCH, NO_PS = M->NO_PS;
+    int   oind = 0, level = 0, SIDE = 0;
+    float phi, cos_theta, sin_theta;
+    f3    DIR = {0.0f, 0.0f, 0.0f}, POS = {0.0f, 0.0f, 0.0f};
+    float PHOTONS = 0.0f, X0 = 0, Y0 = 0, Z0 = 0, DX = 0, DY = 0, DZ = 0, v1, v2;
+    rng_t rng;
+    long  nt = 0;
+    int   ind = -1, level0;
+
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+
+    if ((SOURCE == 1) && (id >= (8 * AREA))) return 0;
+    if (SOURCE == 3) return 0;
+
+    if (SOURCE == 1) {
+        ind = id % AREA;
+        DX = 1.0f; DY = 1.0f; DZ = 1.0f;
+        if (ind < (NY * NZ)) {
+            SIDE = 0;  X0 = PEPS;       Y0 = ind % NY;  Z0 = ind / NY;  DX = 0.0f;
+        } else {
+            ind -= NY * NZ;
+            if (ind < (NY * NZ)) {
+                SIDE = 1;  X0 = NX - PEPS;  Y0 = ind % NY;  Z0 = ind / NY;  DX = 0.0f;
+            } else {
+                ind -= NY * NZ;
+                if (ind < (NX * NZ)) {
+                    SIDE = 2;  Y0 = PEPS;  X0 = ind % NX;  Z0 = ind / NX;  DY = 0.0f;
+                } else {
+                    ind -= NX * NZ;
+                    if (ind < (NX * NZ)) {
+                        SIDE = 3;  Y0 = NY - PEPS;  X0 = ind % NX;  Z0 = ind / NX;  DY = 0.0f;
+                    } else {
+                        ind -= NX * NZ;
+                        if (ind < (NX * NY)) {
+                            SIDE = 4;  Z0 = PEPS;  X0 = ind % NX;  Y0 = ind / NX;  DZ = 0.0f;
+                        } else {
+                            ind -= NX * NY;
+                            SIDE = 5;  Z0 = NZ - PEPS;  X0 = ind % NX;  Y0 = ind / NX;  DZ = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    for (int III = 0; III < BATCH; III++) {
+        if (SOURCE == 0) {
+            phi       = TWOPI * Rand(&rng);
+            cos_theta = 0.999997f - 1.999995f * Rand(&rng);
+            sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+            DIR.x = sin_theta * M_COS(phi);
+            DIR.y = sin_theta * M_SIN(phi);
+            DIR.z = cos_theta;
+            level0  = III % NO_PS;
+            PHOTONS = M->PS[level0];
+            f3 SRC = { M->PSPOS[4 * level0], M->PSPOS[4 * level0 + 1], M->PSPOS[4 * level0 + 2] };
+            POS = SRC;
+            IndexG(M, &POS, &level, &ind);
+            if ((ind < 0) || (ind >= M->CELLS)) {
+                if (M->PS_METHOD == 0) {
+                    Surface(M, &POS, &DIR);
+                    IndexG(M, &POS, &level, &ind);
+                }
+                if (M->PS_METHOD == 1) {
+                    POS = SRC;
+                    if (POS.z > NZ) {
+                        if (DIR.z > 0.0f) DIR.z = -DIR.z;
+                    } else {
+                        if (POS.z < 0.0f) {
+                            if (DIR.z < 0.0f) DIR.z = -DIR.z;
+                        } else {
+                            if (POS.x > NX) {
+                                if (DIR.x > 0.0f) DIR.x = -DIR.x;
+                            } else {
+                                if (POS.x < 0.0f) {
+                                    if (DIR.x < 0.0f) DIR.x = -DIR.x;
+                                } else {
+                                    if (POS.y > NY) {
+                                        if (DIR.y > 0.0f) DIR.y = -DIR.y;
+                                    } else {
+                                        if (POS.y < 0.0f) {
+                                            if (DIR.y < 0.0f) DIR.y = -DIR.y;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    Surface(M, &POS, &DIR);
+                    PHOTONS *= 0.5f;
+                    IndexG(M, &POS, &level, &ind);
+                }
+                if (M->PS_METHOD == 2) {
+                    POS = SRC;
+                    ind = M_FLOOR(Rand(&rng) * M->XPS_NSIDE[level0] * 0.999999f);
+                    PHOTONS /= M->XPS_AREA[3 * level0 + ind];
+                    ind = M->XPS_SIDE[3 * level0 + ind];
+                    float a = Rand(&rng), b = Rand(&rng);
+                    if (ind == 0) { POS.x = NX - PEPS;  POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
+                    if (ind == 1) { POS.x = PEPS;       POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
+                    if (ind == 2) { POS.y = NY - PEPS;  POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
+                    if (ind == 3) { POS.y = PEPS;       POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
+                    if (ind == 4) { POS.z = NZ - PEPS;  POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
+                    if (ind == 5) { POS.z = PEPS;       POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
+                    DIR.x = POS.x - SRC.x;  DIR.y = POS.y - SRC.y;  DIR.z = POS.z - SRC.z;
+                    v1 = M_SQRT(DIR.x * DIR.x + DIR.y * DIR.y + DIR.z * DIR.z);   /* distance() */
+                    normalize3(&DIR);
+                    v2 = (ind < 2) ? (fabsf(DIR.x)) : ((ind < 4) ? (fabsf(DIR.y)) : (fabsf(DIR.z)));
+                    PHOTONS *= v2 * b / (4.0f * PI_F * v1 * v1);
+                    IndexG(M, &POS, &level, &ind);
+                }
+                if (M->PS_METHOD == 4) {
+                    v1 = SRC.z - NZ;
+                    cos_theta = v1 / M_SQRT(v1 * v1 + 0.25f * NX * NX + 0.25f * NY * NY);
+                    PHOTONS *= 0.5f * (1.0f - cos_theta);
+                    cos_theta = 1.0f - Rand(&rng) * (1.0f - cos_theta);
+                    v1 = TWOPI * Rand(&rng);
+                    DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                    DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                    DIR.z = -cos_theta;
+                    Surface(M, &POS, &DIR);
+                    IndexG(M, &POS, &level, &ind);
+                }
+                if (M->PS_METHOD == 5) {
+                    cos_theta = M->XPS_AREA[3 * level0];
+                    PHOTONS *= 0.5f * (1.0f - cos_theta);
+                    cos_theta = 1.0f - Rand(&rng) * (1.0f - cos_theta);
+                    v1   = TWOPI * Rand(&rng);
+                    oind = M->XPS_SIDE[3 * level0];
+                    if (oind < 2) {
+                        DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                        DIR.z = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                        if (oind == 0) DIR.x = -cos_theta;
+                        else           DIR.x = +cos_theta;
+                    } else {
+                        if (oind < 4) {
+                            DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                            DIR.z = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                            if (oind == 2) DIR.y = -cos_theta;
+                            else           DIR.y = +cos_theta;
+                        } else {
+                            DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                            DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                            if (oind == 4) DIR.z = -cos_theta;
+                            else           DIR.z = +cos_theta;
+                        }
+                    }
+                    Surface(M, &POS, &DIR);
+                    IndexG(M, &POS, &level, &ind);
+                }
+            }
+        }
+        if (SOURCE == 1) {
+            POS.x = clampf(X0 + DX * Rand(&rng), PEPS, NX - PEPS);
+            POS.y = clampf(Y0 + DY * Rand(&rng), PEPS, NY - PEPS);
+            POS.z = clampf(Z0 + DZ * Rand(&rng), PEPS, NZ - PEPS);
+            cos_theta = M_SQRT(Rand(&rng));
+            phi       = TWOPI * Rand(&rng);
+            sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+            v1 = sin_theta * M_COS(phi);
+            v2 = sin_theta * M_SIN(phi);
+            switch (SIDE) {
+            case 0: DIR.x =  cos_theta; DIR.y = v1; DIR.z = v2; break;
+            case 1: DIR.x = -cos_theta; DIR.y = v1; DIR.z = v2; break;
+            case 2: DIR.y =  cos_theta; DIR.x = v1; DIR.z = v2; break;
+            case 3: DIR.y = -cos_theta; DIR.x = v1; DIR.z = v2; break;
+            case 4: DIR.z =  cos_theta; DIR.x = v1; DIR.y = v2; break;
+            case 5: DIR.z = -cos_theta; DIR.x = v1; DIR.y = v2; break;
+            }
+            PHOTONS = M->BG;
+            IndexG(M, &POS, &level, &ind);
+        }
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0);
+        /* NOTE: in the reference ind/level persist across III; walk_packet leaves ind<0 or
+           consumed, and every branch above overwrites (level, ind) through IndexG before
+           use, so carrying them is unnecessary. */
+        ind = -1;
+    }
+    return nt;
+}
+
+/* ================================ SimRAM_CL ============================================ */
+
+/* One work item of SimRAM_CL, USE_EMWEIGHT 0/1, WITH_ALI 0 (kernel_ASOC.c:1223-1689). */
+static long sim_cl_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, CELLS = M->CELLS, GLOBAL = M->GLOBAL, LEVELS = M->LEVELS;
+    const int *LCELLS = M->LCELLS, *OFF = M->OFF;
+    int   level = 0, batch;
+    float phi, cos_theta, sin_theta;
+    f3    DIR, POS;
+    float PHOTONS, X0, Y0, Z0, PWEI = 1.0f;
+    rng_t rng;
+    long  nt = 0;
+    if (id >= CELLS) return 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    int ICELL = id - GLOBAL;
+    int IRAY = 0;
+    int ind = -1;
+    batch = -1;
+    while (1) {
+        if (IRAY >= batch) {
+            IRAY = 0;
+            PWEI = 1.0f;
+            while (1) {
+                ICELL += GLOBAL;
+                if (ICELL >= CELLS) return nt;
+                if (M->USE_EMWEIGHT > 0) {
+                    PWEI = M->EMWEI[ICELL];
+                    if ((PWEI < 1e-10f) || (M->DENS[ICELL] <= 0.0f)) continue;
+                    batch = (int)M_FLOOR(PWEI);
+                    if (batch < 1) {
+                        batch = 1;  PWEI = 1.0 / (PWEI + 1.0e-30f);
+                    } else {
+                        PWEI = 1.0 / (batch + 1.0e-9f);
+                    }
+                } else {
+                    batch = M->BATCH;
+                    PWEI = 1.0f / (batch + 1.0e-9f);
+                }
+                break;
+            }
+        }
+        ind = ICELL;
+        IRAY += 1;
+        for (level = 0; level < LEVELS - 1; level++) {
+            ind -= LCELLS[level];
+            if (ind < 0) {
+                ind += LCELLS[level];
+                break;
+            }
+        }
+        if (level == 0) {
+            X0 = (ind % NX);
+            Y0 = ((ind / NX) % NY);
+            Z0 = (ind / (NX * NY));
+        } else {
+            int sid = ind % 8;
+            X0 = (sid % 2);
+            Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;
+            Z0 = (sid / 4);
+        }
+        PHOTONS = M->EMIT[OFF[level] + ind] * PWEI;
+        POS.x = X0 + Rand(&rng);  POS.y = Y0 + Rand(&rng);  POS.z = Z0 + Rand(&rng);
+        phi       = TWOPI * Rand(&rng);
+        cos_theta = 0.999997f - 1.999995f * Rand(&rng);
+        sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+        DIR.x = sin_theta * M_COS(phi);
+        DIR.y = sin_theta * M_SIN(phi);
+        DIR.z = cos_theta;
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 1);
+    }
+}
+
+/* ================================ exported API ========================================= */
+
+#define EXPORT __attribute__((visibility("default")))
+
+EXPORT int orc_math_mode(void)
+{
+#ifdef SOC_ORACLE_LIBM
+    return 0;
+#else
+    return 1;
+#endif
+}
+
+EXPORT uint64_t orc_seed_base(float SEED) { return seed_base(SEED); }
+
+EXPORT void orc_seed(float SEED, uint64_t gid, uint32_t *x, uint32_t *c)
+{
+    rng_t s;
+    seed_workitem(&s, SEED, gid);
+    *x = s.x;
+    *c = s.c;
+}
+
+EXPORT void orc_draws(uint32_t *x, uint32_t *c, int n, uint32_t *out_uint, float *out_rand)
+{
+    rng_t s = { *x, *c };
+    for (int i = 0; i < n; i++) {
+        rng_t t = s;
+        uint32_t u = NextUint(&s);
+        if (out_uint) out_uint[i] = u;
+        if (out_rand) out_rand[i] = Rand(&t);
+    }
+    *x = s.x;
+    *c = s.c;
+}
+
+/* Parents kernel, kernel_ASOC_aux.c:688-718.  PAR has CELLS-NX*NY*NZ entries. */
+EXPORT void orc_parents(const orc_model *M, int *PAR)
+{
+    const int NXYZ = M->NX * M->NY * M->NZ;
+    for (int level = 0; level < (M->LEVELS - 1); level++) {
+        for (int ipar = 0; ipar < M->LCELLS[level]; ipar++) {
+            float link = M->DENS[M->OFF[level] + ipar];
+            if (link < 1.0e-10f) {
+                link = -link;
+                int ind;
+                memcpy(&ind, &link, 4);
+                for (int i = 0; i < 8; i++) PAR[M->OFF[level + 1] - NXYZ + ind + i] = ipar;
+            }
+        }
+    }
+}
+
+EXPORT void orc_indexg(const orc_model *M, float *pos, int *level, int *ind)
+{
+    f3 p = { pos[0], pos[1], pos[2] };
+    IndexG(M, &p, level, ind);
+    pos[0] = p.x; pos[1] = p.y; pos[2] = p.z;
+}
+
+/* Follow one ray from a global position until it leaves the grid (no scattering):
+ * records (level, ind, ds) of each step.  Returns the number of steps taken. */
+EXPORT int orc_trace(const orc_model *M, const float *pos, const float *dir, int maxsteps,
+                     int *levels, int *inds, float *dss, float *endpos)
+{
+    f3 POS = { pos[0], pos[1], pos[2] }, DIR = { dir[0], dir[1], dir[2] };
+    int level = 0, ind = -1, n = 0;
+    IndexG(M, &POS, &level, &ind);
+    while ((ind >= 0) && (n < maxsteps)) {
+        levels[n] = level;
+        inds[n]   = ind;
+        dss[n]    = GetStep(M, &POS, &DIR, &level, &ind);
+        n++;
+    }
+    endpos[0] = POS.x; endpos[1] = POS.y; endpos[2] = POS.z;
+    return n;
+}
+
+EXPORT void orc_scatter(float *dir, const float *CSC, int BINS, uint32_t *x, uint32_t *c)
+{
+    f3 D = { dir[0], dir[1], dir[2] };
+    rng_t s = { *x, *c };
+    Scatter(&D, CSC, BINS, &s);
+    dir[0] = D.x; dir[1] = D.y; dir[2] = D.z;
+    *x = s.x; *c = s.c;
+}
+
+EXPORT void orc_deflect(float *dir, float cos_theta, float phi)
+{
+    f3 D = { dir[0], dir[1], dir[2] };
+    Deflect(&D, cos_theta, phi);
+    dir[0] = D.x; dir[1] = D.y; dir[2] = D.z;
+}
+
+/* Run work items [gid0, gid1) of SimRAM_PB (kind 0) or SimRAM_CL (kind 1).
+ * nthreads <= 1: sequential, deterministic summation order (= the reference run one
+ * work item after another).  Returns the number of tally events (TABS updates). */
+EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int nthreads)
+{
+    long total = 0;
+    if (nthreads <= 1) {
+        M->threaded = 0;
+        for (int id = gid0; id < gid1; id++)
+            total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
+    } else {
+        M->threaded = 1;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
+        for (int id = gid0; id < gid1; id++)
+            total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
+    }
+    return total;
+}
+
+/* math probes for tests/test_math.py */
+EXPORT void orc_math_eval(int fn, const float *x, float *y, long n)
+{
+    for (long i = 0; i < n; i++) {
+        switch (fn) {
+        case 0: y[i] = M_EXP(x[i]); break;
+        case 1: y[i] = M_LOG(x[i]); break;
+        case 2: y[i] = M_SIN(x[i]); break;
+        case 3: y[i] = M_COS(x[i]); break;
+        case 4: y[i] = M_ACOS(x[i]); break;
+        case 5: y[i] = M_SQRT(x[i]); break;
+        case 6: y[i] = M_FMOD1(x[i]); break;
+        default: y[i] = 0.0f;
+        }
+    }
+}

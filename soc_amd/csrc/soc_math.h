@@ -1,0 +1,189 @@
+// soc_math.h -- deterministic fp32 math for the photon-packet path.
+//
+// The reference (kernel_ASOC.c / kernel_ASOC_aux.c) calls the OpenCL device
+// built-ins exp, log, sin, cos, sincos, acos, sqrt, fmod, ldexp, floor.  Their
+// last-bit rounding differs between OpenCL devices, and a one-ulp difference
+// flips a cell-boundary decision, after which a packet visits different cells
+// (SURVEY.md 7.3-1).  To make fixed-seed results reproducible between the host
+// CPU and gfx950, every transcendental used on the path is defined HERE, from
+// IEEE-754 fp32 add/mul/fma, correctly rounded sqrt/div and integer bit
+// operations only.  The same header is compiled
+//   * by hipcc for the device kernels (soc_kernels.hip), and
+//   * by gcc for the CPU oracle's "soc" math mode (oracle/soc_oracle.c),
+// with -ffp-contract=off on both sides, so the two produce bit-identical values.
+// Accuracy is ~1 ulp (checked against libm in tests/test_math.py).
+//
+// No function here reads or writes memory other than its arguments.
+#ifndef SOC_MATH_H
+#define SOC_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#  define SOC_HD __host__ __device__ static inline
+#else
+#  define SOC_HD static inline
+#endif
+
+#define SOC_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+SOC_HD uint32_t soc_f2u(float f)
+{
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    return v.u;
+}
+SOC_HD float soc_u2f(uint32_t u)
+{
+    union { float f; uint32_t u; } v;
+    v.u = u;
+    return v.f;
+}
+
+// correctly rounded on both targets (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt is the default)
+SOC_HD float soc_sqrtf(float x) { return __builtin_sqrtf(x); }
+SOC_HD float soc_floorf(float x) { return __builtin_floorf(x); }
+SOC_HD float soc_fabsf(float x) { return __builtin_fabsf(x); }
+SOC_HD float soc_fminf(float a, float b) { return (b < a) ? b : a; }
+SOC_HD float soc_fmaxf(float a, float b) { return (b > a) ? b : a; }
+SOC_HD float soc_clampf(float x, float lo, float hi) { return soc_fminf(soc_fmaxf(x, lo), hi); }
+
+// fmod(x, 1.0f): exact, result has the sign of x (C99 fmodf semantics)
+SOC_HD float soc_fmod1f(float x)
+{
+    float r = x - __builtin_truncf(x);
+    return __builtin_copysignf(r, x);
+}
+SOC_HD double soc_fmod1d(double x)
+{
+    double r = x - __builtin_trunc(x);
+    return __builtin_copysign(r, x);
+}
+
+// ldexp(x, -level) / ldexp(x, +level) for 0 <= level <= 30: exact power-of-two scaling
+SOC_HD float soc_scale_down(float x, int level) { return x * soc_u2f((uint32_t)(127 - level) << 23); }
+SOC_HD float soc_scale_up(float x, int level) { return x * soc_u2f((uint32_t)(127 + level) << 23); }
+
+// exp(x).  Results below FLT_MIN are flushed to zero (x < -87), overflow gives +inf.
+SOC_HD float soc_expf(float x)
+{
+    if (!(x >= -87.0f)) return (x != x) ? x : 0.0f;
+    if (x > 88.72f) return soc_u2f(0x7f800000u);
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = SOC_FMA(-n, 0.693359375f, x);          // ln2 high part (exact product for |n| < 2^12)
+    r = SOC_FMA(-n, -2.12194440e-4f, r);             // ln2 low part
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = SOC_FMA(p, r, 1.3981999507e-3f);
+    p = SOC_FMA(p, r, 8.3334519073e-3f);
+    p = SOC_FMA(p, r, 4.1665795894e-2f);
+    p = SOC_FMA(p, r, 1.6666665459e-1f);
+    p = SOC_FMA(p, r, 5.0000001201e-1f);
+    float y = SOC_FMA(p, z, r) + 1.0f;
+    int   k  = (int)n;                                // -126 .. 128
+    int   k1 = k >> 1, k2 = k - k1;                   // two normal factors, product never overflows early
+    y = y * soc_u2f((uint32_t)(127 + k1) << 23);
+    y = y * soc_u2f((uint32_t)(127 + k2) << 23);
+    return y;
+}
+
+// natural logarithm.  log(0) = -inf, log(x<0) = NaN.
+SOC_HD float soc_logf(float x)
+{
+    if (!(x > 0.0f)) {
+        if (x == 0.0f) return soc_u2f(0xff800000u);
+        return soc_u2f(0x7fc00000u);
+    }
+    uint32_t ix = soc_f2u(x);
+    if (ix >= 0x7f800000u) return x;                  // +inf
+    int e = 0;
+    if (ix < 0x00800000u) {                           // subnormal: scale by 2^23
+        x  = x * 8388608.0f;
+        ix = soc_f2u(x);
+        e  = -23;
+    }
+    e += (int)(ix >> 23) - 126;                       // x = m * 2^e, m in [0.5, 1)
+    float m = soc_u2f((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = SOC_FMA(p, m, -1.1514610310e-1f);
+    p = SOC_FMA(p, m, 1.1676998740e-1f);
+    p = SOC_FMA(p, m, -1.2420140846e-1f);
+    p = SOC_FMA(p, m, 1.4249322787e-1f);
+    p = SOC_FMA(p, m, -1.6668057665e-1f);
+    p = SOC_FMA(p, m, 2.0000714765e-1f);
+    p = SOC_FMA(p, m, -2.4999993993e-1f);
+    p = SOC_FMA(p, m, 3.3333331174e-1f);
+    float y  = (p * m) * z;
+    float fe = (float)e;
+    y = SOC_FMA(fe, -2.12194440e-4f, y);
+    y = SOC_FMA(-0.5f, z, y);
+    float r = m + y;
+    r = SOC_FMA(fe, 0.693359375f, r);
+    return r;
+}
+
+// sin and cos together.  Three-term Cody-Waite reduction: accurate for |x| < ~1e4,
+// which covers every call on the path (arguments lie in [-2 pi, 2 pi]).
+SOC_HD void soc_sincosf(float x, float *s, float *c)
+{
+    float q = __builtin_rintf(x * 0.636619772367581343f);   // x * 2/pi
+    float r = SOC_FMA(-q, 1.5703125f, x);
+    r = SOC_FMA(-q, 4.837512969970703125e-4f, r);
+    r = SOC_FMA(-q, 7.54978995489188216e-8f, r);
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = SOC_FMA(ps, z, 8.3321608736e-3f);
+    ps = SOC_FMA(ps, z, -1.6666654611e-1f);
+    float sr = SOC_FMA(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = SOC_FMA(pc, z, -1.388731625493765e-3f);
+    pc = SOC_FMA(pc, z, 4.166664568298827e-2f);
+    float cr = SOC_FMA(pc * z, z, SOC_FMA(-0.5f, z, 1.0f));
+    int   iq = (int)q;
+    float ss = (iq & 1) ? cr : sr;
+    float cc = (iq & 1) ? sr : cr;
+    if (iq & 2) ss = -ss;
+    if ((iq + 1) & 2) cc = -cc;
+    *s = ss;
+    *c = cc;
+}
+SOC_HD float soc_sinf(float x) { float s, c; soc_sincosf(x, &s, &c); return s; }
+SOC_HD float soc_cosf(float x) { float s, c; soc_sincosf(x, &s, &c); return c; }
+
+// asin on |a| <= 0.5 (polynomial), building block of acos
+SOC_HD float soc_asin_core(float a)
+{
+    float z = a * a;
+    float p = 4.2163199048e-2f;
+    p = SOC_FMA(p, z, 2.4181311049e-2f);
+    p = SOC_FMA(p, z, 4.5470025998e-2f);
+    p = SOC_FMA(p, z, 7.4953002686e-2f);
+    p = SOC_FMA(p, z, 1.6666752422e-1f);
+    return SOC_FMA(p * z, a, a);
+}
+
+// acos(x); arguments outside [-1, 1] are clamped (the path never produces them).
+SOC_HD float soc_acosf(float x)
+{
+    if (x != x) return x;
+    if (x >= 1.0f) return 0.0f;
+    if (x <= -1.0f) return 3.14159265358979323846f;
+    if (x > 0.5f) {
+        float a = soc_sqrtf(0.5f * (1.0f - x));
+        return 2.0f * soc_asin_core(a);
+    }
+    if (x < -0.5f) {
+        float a = soc_sqrtf(0.5f * (1.0f + x));
+        return 3.14159265358979323846f - 2.0f * soc_asin_core(a);
+    }
+    return 1.57079632679489661923f - soc_asin_core(x);
+}
+
+#endif  // SOC_MATH_H
