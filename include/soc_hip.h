@@ -1,0 +1,131 @@
+/*
+ * soc_hip.h -- C ABI of libsoc_hip.so, the MI355X (gfx950) engine for SOC's photon-packet path.
+ *
+ * The reference has no FFI layer: its host scripts drive OpenCL kernels through pyopencl
+ * (cl.Buffer / enqueue_copy / kernel(queue,[GLOBAL],[LOCAL],args...)).  Each entry point
+ * below replaces one group of those calls; file:line citations are into /root/reference.
+ * Conventions:
+ *   - every function returns 0 on success, a negative code on error; the message is
+ *     available from soc_last_error().  Nothing throws or exits.
+ *   - host pointers are only read/written during the call; the library owns all device
+ *     memory behind the handle (NULL is allowed for unused optional arrays).
+ *   - scalars have the types pyopencl passes (set_scalar_arg_dtypes, ASOC.py:846-858):
+ *     int32 / float32.  SEED, BG, TW are float32 at the boundary.
+ *   - a handle is bound to one GPU and is not thread-safe; launches are asynchronous on the
+ *     handle's stream; soc_read_tally() and soc_sync() synchronise.
+ */
+#ifndef SOC_HIP_H
+#define SOC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct soc_ctx soc_ctx;
+
+#define SOC_OK            0
+#define SOC_ERR_ARG      -1   /* invalid argument / inconsistent model        */
+#define SOC_ERR_STATE    -2   /* call order: grid / tables not set yet         */
+#define SOC_ERR_HIP      -3   /* HIP runtime error (message has the details)   */
+
+/* tallies selectable in soc_zero / soc_read_tally / soc_tally_ptr */
+#define SOC_TALLY_TABS    0   /* absorbed energy integrated over frequency (TABS, kernel arg 15) */
+#define SOC_TALLY_INT     1   /* per-frequency absorptions (INT, kernel arg 20)                  */
+
+/* replaces ASOC_aux.py:1188-1256 opencl_init(): create a context on GPU `device` */
+int  soc_create(int device, soc_ctx **out);
+void soc_destroy(soc_ctx *ctx);
+const char *soc_last_error(const soc_ctx *ctx);   /* ctx may be NULL: last creation error */
+const char *soc_version(void);
+
+/* run on an externally owned HIP stream (e.g. the caller's torch stream); NULL = own stream */
+int soc_set_stream(soc_ctx *ctx, void *hip_stream);
+
+/* replaces the -D NX,NY,NZ,LEVELS,CELLS macros (ASOC.py:344-362), the LCELLS/OFF/DENS
+ * uploads (ASOC.py:524-539) and the Parents kernel launch (ASOC.py:585,
+ * kernel_ASOC_aux.c:688-718).  DENS is the concatenated hierarchy as read_cloud() returns
+ * it (ASOC_aux.py:716-803): value > 0 leaf density, value <= 0 link to 8 children.
+ * The hierarchy is validated (links in range, octets aligned) before anything is uploaded. */
+int soc_set_grid(soc_ctx *ctx, int NX, int NY, int NZ, int LEVELS, const int32_t *LCELLS, const float *DENS);
+
+/* feature switches the reference compiles in with -D (ASOC.py:344-362):
+ *   with_int     : SAVE_INTENSITY in (1,2) or NOABSORBED==0 -> INT tally is updated
+ *   ps_method    : PS_METHOD 0,1,2,4,5 (3 does not compile in the reference)
+ *   use_emweight : USE_EMWEIGHT 0 or 1 (SimRAM_CL)                                         */
+int soc_set_features(soc_ctx *ctx, int with_int, int ps_method, int use_emweight);
+
+/* replaces the per-frequency uploads of ABS, SCA (ASOC.py:1171-1175); ndust must be 1
+ * (the host sums the species, ASOC.py:1166-1170) */
+int soc_set_optical(soc_ctx *ctx, const float *ABS, const float *SCA, int ndust);
+
+/* replaces the OPT upload for abundance runs (WITH_ABU, ASOC.py:1146-1160):
+ * OPT[CELLS][2] = (abs, sca) per cell; NULL switches back to scalar ABS/SCA */
+int soc_set_opt(soc_ctx *ctx, const float *OPT);
+
+/* replaces the DSC/CSC row uploads (ASOC.py:1234-1243); DSC may be NULL (unused by the
+ * absorption kernels); BINS = USER.DSC_BINS */
+int soc_set_scatter_table(soc_ctx *ctx, const float *DSC, const float *CSC, int BINS);
+
+/* replaces the EMIT / EMWEI uploads (ASOC.py:1276, 1291); arrays of CELLS floats */
+int soc_set_emission(soc_ctx *ctx, const float *EMIT, const float *EMWEI);
+
+/* replaces ZeroAMC (kernel_ASOC_aux.c:657-683; ASOC.py:1115,1183): tag 0 clears TABS,
+ * tag 1 clears INT */
+int soc_zero(soc_ctx *ctx, int tag);
+
+/* replaces the kernel_ram_pb launch (ASOC.py:1360-1372 -> SimRAM_PB, kernel_ASOC.c:15-52).
+ * SOURCE 0 = point sources, 1 = isotropic background.  PSPOS holds 4 floats per source
+ * (cl float3).  GLOBAL is the logical launch size; this call executes the logical work
+ * items [gid_first, gid_first+gid_count) so that several GPUs can share one launch with
+ * exactly the streams a single device would use (get_global_id -> logical id). */
+int soc_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
+               const float *PSPOS, const float *PS, int NO_PS,
+               const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
+               int GLOBAL, int gid_first, int gid_count);
+
+/* replaces the kernel_ram_cl launch (ASOC.py:1308-1316, 1847 -> SimRAM_CL,
+ * kernel_ASOC.c:1223-1256); uses EMIT/EMWEI from soc_set_emission() */
+int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
+               int GLOBAL, int gid_first, int gid_count);
+
+/* replaces queue.finish() (ASOC.py:1461) */
+int soc_sync(soc_ctx *ctx);
+
+/* replaces cl.enqueue_copy(host, TABS_buf / INT_buf) (ASOC.py:1482, 1533); n = CELLS */
+int soc_read_tally(soc_ctx *ctx, int which, float *out, int64_t n);
+/* the inverse (e.g. `cload` restart files, ASOC.py:1013-1018) */
+int soc_write_tally(soc_ctx *ctx, int which, const float *in, int64_t n);
+
+/* device address of a tally (for an RCCL all-reduce by the caller), or bind caller-owned
+ * device memory (CELLS floats) as the tally so a framework tensor can be reduced in place */
+void *soc_tally_ptr(soc_ctx *ctx, int which);
+int   soc_bind_tally(soc_ctx *ctx, int which, void *device_ptr);
+
+/* PAR table computed by soc_set_grid (CELLS - NX*NY*NZ entries), for verification */
+int soc_read_par(soc_ctx *ctx, int32_t *out, int64_t n);
+
+/* counters accumulated by the kernels since the last reset:
+ * out[0] tally events, out[1] packets created, out[2] scattering events */
+int soc_stats(soc_ctx *ctx, uint64_t out[3], int reset);
+
+/* HIP-event timing on the handle's stream: bracket launches, then read elapsed ms */
+int soc_timer_start(soc_ctx *ctx);
+int soc_timer_stop(soc_ctx *ctx, float *elapsed_ms);
+
+/* ---- verification probes (used by the parity tests only) ---- */
+/* RNG stream states and first draws of logical work items [gid_first, gid_first+n)
+ * (MWC64X_SeedStreams + MWC64X_NextUint, mwc64x_rng.cl:35-48) */
+int soc_probe_rng(soc_ctx *ctx, float SEED, uint32_t gid_first, uint32_t n, int ndraw,
+                  uint32_t *state_xc, uint32_t *draws);
+/* device math header: fn 0 exp, 1 log, 2 sin, 3 cos, 4 acos, 5 sqrt, 6 fmod(x,1), 7 1/x */
+int soc_probe_math(soc_ctx *ctx, int fn, const float *x, float *y, int64_t n);
+/* follow one ray (IndexG + GetStep until exit); returns the number of steps in *nsteps */
+int soc_probe_trace(soc_ctx *ctx, const float pos[3], const float dir[3], int maxsteps,
+                    int32_t *levels, int32_t *inds, float *ds, float endpos[3], int32_t *nsteps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOC_HIP_H */

@@ -1,0 +1,585 @@
+// soc_capi.hip -- host side of libsoc_hip.so: the C ABI declared in include/soc_hip.h.
+// Owns device memory, validates the model on the host before anything reaches a kernel,
+// derives the per-launch seed constants and dispatches the kernels of soc_kernels.hip.
+#include "../../include/soc_hip.h"
+#include "soc_dev.h"
+#include "soc_rng.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct soc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // model
+    bool have_grid = false;
+    SocGrid G{};
+    float *dDENS = nullptr;
+    int   *dPAR = nullptr;
+    int64_t npar = 0;
+    // tables / per-frequency data
+    float *dCSC = nullptr, *dDSC = nullptr;
+    int    BINS = 0;
+    float  ABS = 0.0f, SCA = 0.0f;
+    bool   have_optical = false;
+    float2 *dOPT = nullptr;
+    float *dEMIT = nullptr, *dEMWEI = nullptr;
+    bool   have_emit = false;
+    // tallies
+    float *dTABS = nullptr, *dINT = nullptr;
+    bool   own_TABS = false, own_INT = false;
+    // point-source scratch
+    float4 *dPSPOS = nullptr;
+    float  *dPS = nullptr, *dXPS_AREA = nullptr;
+    int    *dXPS_NSIDE = nullptr, *dXPS_SIDE = nullptr;
+    int     ps_cap = 0;
+    // rng
+    uint64_t *dSeedTab = nullptr;
+    unsigned long long *dStats = nullptr;
+    // features
+    int with_int = 0, ps_method = 0, use_emweight = 0;
+};
+
+static std::string g_create_err;
+
+static int fail(soc_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else   g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), SOC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+template <typename T>
+static hipError_t dev_alloc(T **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *soc_version(void) { return "soc_hip 0.1 (gfx950)"; }
+
+const char *soc_last_error(const soc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int soc_create(int device, soc_ctx **out)
+{
+    if (!out) return fail(nullptr, SOC_ERR_ARG, "soc_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SOC_ERR_HIP, "soc_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, SOC_ERR_ARG, "soc_create: device %d out of range (0..%d)", device, ndev - 1);
+    soc_ctx *c = new soc_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        int r = fail(nullptr, SOC_ERR_HIP, "soc_create: %s", hipGetErrorString(e));
+        delete c;
+        return r;
+    }
+    c->stream = c->own_stream;
+    // seed tables: T[k][b] = G^(b*256^k) mod M with G = A^(2^38) mod M  (soc_rng.h)
+    std::vector<uint64_t> tab(1024);
+    uint64_t g = soc_powmod(SOC_MWC_A, SOC_STREAM_GAP);
+    for (int k = 0; k < 4; k++) {
+        uint64_t acc = 1;
+        for (int b = 0; b < 256; b++) {
+            tab[256 * k + b] = acc;
+            acc = soc_mulmod(acc, g);
+        }
+        g = acc;                                      // g^(256)
+    }
+    if ((e = hipMalloc((void **)&c->dSeedTab, 1024 * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMemcpy(c->dSeedTab, tab.data(), 1024 * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->dStats, 3 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->dStats, 0, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        int r = fail(nullptr, SOC_ERR_HIP, "soc_create: %s", hipGetErrorString(e));
+        soc_destroy(c);
+        return r;
+    }
+    *out = c;
+    return SOC_OK;
+}
+
+void soc_destroy(soc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dPSPOS, c->dPS,
+                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats };
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
+    if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int soc_set_stream(soc_ctx *c, void *hip_stream)
+{
+    if (!c) return SOC_ERR_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return SOC_OK;
+}
+
+int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *LCELLS, const float *DENS)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!LCELLS || !DENS) return fail(c, SOC_ERR_ARG, "soc_set_grid: NULL array");
+    if (NX < 1 || NY < 1 || NZ < 1 || NX > 9999) return fail(c, SOC_ERR_ARG, "soc_set_grid: bad dimensions %d %d %d", NX, NY, NZ);
+    if (LEVELS < 1 || LEVELS > SOC_MAXL) return fail(c, SOC_ERR_ARG, "soc_set_grid: LEVELS=%d unsupported (1..%d)", LEVELS, SOC_MAXL);
+    const int64_t nxyz = (int64_t)NX * NY * NZ;
+    if (nxyz > 2147483647LL || LCELLS[0] != nxyz)
+        return fail(c, SOC_ERR_ARG, "soc_set_grid: LCELLS[0]=%d does not match NX*NY*NZ=%lld", LCELLS[0], (long long)nxyz);
+    SocGrid G{};
+    G.NX = NX; G.NY = NY; G.NZ = NZ; G.LEVELS = LEVELS; G.NXYZ = (int)nxyz;
+    int64_t cells = 0;
+    for (int l = 0; l < LEVELS; l++) {
+        if (LCELLS[l] < 0 || (l > 0 && LCELLS[l] % 8 != 0))
+            return fail(c, SOC_ERR_ARG, "soc_set_grid: LCELLS[%d]=%d is not a whole number of octets", l, LCELLS[l]);
+        G.OFF[l] = (int)cells;
+        G.LCELLS[l] = LCELLS[l];
+        cells += LCELLS[l];
+        if (cells > 2147483647LL) return fail(c, SOC_ERR_ARG, "soc_set_grid: more than 2^31-1 cells");
+    }
+    G.CELLS = (int)cells;
+    // validate links on the host: every parent must point at an aligned octet of the next level
+    for (int l = 0; l < LEVELS; l++) {
+        const float *d = DENS + G.OFF[l];
+        const int nchild = (l + 1 < LEVELS) ? LCELLS[l + 1] : 0;
+        for (int i = 0; i < LCELLS[l]; i++) {
+            float v = d[i];
+            if (v != v) return fail(c, SOC_ERR_ARG, "soc_set_grid: NaN density at level %d cell %d", l, i);
+            if (!(v > 0.0f)) {
+                uint32_t bits;
+                memcpy(&bits, &v, 4);
+                int first = (int)(bits ^ 0x80000000u);
+                if (first < 0 || first % 8 != 0 || first + 8 > nchild)
+                    return fail(c, SOC_ERR_ARG, "soc_set_grid: level %d cell %d: value %g is not a density and not a valid child link", l, i, (double)v);
+            }
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, dev_alloc(&c->dDENS, (size_t)cells));
+    HIPCHK(c, hipMemcpy(c->dDENS, DENS, (size_t)cells * 4, hipMemcpyHostToDevice));
+    c->npar = cells - nxyz;
+    HIPCHK(c, dev_alloc(&c->dPAR, (size_t)c->npar));
+    HIPCHK(c, hipMemset(c->dPAR, 0, (size_t)(c->npar ? c->npar : 1) * 4));
+    G.DENS = c->dDENS;
+    G.PAR = c->dPAR;
+    if ((int64_t)G.CELLS != c->G.CELLS || !c->have_grid) {
+        // tallies follow the cell count (unless the caller bound its own memory)
+        if (c->own_TABS || !c->dTABS) { c->dTABS = nullptr; HIPCHK(c, dev_alloc(&c->dTABS, (size_t)cells)); c->own_TABS = true; HIPCHK(c, hipMemset(c->dTABS, 0, (size_t)cells * 4)); }
+        if (c->own_INT || !c->dINT) { c->dINT = nullptr; HIPCHK(c, dev_alloc(&c->dINT, (size_t)cells)); c->own_INT = true; HIPCHK(c, hipMemset(c->dINT, 0, (size_t)cells * 4)); }
+        if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
+        c->have_emit = false;
+    }
+    c->G = G;
+    c->have_grid = true;
+    HIPCHK(c, soc_launch_parents(c->G, c->dPAR, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!(ps_method == 0 || ps_method == 1 || ps_method == 2 || ps_method == 4 || ps_method == 5))
+        return fail(c, SOC_ERR_ARG, "soc_set_features: PS_METHOD %d not supported (0,1,2,4,5)", ps_method);
+    if (use_emweight < 0 || use_emweight > 1)
+        return fail(c, SOC_ERR_ARG, "soc_set_features: USE_EMWEIGHT %d not supported (0,1)", use_emweight);
+    c->with_int = with_int ? 1 : 0;
+    c->ps_method = ps_method;
+    c->use_emweight = use_emweight;
+    return SOC_OK;
+}
+
+int soc_set_optical(soc_ctx *c, const float *ABS, const float *SCA, int ndust)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!ABS || !SCA || ndust != 1) return fail(c, SOC_ERR_ARG, "soc_set_optical: need ABS, SCA with ndust==1 (WITH_MSF is not supported)");
+    c->ABS = ABS[0];
+    c->SCA = SCA[0];
+    c->have_optical = true;
+    return SOC_OK;
+}
+
+int soc_set_opt(soc_ctx *c, const float *OPT)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_opt: call soc_set_grid first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!OPT) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
+        return SOC_OK;
+    }
+    if (!c->dOPT) HIPCHK(c, dev_alloc(&c->dOPT, (size_t)c->G.CELLS));
+    HIPCHK(c, hipMemcpyAsync(c->dOPT, OPT, (size_t)c->G.CELLS * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BINS)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!CSC || BINS < 1 || BINS > 16000) return fail(c, SOC_ERR_ARG, "soc_set_scatter_table: need CSC and 1 <= BINS <= 16000 (got %d)", BINS);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (BINS != c->BINS || !c->dCSC) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dCSC, (size_t)BINS));
+        HIPCHK(c, dev_alloc(&c->dDSC, (size_t)BINS));
+        c->BINS = BINS;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dCSC, CSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
+    if (DSC) HIPCHK(c, hipMemcpyAsync(c->dDSC, DSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffer may be reused by the caller
+    return SOC_OK;
+}
+
+int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_emission: call soc_set_grid first");
+    if (!EMIT) return fail(c, SOC_ERR_ARG, "soc_set_emission: EMIT is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->G.CELLS;
+    if (!c->have_emit) {
+        HIPCHK(c, dev_alloc(&c->dEMIT, n));
+        HIPCHK(c, dev_alloc(&c->dEMWEI, n));
+        HIPCHK(c, hipMemset(c->dEMWEI, 0, n * 4));
+        c->have_emit = true;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dEMIT, EMIT, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (EMWEI) HIPCHK(c, hipMemcpyAsync(c->dEMWEI, EMWEI, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+static float *tally_buf(soc_ctx *c, int which)
+{
+    if (which == SOC_TALLY_TABS) return c->dTABS;
+    if (which == SOC_TALLY_INT) return c->dINT;
+    return nullptr;
+}
+
+int soc_zero(soc_ctx *c, int tag)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_zero: call soc_set_grid first");
+    float *b = tally_buf(c, tag);
+    if (!b) return fail(c, SOC_ERR_ARG, "soc_zero: tag %d", tag);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(b, 0, (size_t)c->G.CELLS * 4, c->stream));
+    return SOC_OK;
+}
+
+// base offset of the streams: (ulong)(fmod(SEED*7.0f*PI,1.0f)*4294967296L), kernel_ASOC.c:77
+static uint64_t seed_base(float SEED)
+{
+    volatile float a = SEED * 7.0f;
+    volatile float b = a * 3.1415926535897f;
+    volatile float f = fmodf(b, 1.0f);
+    volatile float g = f * 4294967296.0f;
+    return (uint64_t)g;
+}
+
+static uint64_t seed_mul(float SEED)
+{
+    return soc_mulmod(SOC_MWC_BASEID, soc_powmod(SOC_MWC_A, seed_base(SEED)));
+}
+
+static int check_launch(soc_ctx *c, const char *who, int BATCH, int GLOBAL, int gid_first, int gid_count)
+{
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "%s: call soc_set_grid first", who);
+    if (!c->dCSC) return fail(c, SOC_ERR_STATE, "%s: call soc_set_scatter_table first", who);
+    if (!c->dOPT && !c->have_optical) return fail(c, SOC_ERR_STATE, "%s: call soc_set_optical or soc_set_opt first", who);
+    if (BATCH < 0) return fail(c, SOC_ERR_ARG, "%s: BATCH=%d", who, BATCH);
+    if (GLOBAL < 1 || gid_first < 0 || gid_count < 0 || (int64_t)gid_first + gid_count > GLOBAL)
+        return fail(c, SOC_ERR_ARG, "%s: work-item range [%d,+%d) outside GLOBAL=%d", who, gid_first, gid_count, GLOBAL);
+    return SOC_OK;
+}
+
+static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH, float SEED, float BG, float TW,
+                     int GLOBAL, int gid_first, int gid_count)
+{
+    memset(&S, 0, sizeof S);
+    S.SOURCE = SOURCE; S.BATCH = BATCH; S.GLOBAL = GLOBAL;
+    S.PS_METHOD = c->ps_method; S.BINS = c->BINS; S.USE_EMWEIGHT = c->use_emweight;
+    S.gid0 = (uint32_t)gid_first; S.gid_count = (uint32_t)gid_count;
+    S.seed_mul = seed_mul(SEED); S.seed_tab = c->dSeedTab;
+    S.ABS = c->ABS; S.SCA = c->SCA; S.BG = BG; S.TW = TW;
+    S.CSC = c->dCSC; S.OPT = c->dOPT;
+    S.EMIT = c->dEMIT; S.EMWEI = c->dEMWEI;
+    S.TABS = c->dTABS; S.INT = c->dINT;
+    S.stats = c->dStats;
+    V.octree = c->G.LEVELS > 1;
+    V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);   // DIMLIM, kernel_ASOC_aux.c:25-37
+    V.abu = c->dOPT != nullptr;
+    V.wint = c->with_int;
+}
+
+int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
+               const float *PSPOS, const float *PS, int NO_PS,
+               const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
+               int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (SOURCE != 0 && SOURCE != 1) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE=%d (0 point sources, 1 background)", SOURCE);
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
+    if (SOURCE == 0) {
+        if (NO_PS < 1 || !PSPOS || !PS) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE=0 needs PSPOS, PS and NO_PS>=1");
+        if ((c->ps_method == 2 || c->ps_method == 5) && (!XPS_NSIDE || !XPS_SIDE || !XPS_AREA))
+            return fail(c, SOC_ERR_ARG, "soc_sim_pb: PS_METHOD %d needs XPS_NSIDE/XPS_SIDE/XPS_AREA", c->ps_method);
+        if (c->ps_method == 2) {
+            for (int i = 0; i < NO_PS; i++) {
+                if (XPS_NSIDE[i] < 0 || XPS_NSIDE[i] > 3) return fail(c, SOC_ERR_ARG, "soc_sim_pb: XPS_NSIDE[%d]=%d", i, XPS_NSIDE[i]);
+                for (int k = 0; k < 3; k++)
+                    if (XPS_SIDE[3 * i + k] < 0 || XPS_SIDE[3 * i + k] > 5) return fail(c, SOC_ERR_ARG, "soc_sim_pb: XPS_SIDE[%d]=%d", 3 * i + k, XPS_SIDE[3 * i + k]);
+            }
+        }
+        if (NO_PS > c->ps_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_alloc(&c->dPSPOS, (size_t)NO_PS));
+            HIPCHK(c, dev_alloc(&c->dPS, (size_t)NO_PS));
+            HIPCHK(c, dev_alloc(&c->dXPS_NSIDE, (size_t)NO_PS));
+            HIPCHK(c, dev_alloc(&c->dXPS_SIDE, (size_t)3 * NO_PS));
+            HIPCHK(c, dev_alloc(&c->dXPS_AREA, (size_t)3 * NO_PS));
+            c->ps_cap = NO_PS;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dPSPOS, PSPOS, (size_t)NO_PS * 16, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dPS, PS, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+        if (XPS_NSIDE) HIPCHK(c, hipMemcpyAsync(c->dXPS_NSIDE, XPS_NSIDE, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+        else           HIPCHK(c, hipMemsetAsync(c->dXPS_NSIDE, 0, (size_t)NO_PS * 4, c->stream));
+        if (XPS_SIDE)  HIPCHK(c, hipMemcpyAsync(c->dXPS_SIDE, XPS_SIDE, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+        else           HIPCHK(c, hipMemsetAsync(c->dXPS_SIDE, 0, (size_t)NO_PS * 12, c->stream));
+        if (XPS_AREA)  HIPCHK(c, hipMemcpyAsync(c->dXPS_AREA, XPS_AREA, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+        else           HIPCHK(c, hipMemsetAsync(c->dXPS_AREA, 0, (size_t)NO_PS * 12, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        S.NO_PS = NO_PS;
+        S.PSPOS = c->dPSPOS; S.PS = c->dPS;
+        S.XPS_NSIDE = c->dXPS_NSIDE; S.XPS_SIDE = c->dXPS_SIDE; S.XPS_AREA = c->dXPS_AREA;
+    } else {
+        S.NO_PS = 1;
+    }
+    HIPCHK(c, soc_launch_sim_pb(c->G, S, V, c->stream));
+    return SOC_OK;
+}
+
+int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
+               int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sim_cl: call soc_set_emission first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, SOURCE, BATCH, SEED, 0.0f, TW, GLOBAL, gid_first, gid_count);
+    S.NO_PS = 1;
+    HIPCHK(c, soc_launch_sim_cl(c->G, S, V, c->stream));
+    return SOC_OK;
+}
+
+int soc_sync(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_read_tally(soc_ctx *c, int which, float *out, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_read_tally: call soc_set_grid first");
+    float *b = tally_buf(c, which);
+    if (!b || !out || n < 0 || n > c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_read_tally: which=%d n=%lld", which, (long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_write_tally(soc_ctx *c, int which, const float *in, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_write_tally: call soc_set_grid first");
+    float *b = tally_buf(c, which);
+    if (!b || !in || n < 0 || n > c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_write_tally: which=%d n=%lld", which, (long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(b, in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+void *soc_tally_ptr(soc_ctx *c, int which) { return c ? (void *)tally_buf(c, which) : nullptr; }
+
+int soc_bind_tally(soc_ctx *c, int which, void *device_ptr)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!device_ptr || (which != SOC_TALLY_TABS && which != SOC_TALLY_INT)) return fail(c, SOC_ERR_ARG, "soc_bind_tally: which=%d ptr=%p", which, device_ptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (which == SOC_TALLY_TABS) {
+        if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
+        c->dTABS = (float *)device_ptr; c->own_TABS = false;
+    } else {
+        if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
+        c->dINT = (float *)device_ptr; c->own_INT = false;
+    }
+    return SOC_OK;
+}
+
+int soc_read_par(soc_ctx *c, int32_t *out, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_read_par: call soc_set_grid first");
+    if (!out || n < 0 || n > c->npar) return fail(c, SOC_ERR_ARG, "soc_read_par: n=%lld (have %lld)", (long long)n, (long long)c->npar);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) HIPCHK(c, hipMemcpy(out, c->dPAR, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SOC_OK;
+}
+
+int soc_stats(soc_ctx *c, uint64_t out[3], int reset)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[3];
+    HIPCHK(c, hipMemcpy(h, c->dStats, sizeof h, hipMemcpyDeviceToHost));
+    if (out) for (int i = 0; i < 3; i++) out[i] = h[i];
+    if (reset) HIPCHK(c, hipMemset(c->dStats, 0, sizeof h));
+    return SOC_OK;
+}
+
+int soc_timer_start(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return SOC_OK;
+}
+
+int soc_timer_stop(soc_ctx *c, float *elapsed_ms)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return SOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// probes
+// ---------------------------------------------------------------------------------------
+
+int soc_probe_rng(soc_ctx *c, float SEED, uint32_t gid_first, uint32_t n, int ndraw, uint32_t *state_xc, uint32_t *draws)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!state_xc || !draws || ndraw < 0 || n == 0) return fail(c, SOC_ERR_ARG, "soc_probe_rng: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t *dS = nullptr, *dD = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dS, (size_t)n * 8));
+    HIPCHK(c, hipMalloc((void **)&dD, (size_t)n * (ndraw ? ndraw : 1) * 4));
+    hipError_t e = soc_launch_seed_probe(seed_mul(SEED), c->dSeedTab, gid_first, n, ndraw, dS, dD, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(state_xc, dS, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ndraw) e = hipMemcpy(draws, dD, (size_t)n * ndraw * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dS);
+    (void)hipFree(dD);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_probe_rng: %s", hipGetErrorString(e));
+    return SOC_OK;
+}
+
+int soc_probe_math(soc_ctx *c, int fn, const float *x, float *y, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!x || !y || n <= 0) return fail(c, SOC_ERR_ARG, "soc_probe_math: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dy = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dx, (size_t)n * 4));
+    HIPCHK(c, hipMalloc((void **)&dy, (size_t)n * 4));
+    hipError_t e = hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = soc_launch_math_probe(fn, dx, dy, (long)n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_probe_math: %s", hipGetErrorString(e));
+    return SOC_OK;
+}
+
+int soc_probe_trace(soc_ctx *c, const float pos[3], const float dir[3], int maxsteps,
+                    int32_t *levels, int32_t *inds, float *ds, float endpos[3], int32_t *nsteps)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_probe_trace: call soc_set_grid first");
+    if (!pos || !dir || maxsteps < 1 || !levels || !inds || !ds || !endpos || !nsteps) return fail(c, SOC_ERR_ARG, "soc_probe_trace: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dIn = nullptr, *dDs = nullptr;
+    int *dLev = nullptr, *dN = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dIn, 9 * 4));
+    HIPCHK(c, hipMalloc((void **)&dDs, (size_t)maxsteps * 4));
+    HIPCHK(c, hipMalloc((void **)&dLev, (size_t)maxsteps * 8));
+    HIPCHK(c, hipMalloc((void **)&dN, 4));
+    float h[9] = { pos[0], pos[1], pos[2], dir[0], dir[1], dir[2], 0, 0, 0 };
+    SocVariant V;
+    V.octree = c->G.LEVELS > 1;
+    V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
+    V.abu = 0; V.wint = 0;
+    hipError_t e = hipMemcpy(dIn, h, sizeof h, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = soc_launch_trace(c->G, V, dIn, dIn + 3, maxsteps, dLev, dLev + maxsteps, dDs, dIn + 6, dN, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(nsteps, dN, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(levels, dLev, (size_t)maxsteps * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(inds, dLev + maxsteps, (size_t)maxsteps * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ds, dDs, (size_t)maxsteps * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(endpos, dIn + 6, 12, hipMemcpyDeviceToHost);
+    (void)hipFree(dIn);
+    (void)hipFree(dDs);
+    (void)hipFree(dLev);
+    (void)hipFree(dN);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_probe_trace: %s", hipGetErrorString(e));
+    return SOC_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,56 @@
+// soc_dev.h -- structures shared by the C-ABI host code (soc_capi.hip) and the kernels.
+#ifndef SOC_DEV_H
+#define SOC_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SOC_MAXL 16            /* hierarchy levels supported (reference models use <= 8) */
+
+// Model geometry.  The reference bakes these into the kernel with -D NX= ... -D CELLS=
+// (ASOC.py:344-362); here they are run-time kernel arguments.
+struct SocGrid {
+    int NX, NY, NZ, LEVELS, CELLS, NXYZ;
+    int OFF[SOC_MAXL];         /* first cell of each level (ASOC_aux.py:772)            */
+    int LCELLS[SOC_MAXL];      /* cells per level                                        */
+    const float *DENS;         /* [CELLS] density (>0) or child link (<=0)               */
+    const int   *PAR;          /* [CELLS-NXYZ] parent cell index within its level        */
+};
+
+// One launch of SimRAM_PB / SimRAM_CL (argument lists: kernel_ASOC.c:15-52, 1223-1256).
+struct SocSim {
+    int   SOURCE, BATCH, GLOBAL, PS_METHOD, NO_PS, BINS, USE_EMWEIGHT;
+    uint32_t gid0, gid_count;  /* this device runs logical work items [gid0, gid0+gid_count) */
+    uint64_t seed_mul;         /* BASEID * A^base mod M for this SEED                     */
+    const uint64_t *seed_tab;  /* 4 x 256 table of G^(b*256^k), see soc_rng.h             */
+    float ABS, SCA, BG, TW;
+    const float  *CSC;         /* [BINS] cumulative scattering function, current frequency */
+    const float2 *OPT;         /* [CELLS] (abs, sca) per cell when WITH_ABU               */
+    const float4 *PSPOS;       /* point-source positions (cl float3 = 16 bytes)           */
+    const float  *PS;
+    const int    *XPS_NSIDE, *XPS_SIDE;
+    const float  *XPS_AREA;
+    const float  *EMIT, *EMWEI;
+    float *TABS, *INT;
+    unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
+};
+
+// feature switches that the reference selects with #if; compiled ahead of time here
+struct SocVariant {
+    int octree;                /* LEVELS > 1                                              */
+    int dbl;                   /* Index() in double: NX > DIMLIM (kernel_ASOC_aux.c:25-37) */
+    int abu;                   /* WITH_ABU                                                */
+    int wint;                  /* INT tally: SAVE_INTENSITY in (1,2) or NOABSORBED==0     */
+};
+
+hipError_t soc_launch_sim_pb(const SocGrid &G, const SocSim &S, const SocVariant &V, hipStream_t st);
+hipError_t soc_launch_sim_cl(const SocGrid &G, const SocSim &S, const SocVariant &V, hipStream_t st);
+hipError_t soc_launch_parents(const SocGrid &G, int *PAR, hipStream_t st);
+hipError_t soc_launch_seed_probe(uint64_t seed_mul, const uint64_t *tab, uint32_t gid0, uint32_t n,
+                                 int ndraw, uint32_t *out_state, uint32_t *out_draws, hipStream_t st);
+hipError_t soc_launch_math_probe(int fn, const float *x, float *y, long n, hipStream_t st);
+hipError_t soc_launch_trace(const SocGrid &G, const SocVariant &V, const float *pos, const float *dir,
+                            int maxsteps, int *levels, int *inds, float *dss, float *endpos, int *nsteps,
+                            hipStream_t st);
+
+#endif

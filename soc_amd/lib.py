@@ -1,0 +1,256 @@
+"""ctypes binding of libsoc_hip.so (include/soc_hip.h) and a thin ``Engine`` object.
+
+The engine is the HIP library and nothing else: if the library cannot be loaded or no GPU
+is present the constructor raises -- there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBNAME = os.path.join(HERE, "libsoc_hip.so")
+
+TALLY_TABS = 0
+TALLY_INT = 1
+
+_F = C.POINTER(C.c_float)
+_I = C.POINTER(C.c_int32)
+_U = C.POINTER(C.c_uint32)
+
+# every symbol include/soc_hip.h declares: (restype, argtypes)
+API = {
+    "soc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "soc_destroy": (None, [C.c_void_p]),
+    "soc_last_error": (C.c_char_p, [C.c_void_p]),
+    "soc_version": (C.c_char_p, []),
+    "soc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "soc_set_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _I, _F]),
+    "soc_set_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
+    "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
+    "soc_set_scatter_table": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
+    "soc_set_emission": (C.c_int, [C.c_void_p, _F, _F]),
+    "soc_zero": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_sim_pb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                             _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
+    "soc_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                             C.c_int, C.c_int, C.c_int]),
+    "soc_sync": (C.c_int, [C.c_void_p]),
+    "soc_read_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
+    "soc_write_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
+    "soc_tally_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "soc_bind_tally": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "soc_read_par": (C.c_int, [C.c_void_p, _I, C.c_int64]),
+    "soc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "soc_timer_start": (C.c_int, [C.c_void_p]),
+    "soc_timer_stop": (C.c_int, [C.c_void_p, _F]),
+    "soc_probe_rng": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int, _U, _U]),
+    "soc_probe_math": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_int64]),
+    "soc_probe_trace": (C.c_int, [C.c_void_p, _F, _F, C.c_int, _I, _I, _F, _F, _I]),
+}
+
+_lib = None
+
+
+class SocError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libsoc_hip.so and declare every prototype.  Raises SocError if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIBNAME
+    if not os.path.exists(path):
+        raise SocError("%s not found: build it with `python -m soc_amd.build` "
+                       "(there is no CPU fallback)" % path)
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise SocError("cannot load %s: %s" % (path, e))
+    for name, (res, args) in API.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(_F)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+class Engine:
+    """One GPU's packet engine.  Method names follow the C ABI one to one."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.soc_create(int(device), C.byref(h))
+        if rc != 0:
+            raise SocError("soc_create(device=%d) failed: %s" %
+                           (device, self.lib.soc_last_error(None).decode()))
+        self.h = h
+        self.device = int(device)
+        self.CELLS = 0
+        self.NPAR = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.soc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SocError("%s (code %d)" % (self.lib.soc_last_error(self.h).decode(), rc))
+
+    # ---- model ----
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.soc_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_grid(self, NX, NY, NZ, LEVELS, LCELLS, DENS):
+        LCELLS = np.ascontiguousarray(LCELLS, np.int32)
+        DENS = np.ascontiguousarray(DENS, np.float32)
+        if len(LCELLS) < LEVELS or DENS.size != int(LCELLS[:LEVELS].sum()):
+            raise SocError("set_grid: DENS has %d values, LCELLS sums to %d" % (DENS.size, int(LCELLS[:LEVELS].sum())))
+        self._chk(self.lib.soc_set_grid(self.h, int(NX), int(NY), int(NZ), int(LEVELS), _i(LCELLS), _f(DENS)))
+        self.CELLS = int(DENS.size)
+        self.NPAR = self.CELLS - int(NX) * int(NY) * int(NZ)
+
+    def set_cloud(self, cloud):
+        self.set_grid(cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, cloud.LCELLS, cloud.DENS)
+
+    def set_features(self, with_int=0, ps_method=0, use_emweight=0):
+        self._chk(self.lib.soc_set_features(self.h, int(with_int), int(ps_method), int(use_emweight)))
+
+    def set_optical(self, ABS, SCA):
+        a = np.asarray([ABS], np.float32).ravel()
+        s = np.asarray([SCA], np.float32).ravel()
+        self._chk(self.lib.soc_set_optical(self.h, _f(a), _f(s), 1))
+
+    def set_opt(self, OPT):
+        if OPT is None:
+            self._chk(self.lib.soc_set_opt(self.h, None))
+            return
+        OPT = np.ascontiguousarray(OPT, np.float32)
+        if OPT.size != 2 * self.CELLS:
+            raise SocError("set_opt: OPT must hold 2*CELLS floats")
+        self._chk(self.lib.soc_set_opt(self.h, _f(OPT)))
+
+    def set_scatter_table(self, DSC, CSC):
+        CSC = np.ascontiguousarray(CSC, np.float32)
+        DSC = None if DSC is None else np.ascontiguousarray(DSC, np.float32)
+        self._chk(self.lib.soc_set_scatter_table(self.h, _f(DSC), _f(CSC), int(CSC.size)))
+
+    def set_emission(self, EMIT, EMWEI=None):
+        EMIT = np.ascontiguousarray(EMIT, np.float32)
+        EMWEI = None if EMWEI is None else np.ascontiguousarray(EMWEI, np.float32)
+        if EMIT.size != self.CELLS or (EMWEI is not None and EMWEI.size != self.CELLS):
+            raise SocError("set_emission: arrays must hold CELLS floats")
+        self._chk(self.lib.soc_set_emission(self.h, _f(EMIT), _f(EMWEI)))
+
+    # ---- launches ----
+    def zero(self, tag):
+        self._chk(self.lib.soc_zero(self.h, int(tag)))
+
+    def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None,
+               GLOBAL=None, gid_first=0, gid_count=None):
+        NO_PS = 0
+        pspos = ps = nside = side = area = None
+        if SOURCE == 0:
+            p = np.asarray(PSPOS, np.float32)
+            if p.ndim == 1:
+                p = p.reshape(-1, 3)
+            NO_PS = p.shape[0]
+            pspos = np.zeros((NO_PS, 4), np.float32)
+            pspos[:, :3] = p[:, :3]
+            ps = np.ascontiguousarray(PS, np.float32)
+            if XPS is not None:
+                nside = np.ascontiguousarray(XPS[0], np.int32)
+                side = np.ascontiguousarray(XPS[1], np.int32)
+                area = np.ascontiguousarray(XPS[2], np.float32)
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sim_pb(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED),
+                                      np.float32(BG), np.float32(TW), _f(pspos), _f(ps), NO_PS,
+                                      _i(nside), _i(side), _f(area), int(GLOBAL), int(gid_first), int(gid_count)))
+
+    def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sim_cl(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED),
+                                      np.float32(TW), int(GLOBAL), int(gid_first), int(gid_count)))
+
+    def sync(self):
+        self._chk(self.lib.soc_sync(self.h))
+
+    # ---- results ----
+    def read_tally(self, which=TALLY_TABS):
+        out = np.zeros(self.CELLS, np.float32)
+        self._chk(self.lib.soc_read_tally(self.h, int(which), _f(out), self.CELLS))
+        return out
+
+    def write_tally(self, which, values):
+        v = np.ascontiguousarray(values, np.float32)
+        self._chk(self.lib.soc_write_tally(self.h, int(which), _f(v), v.size))
+
+    def tally_ptr(self, which=TALLY_TABS):
+        return self.lib.soc_tally_ptr(self.h, int(which))
+
+    def bind_tally(self, which, device_ptr):
+        self._chk(self.lib.soc_bind_tally(self.h, int(which), C.c_void_p(device_ptr)))
+
+    def read_par(self):
+        out = np.zeros(max(self.NPAR, 1), np.int32)
+        self._chk(self.lib.soc_read_par(self.h, _i(out), self.NPAR))
+        return out[:self.NPAR]
+
+    def stats(self, reset=False):
+        out = (C.c_uint64 * 3)()
+        self._chk(self.lib.soc_stats(self.h, out, int(reset)))
+        return dict(tally_events=int(out[0]), packets=int(out[1]), scatterings=int(out[2]))
+
+    def timer_start(self):
+        self._chk(self.lib.soc_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.soc_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- probes ----
+    def probe_rng(self, SEED, gid_first, n, ndraw):
+        st = np.zeros((n, 2), np.uint32)
+        dr = np.zeros((n, max(ndraw, 1)), np.uint32)
+        self._chk(self.lib.soc_probe_rng(self.h, np.float32(SEED), int(gid_first), int(n), int(ndraw),
+                                         st.ctypes.data_as(_U), dr.ctypes.data_as(_U)))
+        return st, dr[:, :ndraw]
+
+    def probe_math(self, fn, x):
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, rcp=7)[fn]
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        self._chk(self.lib.soc_probe_math(self.h, code, _f(x), _f(y), x.size))
+        return y
+
+    def probe_trace(self, pos, direction, maxsteps=100000):
+        pos = np.ascontiguousarray(pos, np.float32)
+        d = np.ascontiguousarray(direction, np.float32)
+        lev = np.zeros(maxsteps, np.int32)
+        ind = np.zeros(maxsteps, np.int32)
+        ds = np.zeros(maxsteps, np.float32)
+        end = np.zeros(3, np.float32)
+        n = C.c_int32()
+        self._chk(self.lib.soc_probe_trace(self.h, _f(pos), _f(d), maxsteps, _i(lev), _i(ind), _f(ds), _f(end), C.byref(n)))
+        n = n.value
+        return lev[:n].copy(), ind[:n].copy(), ds[:n].copy(), end

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_soc():
+    from oracle.pyoracle import Oracle
+    return Oracle("soc")
+
+
+@pytest.fixture(scope="session")
+def oracle_libm():
+    from oracle.pyoracle import Oracle
+    return Oracle("libm")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine on cuda:0.  Fails loudly (no fallback) when the library or GPU is missing."""
+    from soc_amd.lib import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,41 @@
+"""Helpers shared by the parity tests: run one oracle ``Job`` on the HIP engine."""
+import numpy as np
+
+
+def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True):
+    """Execute ``job`` (oracle.pyoracle.Job) through the C ABI.  Returns (TABS, INT, stats)."""
+    cl = job.cloud
+    eng.set_cloud(cl)
+    eng.set_features(with_int=job.WITH_INT, ps_method=job.PS_METHOD, use_emweight=job.USE_EMWEIGHT)
+    eng.set_scatter_table(job.DSC, job.CSC)
+    eng.set_optical(job.ABS, job.SCA)
+    eng.set_opt(job.OPT)
+    if zero:
+        eng.zero(0)
+        eng.zero(1)
+    eng.stats(reset=True)
+    gid_count = job.GLOBAL - gid_first if gid_count is None else gid_count
+    if kind == 0:
+        xps = (job.XPS_NSIDE, job.XPS_SIDE, job.XPS_AREA)
+        eng.sim_pb(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.BG, job.TW,
+                   PSPOS=job.PSPOS[:, :3], PS=job.PS, XPS=xps, GLOBAL=job.GLOBAL,
+                   gid_first=gid_first, gid_count=gid_count)
+    else:
+        eng.set_emission(job.EMIT, job.EMWEI)
+        eng.sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL,
+                   gid_first=gid_first, gid_count=gid_count)
+    eng.sync()
+    return eng.read_tally(0), eng.read_tally(1), eng.stats()
+
+
+def assert_tally_close(got, want, rtol=1e-5, floor_frac=1e-6):
+    """Per-cell comparison: relative tolerance on cells that carry signal, absolute floor
+    (a fraction of the largest tally) elsewhere.  Differences between identical-trajectory
+    runs come only from the order of fp32 atomic adds."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = np.abs(want).max() if want.size else 0.0
+    tol = rtol * np.abs(want) + floor_frac * rtol * scale
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), "%d of %d cells differ; worst rel %.3e" % (
+        bad.sum(), bad.size, (np.abs(got - want) / np.maximum(np.abs(want), 1e-300))[bad].max())
