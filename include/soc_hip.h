@@ -40,7 +40,7 @@ void soc_destroy(soc_ctx *ctx);
 const char *soc_last_error(const soc_ctx *ctx);   /* ctx may be NULL: last creation error */
 const char *soc_version(void);
 
-/* run on an externally owned HIP stream (e.g. the caller's torch stream); NULL = own stream */
+/* run on an externally owned HIP stream (e.g. the stream of the caller's framework); NULL = own stream */
 int soc_set_stream(soc_ctx *ctx, void *hip_stream);
 
 /* replaces the -D NX,NY,NZ,LEVELS,CELLS macros (ASOC.py:344-362), the LCELLS/OFF/DENS

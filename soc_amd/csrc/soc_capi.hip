@@ -103,15 +103,7 @@ int soc_create(int device, soc_ctx **out)
     c->stream = c->own_stream;
     // seed tables: T[k][b] = G^(b*256^k) mod M with G = A^(2^38) mod M  (soc_rng.h)
     std::vector<uint64_t> tab(1024);
-    uint64_t g = soc_powmod(SOC_MWC_A, SOC_STREAM_GAP);
-    for (int k = 0; k < 4; k++) {
-        uint64_t acc = 1;
-        for (int b = 0; b < 256; b++) {
-            tab[256 * k + b] = acc;
-            acc = soc_mulmod(acc, g);
-        }
-        g = acc;                                      // g^(256)
-    }
+    soc_build_seed_table(tab.data());
     if ((e = hipMalloc((void **)&c->dSeedTab, 1024 * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMemcpy(c->dSeedTab, tab.data(), 1024 * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&c->dStats, 3 * sizeof(unsigned long long))) != hipSuccess ||
@@ -300,21 +292,6 @@ int soc_zero(soc_ctx *c, int tag)
     return SOC_OK;
 }
 
-// base offset of the streams: (ulong)(fmod(SEED*7.0f*PI,1.0f)*4294967296L), kernel_ASOC.c:77
-static uint64_t seed_base(float SEED)
-{
-    volatile float a = SEED * 7.0f;
-    volatile float b = a * 3.1415926535897f;
-    volatile float f = fmodf(b, 1.0f);
-    volatile float g = f * 4294967296.0f;
-    return (uint64_t)g;
-}
-
-static uint64_t seed_mul(float SEED)
-{
-    return soc_mulmod(SOC_MWC_BASEID, soc_powmod(SOC_MWC_A, seed_base(SEED)));
-}
-
 static int check_launch(soc_ctx *c, const char *who, int BATCH, int GLOBAL, int gid_first, int gid_count)
 {
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "%s: call soc_set_grid first", who);
@@ -333,7 +310,7 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     S.SOURCE = SOURCE; S.BATCH = BATCH; S.GLOBAL = GLOBAL;
     S.PS_METHOD = c->ps_method; S.BINS = c->BINS; S.USE_EMWEIGHT = c->use_emweight;
     S.gid0 = (uint32_t)gid_first; S.gid_count = (uint32_t)gid_count;
-    S.seed_mul = seed_mul(SEED); S.seed_tab = c->dSeedTab;
+    S.seed_mul = soc_seed_mul(SEED); S.seed_tab = c->dSeedTab;
     S.ABS = c->ABS; S.SCA = c->SCA; S.BG = BG; S.TW = TW;
     S.CSC = c->dCSC; S.OPT = c->dOPT;
     S.EMIT = c->dEMIT; S.EMWEI = c->dEMWEI;
@@ -519,7 +496,7 @@ int soc_probe_rng(soc_ctx *c, float SEED, uint32_t gid_first, uint32_t n, int nd
     uint32_t *dS = nullptr, *dD = nullptr;
     HIPCHK(c, hipMalloc((void **)&dS, (size_t)n * 8));
     HIPCHK(c, hipMalloc((void **)&dD, (size_t)n * (ndraw ? ndraw : 1) * 4));
-    hipError_t e = soc_launch_seed_probe(seed_mul(SEED), c->dSeedTab, gid_first, n, ndraw, dS, dD, c->stream);
+    hipError_t e = soc_launch_seed_probe(soc_seed_mul(SEED), c->dSeedTab, gid_first, n, ndraw, dS, dD, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(state_xc, dS, (size_t)n * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess && ndraw) e = hipMemcpy(draws, dD, (size_t)n * ndraw * 4, hipMemcpyDeviceToHost);

@@ -96,4 +96,37 @@ SOC_RNG_HD float soc_rand(soc_rng_t *s)
     return (float)soc_next_uint(s) * 2.3283064365386963e-10f;
 }
 
+// ---- host-side per-launch constants -------------------------------------------------------
+
+// base offset of all streams: (ulong)(fmod(SEED*7.0f*PI,1.0f)*4294967296L), kernel_ASOC.c:77.
+// volatile keeps every intermediate in fp32 whatever the host compiler's excess-precision rules.
+static inline uint64_t soc_seed_base(float SEED)
+{
+    volatile float a = SEED * 7.0f;
+    volatile float b = a * 3.1415926535897f;
+    volatile float f = b - (float)(long long)b;      /* fmod(b, 1.0f): exact for |b| < 2^63 */
+    volatile float g = f * 4294967296.0f;
+    return (uint64_t)g;
+}
+
+// BASEID * A^base mod M
+static inline uint64_t soc_seed_mul(float SEED)
+{
+    return soc_mulmod(SOC_MWC_BASEID, soc_powmod(SOC_MWC_A, soc_seed_base(SEED)));
+}
+
+// T[k][b] = G^(b * 256^k) mod M, G = A^(2^38) mod M; tab holds 4*256 entries
+static inline void soc_build_seed_table(uint64_t *tab)
+{
+    uint64_t g = soc_powmod(SOC_MWC_A, SOC_STREAM_GAP);
+    for (int k = 0; k < 4; k++) {
+        uint64_t acc = 1;
+        for (int b = 0; b < 256; b++) {
+            tab[256 * k + b] = acc;
+            acc = soc_mulmod(acc, g);
+        }
+        g = acc;                                     /* g^256 */
+    }
+}
+
 #endif  // SOC_RNG_H

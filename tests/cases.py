@@ -1,0 +1,88 @@
+"""Named simulation cases shared by the golden-vector generator and the parity tests.
+
+Every case is a small, seeded model that the CPU oracle finishes in well under a second.
+``ref`` names the x86 build of the reference kernels (oracle/build.py: ref_models) whose
+baked-in geometry matches the case; ``kind`` 0 = SimRAM_PB, 1 = SimRAM_CL.
+"""
+import numpy as np
+
+from oracle.pyoracle import Job
+from soc_amd import synth
+
+_DSC, _CSC = synth.hg_scattering_table(0.6)
+_DSC0, _CSC0 = synth.hg_scattering_table(0.0)
+
+
+def _c8():
+    return synth.cartesian_cloud(8, seed=3)
+
+
+def _oct8():
+    return synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+
+
+def _opt(cells, seed=5):
+    rr = np.random.default_rng(seed)
+    opt = np.zeros((cells, 2), np.float32)
+    opt[:, 0] = 1e-4 * rr.uniform(0.5, 2, cells)
+    opt[:, 1] = 3e-4 * rr.uniform(0.5, 2, cells)
+    return opt
+
+
+_PS_IN = np.array([[4.3, 4.2, 4.1], [2.5, 6.5, 3.3]], np.float32)
+_PS_EXT = np.array([[4.0, 4.0, 20.0], [4.3, 4.2, 4.1]], np.float32)
+_XPS2 = (np.array([1, 0], np.int32), np.array([4, 0, 0, 0, 0, 0], np.int32),
+         np.array([1.0, 1, 1, 1, 1, 1], np.float32))
+_XPS5 = (np.array([1, 0], np.int32), np.array([4, 0, 0, 0, 0, 0], np.int32),
+         np.array([0.9, 1, 1, 1, 1, 1], np.float32))
+
+
+def _emit(cloud):
+    return np.where(cloud.DENS > 0, cloud.DENS * 1e-3, 0).astype(np.float32)
+
+
+def _emwei(cloud, seed=5):
+    rr = np.random.default_rng(seed)
+    return rr.uniform(0, 3, cloud.CELLS).astype(np.float32)
+
+
+CASES = {
+    # name: (ref build, kind, job factory)
+    "bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=50, SEED=0.6004384)),
+    "bg_c8_thin": ("c8", 0, lambda: Job(_c8(), _CSC0, ABS=1e-7, SCA=2e-7, SOURCE=1, BATCH=20, SEED=0.25, BG=3.0)),
+    "bg_c8_int": ("c8int", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=20, SEED=0.123,
+                                            WITH_INT=1, TW=2.5)),
+    "bg_c8_abu": ("c8abu", 0, lambda: Job(_c8(), _CSC, SOURCE=1, BATCH=20, SEED=0.3, OPT=_opt(512))),
+    "bg_r654": ("r654", 0, lambda: Job(synth.cartesian_cloud(6, seed=4, NY=5, NZ=4), _CSC, ABS=1e-4, SCA=3e-4,
+                                         SOURCE=1, BATCH=30, SEED=0.77)),
+    "bg_oct8": ("oct8", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=30, SEED=0.41)),
+    "bg_oct4": ("oct4", 0, lambda: Job(synth.kat_octree(), _CSC, ABS=2e-3, SCA=4e-3, SOURCE=1, BATCH=40, SEED=0.51)),
+    "ps_in_c8": ("c8ps0", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                           PSPOS=_PS_IN, PS=[1.0, 2.0])),
+    "ps_ext0_c8": ("c8ps0", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                             PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=0, XPS=_XPS2)),
+    "ps_ext1_c8": ("c8ps1", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                             PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=1, XPS=_XPS2)),
+    "ps_ext2_c8": ("c8ps2", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                             PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=2, XPS=_XPS2)),
+    "ps_ext4_c8": ("c8ps4", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                             PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=4, XPS=_XPS2)),
+    "ps_ext5_c8": ("c8ps5", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
+                                             PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=5, XPS=_XPS5)),
+    "cl_oct8": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                         EMIT=_emit(_oct8()))),
+    "cl_oct8_emw": ("oct8emw", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9,
+                                                GLOBAL=128, EMIT=_emit(_oct8()), EMWEI=_emwei(_oct8()),
+                                                USE_EMWEIGHT=1)),
+    "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
+                                     EMIT=_emit(_c8()))),
+}
+
+# fixed rays for step-by-step traces: (ref build, cloud factory, pos, dir)
+RAYS = {
+    "ray_c32": ("c32", lambda: synth.cartesian_cloud(32, uniform=1.0), [1e-4, 10.3, 20.7], [0.8, 0.36, 0.48]),
+    "ray_oct4": ("oct4", synth.kat_octree, [1e-4, 1.3, 1.2], list(np.array([0.9, 0.2, 0.25]) / np.sqrt(0.9 ** 2 + 0.2 ** 2 + 0.25 ** 2))),
+    "ray_oct8_a": ("oct8", _oct8, [1e-4, 3.37, 5.21], [0.70, 0.55, -0.4555217]),
+    "ray_oct8_b": ("oct8", _oct8, [7.9999, 6.1, 2.2], [-0.6, -0.3, 0.7416198]),
+    "ray_oct8_c": ("oct8", _oct8, [4.4, 1e-4, 4.6], [0.02, 0.9995999, -0.02]),
+}

@@ -1,0 +1,94 @@
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container: it executes the x86 builds of the reference's kernels
+(oracle/_ref, compiled from /root/reference by oracle/build.py) on the seeded cases of
+tests/cases.py and stores inputs + outputs as small .npz files.  The vectors are data --
+no reference source travels.  Work items are executed sequentially, so the fp32 summation
+order (and with it every bit of TABS) is reproducible.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from oracle.pyoracle import Ref, Job  # noqa: E402
+from soc_amd import synth            # noqa: E402
+import cases                         # noqa: E402
+
+
+def main():
+    # ---- RNG: stream states and draws (integer, exact) ----
+    r = Ref("c8")
+    seeds = [0.6004384, 0.7853981634, 0.25, 1.0]
+    gids = [0, 1, 2, 63, 64, 255, 256, 65535, 65536, 49151, 786431, 3145727, 16777215, 16777216]
+    states, draws, bases = [], [], []
+    for s in seeds:
+        for g in gids:
+            x, c = r.seed(s, g)
+            u, _ = r.draws(x, c, 8)
+            states.append((x, c))
+            draws.append(u)
+    np.savez(os.path.join(HERE, "rng.npz"), seeds=np.asarray(seeds, np.float32), gids=np.asarray(gids, np.int64),
+             states=np.asarray(states, np.uint32).reshape(len(seeds), len(gids), 2),
+             draws=np.asarray(draws, np.uint32).reshape(len(seeds), len(gids), 8))
+
+    # ---- fixed rays: (level, ind, ds) per step ----
+    out = {}
+    for name, (ref, mk, pos, d) in cases.RAYS.items():
+        cloud = mk()
+        job = Job(cloud, np.linspace(1, -1, 2500))
+        lev, ind, ds, end = Ref(ref).trace(job, pos, np.asarray(d, np.float32))
+        out[name + "_pos"] = np.asarray(pos, np.float32)
+        out[name + "_dir"] = np.asarray(d, np.float32)
+        out[name + "_lev"], out[name + "_ind"], out[name + "_ds"], out[name + "_end"] = lev, ind, ds, end
+    k = synth.kat_octree()
+    out["par_oct4"] = Ref("oct4").parents(Job(k, np.linspace(1, -1, 2500)))
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    out["par_oct8"] = Ref("oct8").parents(Job(o8, np.linspace(1, -1, 2500)))
+    np.savez(os.path.join(HERE, "rays.npz"), **out)
+
+    # ---- Scatter / Deflect on fixed inputs ----
+    dsc, csc = synth.hg_scattering_table(0.6)
+    rng = np.random.default_rng(99)
+    dirs = rng.standard_normal((64, 3))
+    dirs /= np.sqrt((dirs ** 2).sum(1, keepdims=True))
+    dirs = dirs.astype(np.float32)
+    dirs[0] = [0, 0, 1]
+    dirs[1] = [0, 0, -1]
+    dirs[2] = [1, 0, 0]
+    dirs[3] = [5e-5, 5e-5, 1.0]
+    sc_out, sc_state = [], []
+    for i, d in enumerate(dirs):
+        x, c = r.seed(0.3, i)
+        nd, st = r.scatter(d, csc, x, c)
+        sc_out.append(nd)
+        sc_state.append(st)
+    ct = rng.uniform(-1, 1, 64).astype(np.float32)
+    ph = rng.uniform(0, 2 * np.pi, 64).astype(np.float32)
+    df_out = [r.deflect(d, a, b) for d, a, b in zip(dirs, ct, ph)]
+    np.savez(os.path.join(HERE, "scatter.npz"), dirs=dirs, csc=csc, scatter_out=np.asarray(sc_out, np.float32),
+             scatter_state=np.asarray(sc_state, np.uint32), cos_theta=ct, phi=ph,
+             deflect_out=np.asarray(df_out, np.float32))
+
+    # ---- full simulations ----
+    out = {}
+    for name, (ref, kind, mk) in cases.CASES.items():
+        job = mk()
+        T, I = Ref(ref).sim(job, kind)
+        out[name + "_TABS"] = T
+        if job.WITH_INT:
+            out[name + "_INT"] = I
+        out[name + "_DENS"] = job.DENS          # pins the synthetic-cloud generator as well
+        print("%-14s sum(TABS) = %.9e   nonzero cells %d / %d" % (name, T.sum(dtype=np.float64), (T != 0).sum(), T.size))
+    np.savez_compressed(os.path.join(HERE, "sims.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

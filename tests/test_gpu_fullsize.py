@@ -1,0 +1,66 @@
+"""Size-independent properties at the bench configuration (128^3, ~1e8 packets): the oracle
+cannot run this size, so the checks are invariants of the algorithm."""
+import numpy as np
+import pytest
+
+from soc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N = 128
+ABS, SCA = 8.9084e-7, 5.4552e-6          # tmp.dust row 33 at GL = 0.01 pc
+
+
+@pytest.fixture(scope="module")
+def big(engine):
+    cloud = synth.cartesian_cloud(N, seed=1234)
+    _, csc = synth.hg_scattering_table(0.6)
+    engine.set_cloud(cloud)
+    engine.set_features(0, 0, 0)
+    engine.set_scatter_table(None, csc)
+    engine.set_optical(ABS, SCA)
+    engine.set_opt(None)
+    return cloud
+
+
+def run(engine, cloud, BATCH, SEED, BG=1.0, TW=1.0, first=0, count=None, zero=True):
+    G = 8 * cloud.AREA
+    if zero:
+        engine.zero(0)
+    engine.stats(reset=True)
+    engine.sim_pb(1, 0, BATCH, SEED, BG, TW, GLOBAL=G, gid_first=first, gid_count=count)
+    return engine.read_tally(0), engine.stats()
+
+
+def test_full_size_invariants(engine, big):
+    T, st = run(engine, big, 127, 0.6004384)
+    assert st["packets"] == 8 * big.AREA * 127 == 99876864           # SURVEY.md 8(c) launch arithmetic
+    assert np.isfinite(T).all() and (T >= 0).all() and (T > 0).all()
+    # identical trajectories on a re-run: integer event counts equal, tallies equal to summation order
+    T2, st2 = run(engine, big, 127, 0.6004384)
+    assert st2 == st
+    assert np.allclose(T, T2, rtol=2e-5, atol=0)
+    # linearity in the packet weight and the frequency weight (exact powers of two: bit-for-bit per add)
+    T3, st3 = run(engine, big, 127, 0.6004384, BG=4.0, TW=0.5)
+    assert st3 == st
+    assert np.allclose(T3, 2.0 * T, rtol=2e-5, atol=0)
+    # mean number of cell steps per packet ~ N (mean chord 2N/3 x mean |dx|+|dy|+|dz| = 3/2), SURVEY.md 7.4
+    assert 0.9 * N < st["tally_events"] / st["packets"] < 1.15 * N
+    # absorbed energy: optically thin estimate  sum(TABS) ~ packets * BG * <tau_abs along the path>
+    mean_rho = big.DENS.mean(dtype=np.float64)
+    est = st["packets"] * ABS * mean_rho * (2.0 * N / 3.0)
+    assert abs(T.sum(dtype=np.float64) / est - 1) < 0.15
+
+
+def test_sharding_and_seed_change(engine, big):
+    G = 8 * big.AREA
+    Tw, stw = run(engine, big, 8, 0.25)
+    h = G // 2 + 64
+    Ta, sta = run(engine, big, 8, 0.25, first=0, count=h)
+    Tb, stb = run(engine, big, 8, 0.25, first=h, count=G - h, zero=False)
+    assert sta["tally_events"] + stb["tally_events"] == stw["tally_events"]
+    assert np.allclose(Tb, Tw, rtol=2e-5, atol=0)
+    # another seed: statistically the same field, different packets
+    Ts, sts = run(engine, big, 8, 0.75)
+    assert sts["tally_events"] != stw["tally_events"]
+    assert abs(Ts.sum(dtype=np.float64) / Tw.sum(dtype=np.float64) - 1) < 5e-3

@@ -1,0 +1,66 @@
+"""soc_math.h (the fp32 math the HIP kernels and the oracle's soc mode share) against
+float64 references: accuracy bound in ulp, exactness of fmod/scale, special values."""
+import numpy as np
+import pytest
+
+from hostprobe import HostProbe
+
+
+def ulp_err(got, want64):
+    want32 = want64.astype(np.float32)
+    ulp = np.spacing(np.abs(want32)).astype(np.float64)
+    ulp = np.maximum(ulp, np.float64(np.finfo(np.float32).tiny) * 2 ** -23)
+    return np.abs(got.astype(np.float64) - want64) / ulp
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return HostProbe()
+
+
+def test_exp(hp):
+    x = np.concatenate([np.linspace(-86.9, 88.0, 200001), -np.logspace(-8, 1.9, 50001)]).astype(np.float32)
+    assert ulp_err(hp.math("exp", x), np.exp(x.astype(np.float64))).max() < 1.5
+    sp = hp.math("exp", np.array([-1000.0, -87.5, 0.0, 89.0, np.inf, -np.inf], np.float32))
+    assert sp[0] == 0 and sp[1] == 0 and sp[2] == 1 and np.isinf(sp[3]) and np.isinf(sp[4]) and sp[5] == 0
+
+
+def test_log(hp):
+    x = np.concatenate([np.logspace(-37, 38, 200001), np.linspace(0.5, 2.0, 100001),
+                        (np.arange(1, 2 ** 20, 97) * 2.0 ** -32)]).astype(np.float32)
+    assert ulp_err(hp.math("log", x), np.log(x.astype(np.float64))).max() < 2.0
+    sp = hp.math("log", np.array([0.0, 1.0, -1.0, np.inf], np.float32))
+    assert sp[0] == -np.inf and sp[1] == 0.0 and np.isnan(sp[2]) and sp[3] == np.inf
+
+
+def test_sincos(hp):
+    x = np.linspace(-4 * np.pi, 4 * np.pi, 400001).astype(np.float32)
+    s, c = hp.math("sin", x), hp.math("cos", x)
+    # absolute accuracy (relative accuracy is lost near zeros of sin/cos, as for any fp32 routine)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(s.astype(np.float64) ** 2 + c.astype(np.float64) ** 2 - 1).max() < 5e-7
+
+
+def test_acos(hp):
+    x = np.linspace(-1, 1, 400001).astype(np.float32)
+    assert np.abs(hp.math("acos", x) - np.arccos(x.astype(np.float64))).max() < 5e-7
+    sp = hp.math("acos", np.array([1.0, -1.0, 1.5, -1.5], np.float32))
+    assert sp[0] == 0 and abs(sp[1] - np.pi) < 1e-6 and sp[2] == 0 and abs(sp[3] - np.pi) < 1e-6
+
+
+def test_fmod1_exact(hp):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-300, 300, 100000), [0.0, 1.0, -1.0, 255.99998, 1e-4, -1e-4]]).astype(np.float32)
+    assert np.array_equal(hp.math("fmod1", x), np.fmod(x, np.float32(1.0)))
+
+
+def test_sqrt_correctly_rounded(hp):
+    x = np.random.default_rng(4).uniform(0, 1e6, 100000).astype(np.float32)
+    assert np.array_equal(hp.math("sqrt", x), np.sqrt(x))
+
+
+def test_oracle_soc_mode_uses_this_header(hp, oracle_soc):
+    x = np.random.default_rng(5).uniform(-20, 5, 20000).astype(np.float32)
+    for fn, xx in (("exp", x), ("log", np.abs(x) + 1e-9), ("sin", x), ("cos", x), ("acos", np.clip(x / 20, -1, 1))):
+        assert np.array_equal(hp.math(fn, xx).view(np.uint32), oracle_soc.math(fn, xx).view(np.uint32))

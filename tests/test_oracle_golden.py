@@ -1,0 +1,104 @@
+"""Pin the CPU oracle against the reference's own outputs (tests/golden/*.npz, produced by
+tests/golden/make_golden.py from x86 builds of kernel_ASOC.c).
+
+libm math mode: every tally of every case is required to be BIT-IDENTICAL to the reference
+(same arithmetic, same libm, sequential work items).  soc math mode (the header the HIP
+kernels use): everything that involves no transcendental -- RNG, cell walks -- is still
+bit-identical; full simulations agree statistically because one-ulp differences in
+log/exp/sincos/acos redirect individual packets."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle.pyoracle import Job
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+RAYS = np.load(os.path.join(G, "rays.npz"))
+SCAT = np.load(os.path.join(G, "scatter.npz"))
+SIMS = np.load(os.path.join(G, "sims.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(cases.RAYS))
+@pytest.mark.parametrize("mode", ["libm", "soc"])
+def test_ray_trace_bit_exact(name, mode, oracle_libm, oracle_soc):
+    orc = oracle_libm if mode == "libm" else oracle_soc
+    ref, mk, pos, d = cases.RAYS[name]
+    job = Job(mk(), np.linspace(1, -1, 2500))
+    lev, ind, ds, end = orc.trace(job, RAYS[name + "_pos"], RAYS[name + "_dir"])
+    assert np.array_equal(lev, RAYS[name + "_lev"])
+    assert np.array_equal(ind, RAYS[name + "_ind"])
+    assert np.array_equal(ds.view(np.uint32), RAYS[name + "_ds"].view(np.uint32))
+    assert np.array_equal(end.view(np.uint32), RAYS[name + "_end"].view(np.uint32))
+
+
+def test_ray_kat_values_from_survey(oracle_libm):
+    # 32^3 uniform, 37 steps, path 23.541892, exit (18.83361,18.77508,32.00010)
+    assert len(RAYS["ray_c32_ds"]) == 37 and RAYS["ray_c32_ind"][0] == 20800
+    assert abs(RAYS["ray_c32_ds"].sum(dtype=np.float64) - 23.541892) < 1e-5
+    assert np.allclose(RAYS["ray_c32_end"], [18.83361, 18.77508, 32.00010], atol=1e-5)
+    # octree KAT: (level, ind, ds) sequence
+    want = [(0, 20, 1.061387), (1, 2, 0.085102), (1, 6, 0.445539), (2, 0, 0.265320), (2, 1, 0.244294),
+            (2, 5, 0.021053), (0, 22, 0.934482), (0, 38, 0.126985), (0, 39, 0.159686), (0, 43, 0.901702)]
+    got = list(zip(RAYS["ray_oct4_lev"], RAYS["ray_oct4_ind"], RAYS["ray_oct4_ds"]))
+    assert len(got) == len(want)
+    for (l, i, s), (wl, wi, ws) in zip(got, want):
+        assert (l, i) == (wl, wi) and abs(s - ws) < 2e-6
+
+
+def test_parents(oracle_libm):
+    from soc_amd import synth
+    assert np.array_equal(oracle_libm.parents(Job(synth.kat_octree(), np.linspace(1, -1, 2500))), RAYS["par_oct4"])
+    assert list(RAYS["par_oct4"]) == [21] * 8 + [7] * 8
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    assert np.array_equal(oracle_libm.parents(Job(o8, np.linspace(1, -1, 2500))), RAYS["par_oct8"])
+
+
+def test_scatter_deflect(oracle_libm, oracle_soc):
+    dirs, csc = SCAT["dirs"], SCAT["csc"]
+    for i, d in enumerate(dirs):
+        x, c = oracle_libm.seed(0.3, i)
+        nd, st = oracle_libm.scatter(d, csc, x, c)
+        assert np.array_equal(nd.view(np.uint32), SCAT["scatter_out"][i].view(np.uint32))
+        assert st == tuple(int(v) for v in SCAT["scatter_state"][i])
+        nd2, st2 = oracle_soc.scatter(d, csc, x, c)
+        assert st2 == st
+        assert np.abs(nd2 - SCAT["scatter_out"][i]).max() < 2e-6
+        df = oracle_libm.deflect(d, SCAT["cos_theta"][i], SCAT["phi"][i])
+        assert np.array_equal(df.view(np.uint32), SCAT["deflect_out"][i].view(np.uint32))
+        df2 = oracle_soc.deflect(d, SCAT["cos_theta"][i], SCAT["phi"][i])
+        assert np.abs(df2 - SCAT["deflect_out"][i]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_simulation_libm_bit_exact(name, oracle_libm):
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    assert np.array_equal(job.DENS.view(np.uint32), SIMS[name + "_DENS"].view(np.uint32)), "synthetic cloud changed"
+    T, I, n = oracle_libm.sim(job, kind)
+    assert np.array_equal(T.view(np.uint32), SIMS[name + "_TABS"].view(np.uint32))
+    if job.WITH_INT:
+        assert np.array_equal(I.view(np.uint32), SIMS[name + "_INT"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_simulation_soc_mode_statistical(name, oracle_soc):
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    want = SIMS[name + "_TABS"]
+    assert abs(T.sum(dtype=np.float64) / want.sum(dtype=np.float64) - 1) < 2e-3
+    # most packets follow identical trajectories: the typical per-cell difference is tiny
+    big = want > 0.05 * want.max()
+    rel = np.abs(T[big] - want[big]) / want[big]
+    assert np.median(rel) < 1e-3 and rel.max() < 0.1
+
+
+def test_threaded_run_agrees_with_sequential(oracle_soc):
+    ref, kind, mk = cases.CASES["bg_oct8"]
+    job = mk()
+    T1, _, n1 = oracle_soc.sim(job, kind)
+    T4, _, n4 = oracle_soc.sim(job, kind, nthreads=4)
+    assert n1 == n4
+    assert np.allclose(T1, T4, rtol=1e-5, atol=1e-6 * T1.max())
