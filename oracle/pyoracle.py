@@ -113,7 +113,7 @@ class Oracle:
         L.orc_scatter.argtypes = [_F, _F, C.c_int, _U, _U]
         L.orc_deflect.argtypes = [_F, C.c_float, C.c_float]
         L.orc_sim.restype = C.c_long
-        L.orc_sim.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_sim.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_math_eval.argtypes = [C.c_int, _F, _F, C.c_long]
         L.orc_indexg.argtypes = [C.POINTER(OrcModel), _F, _I, _I]
         assert L.orc_math_mode() == (1 if mode == "soc" else 0)
@@ -191,8 +191,8 @@ class Oracle:
         self.lib.orc_deflect(_fp(d), np.float32(cos_theta), np.float32(phi))
         return d
 
-    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None):
-        """Run work items [gid0,gid1) of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
+    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None, stride=1):
+        """Run work items gid0, gid0+stride, ... < gid1 of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
         Returns (TABS, INT, tally_events)."""
         m = self._model(job)
         cells = job.cloud.CELLS
@@ -200,7 +200,7 @@ class Oracle:
         INT = np.zeros(cells, np.float32) if INT is None else INT
         m.TABS, m.INT = _fp(TABS), _fp(INT)
         gid1 = job.GLOBAL if gid1 is None else gid1
-        n = self.lib.orc_sim(C.byref(m), kind, gid0, gid1, nthreads)
+        n = self.lib.orc_sim(C.byref(m), kind, gid0, gid1, stride, nthreads)
         return TABS, INT, int(n)
 
     def math(self, fn, x):
@@ -223,7 +223,7 @@ class Ref:
             raise FileNotFoundError("reference build %s not available" % tag)
         self.lib = C.CDLL(path)
         L = self.lib
-        L.ref_sim.argtypes = [C.POINTER(RefArgs), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_sim.argtypes = [C.POINTER(RefArgs), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_parents.argtypes = [_F, _I, _I, _I]
         L.ref_seed.argtypes = [C.c_float, C.c_ulong, _U, _U]
         L.ref_draws.argtypes = [_U, _U, C.c_int, _U]
@@ -302,7 +302,7 @@ class Ref:
         self.lib.ref_deflect(_fp(d), np.float32(cos_theta), np.float32(phi))
         return d
 
-    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None):
+    def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None, stride=1):
         self._check(job)
         cells = job.cloud.CELLS
         PAR = self.parents(job)
@@ -325,5 +325,5 @@ class Ref:
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         a.EMINDEX = _ip(idummy)
         gid1 = job.GLOBAL if gid1 is None else gid1
-        self.lib.ref_sim(C.byref(a), kind, gid0, gid1, nthreads)
+        self.lib.ref_sim(C.byref(a), kind, gid0, gid1, stride, nthreads)
         return TABS, INT

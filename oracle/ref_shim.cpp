@@ -137,10 +137,10 @@ struct ref_args {
     int   *EMINDEX;
 };
 
-static void run_range(const ref_args *a, int kind, int gid0, int gid1)
+static void run_range(const ref_args *a, int kind, int gid0, int gid1, int stride = 1)
 {
     g_gsize = (size_t)a->GLOBAL;
-    for (int id = gid0; id < gid1; id++) {
+    for (int id = gid0; id < gid1; id += stride) {
         g_gid = (size_t)id;
         if (kind == 0)
             SimRAM_PB(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->BG,
@@ -156,19 +156,22 @@ static void run_range(const ref_args *a, int kind, int gid0, int gid1)
 
 extern "C" {
 
-// Execute work items [gid0, gid1) of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
-void ref_sim(const ref_args *a, int kind, int gid0, int gid1, int nthreads)
+// Execute work items gid0, gid0+stride, ... < gid1 of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
+// stride > 1 samples a launch evenly (bench.py's bounded CPU baseline).
+void ref_sim(const ref_args *a, int kind, int gid0, int gid1, int stride, int nthreads)
 {
+    if (stride < 1) stride = 1;
     if (nthreads <= 1) {
-        run_range(a, kind, gid0, gid1);
+        run_range(a, kind, gid0, gid1, stride);
         return;
     }
     std::vector<std::thread> th;
-    // interleaved blocks of 64 ids keep the threads balanced
+    // interleaved blocks of 64 sampled ids keep the threads balanced
+    const long blk = 64L * stride;
     for (int t = 0; t < nthreads; t++) {
         th.emplace_back([=]() {
-            for (int b = gid0 + 64 * t; b < gid1; b += 64 * nthreads)
-                run_range(a, kind, b, (b + 64 < gid1) ? (b + 64) : gid1);
+            for (long b = gid0 + blk * t; b < gid1; b += blk * nthreads)
+                run_range(a, kind, (int)b, (int)((b + blk < gid1) ? (b + blk) : gid1), stride);
         });
     }
     for (auto &x : th) x.join();

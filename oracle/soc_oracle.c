@@ -760,21 +760,25 @@ EXPORT void orc_deflect(float *dir, float cos_theta, float phi)
     dir[0] = D.x; dir[1] = D.y; dir[2] = D.z;
 }
 
-/* Run work items [gid0, gid1) of SimRAM_PB (kind 0) or SimRAM_CL (kind 1).
+/* Run work items gid0, gid0+stride, ... < gid1 of SimRAM_PB (kind 0) or SimRAM_CL (kind 1).
  * nthreads <= 1: sequential, deterministic summation order (= the reference run one
  * work item after another).  Returns the number of tally events (TABS updates). */
-EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int nthreads)
+EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int stride, int nthreads)
 {
     long total = 0;
+    if (stride < 1) stride = 1;
     if (nthreads <= 1) {
         M->threaded = 0;
-        for (int id = gid0; id < gid1; id++)
+        for (int id = gid0; id < gid1; id += stride)
             total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
     } else {
         M->threaded = 1;
+        const long n = ((long)gid1 - gid0 + stride - 1) / stride;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
-        for (int id = gid0; id < gid1; id++)
+        for (long k = 0; k < n; k++) {
+            int id = (int)(gid0 + k * stride);
             total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
+        }
     }
     return total;
 }

@@ -1,0 +1,99 @@
+"""Launch arithmetic of the absorption run: packet counts, launch sizes, packet weights,
+integration weights and seeds.  These host formulas define the results as much as the
+kernels do; each function cites the ASOC.py lines it restates.
+"""
+import math
+
+import numpy as np
+
+# constants, ASOC_aux.py:28-54 and ASOC.py:81,86
+FACTOR = 1.0e20
+C_LIGHT = 2.99792458e10
+PLANCK = 6.62606957e-27
+H_K = 4.79924335e-11
+PARSEC = 3.08567758e18
+SEED0 = 0.8150982470475214
+SEED1 = 0.1393378751427912
+ADHOC = 1.0
+GLOBAL_0 = 32768          # reference default for point-source / cell-emission launches
+LOCAL_GPU = 32
+
+
+def um2f(um):
+    """wavelength [um] -> frequency [Hz] (ASOC_aux.py:67-68)"""
+    return C_LIGHT / (1.0e-4 * um)
+
+
+def Fix(n, l):
+    """smallest integer >= n divisible by l (ASOC_aux.py:1504-1506)"""
+    return int(int(math.floor((n + l - 1) / l)) * l)
+
+
+def packet_counts(BGPAC, PSPAC, CLPAC, DFPAC, AREA, CELLS, LOCAL=LOCAL_GPU, USE_EMWEIGHT=0):
+    """Rounded packet counts (ASOC.py:234-250).  Returns dict(PSPAC, BGPAC, CLPAC, DFPAC)."""
+    PS = Fix(PSPAC, LOCAL)
+    BG = Fix(Fix(BGPAC, AREA), LOCAL)
+    DF = 0
+    if CLPAC < 1:
+        USE_EMWEIGHT = 0
+    if USE_EMWEIGHT > 0:
+        CL = Fix(CLPAC, LOCAL)
+        if DFPAC > 0:
+            DF = Fix(DFPAC, LOCAL)
+    else:
+        CL = Fix(Fix(CLPAC, CELLS), LOCAL)
+        if DFPAC > 0:
+            DF = Fix(Fix(DFPAC, CELLS), LOCAL)
+    return dict(PSPAC=PS, BGPAC=BG, CLPAC=CL, DFPAC=DF)
+
+
+def ps_launch(PSPAC, NO_PS, GL, GLOBAL=GLOBAL_0):
+    """Point sources (ASOC.py:1031-1045).  Returns dict(GLOBAL, BATCH, PACKETS, WPS)."""
+    BATCH = int(max([1, PSPAC / GLOBAL]))
+    per_source = GLOBAL * BATCH
+    WPS = 1.0 / (PLANCK * per_source * ((GL * PARSEC) ** 2.0))
+    return dict(GLOBAL=GLOBAL, BATCH=BATCH * NO_PS, PACKETS=per_source * NO_PS, WPS=WPS)
+
+
+def bg_launch(BGPAC, AREA):
+    """Isotropic background (ASOC.py:1061-1066): 8 work items per surface element.
+    Returns dict(GLOBAL, BATCH, PACKETS, WBG)."""
+    BATCH = max([1, int(round(BGPAC / (8 * AREA)))])
+    PACKETS = int(8 * AREA * BATCH)
+    WBG = np.pi / (PLANCK * 8 * BATCH)
+    GLOBAL = Fix(int(8 * AREA), 64)
+    return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
+
+
+def cl_launch(PAC, CELLS, GLOBAL=GLOBAL_0):
+    """Cell emission: diffuse (ASOC.py:1086-1090) or dust re-emission (ASOC.py:1640).
+    Returns dict(GLOBAL, BATCH, PACKETS)."""
+    return dict(GLOBAL=GLOBAL, BATCH=int(PAC / CELLS), PACKETS=PAC)
+
+
+def trapezoid_weight(FFREQ, IFREQ):
+    """FF = FREQ * (trapezoid interval), kernel argument TW (ASOC.py:1219-1223)."""
+    NFREQ = len(FFREQ)
+    FF = float(FFREQ[IFREQ])
+    if IFREQ == 0:
+        FF *= 0.5 * (float(FFREQ[1]) - float(FFREQ[0]))
+    elif IFREQ == NFREQ - 1:
+        FF *= 0.5 * (float(FFREQ[NFREQ - 1]) - float(FFREQ[NFREQ - 2]))
+    else:
+        FF *= 0.5 * (float(FFREQ[IFREQ + 1]) - float(FFREQ[IFREQ - 1]))
+    return FF
+
+
+def launch_seed(SEED, IFREQ, DEVICES=1, ID=0):
+    """seed = fmod(SEED+SEED0+(DEVICES*IFREQ+ID)*SEED1, 1.0) (ASOC.py:1247); the reference's
+    per-device term is what the weak-scaling multi-GPU mode uses (one replica per rank)."""
+    return math.fmod(SEED + SEED0 + (DEVICES * IFREQ + ID) * SEED1, 1.0)
+
+
+def shard_range(GLOBAL, rank, world):
+    """Work-item range of `rank` when one logical launch is split over `world` GPUs
+    (SURVEY.md 8(e)): contiguous, multiples of 64 except possibly the last."""
+    per = Fix(int(math.ceil(GLOBAL / world)), 64)
+    first = min(GLOBAL, rank * per)
+    last = min(GLOBAL, first + per)
+    return first, last - first
