@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""asoc -- the absorption run of SOC on MI355X:  python -m soc_amd.asoc my.ini
+
+Drop-in for the photon-packet part of ``ASOC.py <ini>`` (reference ASOC.py:77-1560): reads
+the same ini file and the same cloud / dust / dsc / background / point-source / diffuse
+files, simulates the constant radiation sources frequency by frequency on the HIP engine
+and writes the same products of that stage: ``packet.info``, the ``absorbed`` file
+(unless ``noabsorbed``) and the ``csave`` file of frequency-integrated absorptions.
+Temperature solve, emission and maps are downstream of the tallies and
+not part of this engine; with ``noabsorbed`` the integrated absorptions are written to
+``<prefix>.ctabs`` so a downstream solver can pick them up.
+
+The host loop is the reference's (source block II -> frequency IFREQ, ASOC.py:1028-1545);
+what runs inside is new: geometry and feature switches are run-time arguments of one
+ahead-of-time compiled library (no per-run kernel build), and with several ranks each
+launch is split by logical work-item id with one all-reduce of the tallies
+(soc_amd/dist.py).
+"""
+import sys
+import time
+
+import numpy as np
+
+from . import files, launch
+from .ini import User
+from .launch import PLANCK, PARSEC
+
+
+class UnsupportedOption(RuntimeError):
+    pass
+
+
+def _check_supported(USER, NDUST, WITH_MSF):
+    bad = []
+    if WITH_MSF:
+        bad.append("several dsc files (WITH_MSF)")
+    if USER.DO_SPLIT:
+        bad.append("split")
+    if USER.WITH_ALI:
+        bad.append("ali")
+    if USER.STEP_WEIGHT[0] > 0:
+        bad.append("stepweight")
+    if USER.DIR_WEIGHT[0] > 0:
+        bad.append("direweight")
+    if USER.MIRROR:
+        bad.append("mirror")
+    if USER.WITH_ROI_SAVE or USER.WITH_ROI_LOAD:
+        bad.append("roisave/roiload")
+    if len(USER.file_hpbg) > 2:
+        bad.append("hpbg (HEALPix background)")
+    if USER.SAVE_INTENSITY == 2:
+        bad.append("saveint 2 (intensity vectors)")
+    if USER.PS_METHOD == 3:
+        bad.append("psmethod 3 (does not compile in the reference either)")
+    if USER.USE_EMWEIGHT > 1:
+        bad.append("emweight 2")
+    if USER.OPT_IS_HALF:
+        bad.append("optishalf")
+    if bad:
+        raise UnsupportedOption("ini options not supported by this engine: " + ", ".join(bad))
+
+
+class AbsorptionRun:
+    """The constant-source part of an ASOC run.  ``engine`` is a soc_amd.lib.Engine (or an
+    object with the same methods); ``comm`` a soc_amd.dist.Comm."""
+
+    def __init__(self, USER, engine, comm=None, verbose=None, workdir="."):
+        self.U = USER
+        self.eng = engine
+        self.comm = comm
+        self.rank = comm.rank if comm else 0
+        self.world = comm.world if comm else 1
+        self.verbose = USER.VERBOSE if verbose is None else verbose
+        self.timers = dict(Tkernel=0.0, Tpush=0.0, Tpull=0.0)
+        self.packets = 0
+        self._load_inputs()
+
+    def log(self, *a):
+        if self.verbose and self.rank == 0:
+            print(*a)
+
+    # ---------------------------------------------------------------------------------
+    def _load_inputs(self):
+        U = self.U
+        if not U.Validate():
+            raise ValueError("check the ini file: no cloud defined")
+        if U.GL <= 0.0:
+            raise ValueError("gridlength must be given")
+        self.FFREQ, self.AFG, self.AFABS, self.AFSCA = files.read_dust(U.file_optical, U.GL)
+        self.NFREQ = U.NFREQ = len(self.FFREQ)
+        self.NDUST = len(self.AFABS)
+        if self.NFREQ < 2:
+            raise ValueError("the dust file needs >= 2 frequencies (trapezoid weights, ASOC.py:1220); "
+                             "restrict the simulated range with `simum` instead")
+        self.FDSC, self.FCSC = files.read_scattering_functions(U.file_scafunc, self.NFREQ, U.DSC_BINS)
+        WITH_MSF = len(self.FDSC) > 1
+        _check_supported(U, self.NDUST, WITH_MSF)
+        self.IBG = files.read_background_intensity(U.file_background, self.NFREQ, U.scale_background) \
+            if U.BGPAC > 0 else []
+        self.LPS = files.read_source_luminosities(U.file_pointsource[:U.NO_PS], self.NFREQ, U.PS_SCALING) \
+            if U.NO_PS > 0 else []
+        self.cloud = files.read_cloud(U.file_cloud, U.KDENSITY, U.LEVELS)
+        c = self.cloud
+        U.AREA, U.CELLS = float(c.AREA), c.CELLS
+        self.log("NX %d, NY %d, NZ %d LEVELS %d, CELLS %d" % (c.NX, c.NY, c.NZ, c.LEVELS, c.CELLS))
+        self.ABU = files.read_abundances(U.file_abundance, c.CELLS)
+        self.WITH_ABU = self.ABU is not None
+        if self.WITH_ABU and U.SINGLE_ABU:
+            if self.NDUST != 2:
+                raise ValueError("singleabu assumes exactly two dust components")
+            self.ABU = np.ravel(self.ABU[:, 0])
+        self.DIFFUSERAD = files.mmap_diffuserad(U.file_diffuse, c.CELLS) if len(U.file_diffuse) > 0 else []
+
+        # LOCAL only enters through the rounding of packet counts (ASOC.py:221-227)
+        LOCAL = 8 if 'c' in U.DEVICES else 32
+        if 'local' in U.KEYS:
+            LOCAL = int(U.KEYS['local'][0])
+        self.LOCAL = LOCAL
+        pc = launch.packet_counts(U.BGPAC, U.PSPAC, U.CLPAC, U.DFPAC, int(U.AREA), c.CELLS, LOCAL, U.USE_EMWEIGHT)
+        self.PSPAC, self.BGPAC, self.CLPAC, self.DFPAC = pc["PSPAC"], pc["BGPAC"], pc["CLPAC"], pc["DFPAC"]
+        if U.ITERATIONS < 1:
+            U.NOABSORBED = 1
+        self.log('PACKETS: PSPAC %d   BGPAC %d  CLPAC %d  DFPAC %d' % (self.PSPAC, self.BGPAC, self.CLPAC, self.DFPAC))
+        self.XPS = files.analyse_external_point_sources(c.NX, c.NY, c.NZ, U.PSPOS, int(U.NO_PS), int(U.PS_METHOD))
+        # launch size for point-source / cell-emission launches: reference default 32768
+        # (ASOC.py:86), `global` keyword overrides (more work items fill an MI355X better)
+        self.GLOBAL_0 = U.GLOBAL if U.GLOBAL > 0 else launch.GLOBAL_0
+        self.with_int = int((U.SAVE_INTENSITY in (1, 2)) or (not U.NOABSORBED))
+
+    def write_packet_info(self, path="packet.info"):
+        """int32 [BGPAC, PSPAC, DFPAC, CLPAC] (ASOC.py:251)"""
+        if self.rank == 0:
+            np.asarray([self.BGPAC, self.PSPAC, self.DFPAC, self.CLPAC], np.int32).tofile(path)
+
+    # ---------------------------------------------------------------------------------
+    def setup_engine(self):
+        e, c, U = self.eng, self.cloud, self.U
+        e.set_cloud(c)
+        e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(U.USE_EMWEIGHT, 1))
+        if self.comm:
+            self.comm.attach(e, c.CELLS)
+
+    def _optical_for(self, IFREQ):
+        """scalar ABS,SCA summed over species, or OPT[CELLS,2] with abundances (ASOC.py:1146-1175)"""
+        e = self.eng
+        if self.WITH_ABU:
+            OPT = np.zeros((self.cloud.CELLS, 2), np.float32)
+            if self.U.SINGLE_ABU:
+                OPT[:, 0] += self.ABU * self.AFABS[0][IFREQ] + (1.0 - self.ABU) * self.AFABS[1][IFREQ]
+                OPT[:, 1] += self.ABU * self.AFSCA[0][IFREQ] + (1.0 - self.ABU) * self.AFSCA[1][IFREQ]
+            else:
+                for idust in range(self.NDUST):
+                    OPT[:, 0] += self.ABU[:, idust] * self.AFABS[idust][IFREQ]
+                    OPT[:, 1] += self.ABU[:, idust] * self.AFSCA[idust][IFREQ]
+            e.set_opt(OPT)
+            ABS = np.float32(sum(a[IFREQ] for a in self.AFABS))
+            SCA = np.float32(sum(a[IFREQ] for a in self.AFSCA))
+        else:
+            ABS, SCA = np.float32(0.0), np.float32(0.0)
+            for idust in range(self.NDUST):
+                ABS += self.AFABS[idust][IFREQ]
+                SCA += self.AFSCA[idust][IFREQ]
+            e.set_opt(None)
+        e.set_optical(ABS, SCA)
+        return ABS, SCA
+
+    def simulate_constant_sources(self):
+        """for II in (point sources, background, diffuse): for IFREQ: launch (ASOC.py:1028-1545).
+        Returns CTABS[CELLS] and FABSORBED[CELLS,NFREQ] (or None with noabsorbed)."""
+        U, e, c = self.U, self.eng, self.cloud
+        CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
+        CTABS = np.zeros(CELLS, np.float32)
+        FABSORBED = None if U.NOABSORBED else np.zeros((CELLS, NFREQ), np.float32)
+        if len(U.file_constant_load) > 0:
+            self.log("=== CLOAD => %s" % U.file_constant_load)
+            return np.fromfile(U.file_constant_load, np.float32, CELLS), FABSORBED
+        rng = np.random.default_rng()
+        DEVICES, ID, KDEV = 1, 0, 1.0                 # sharded launches reproduce ONE device (ASOC.py:179-181)
+        for II in range(3):
+            if U.ITERATIONS < 1:
+                continue
+            WPS = WBG = 0.0
+            if II == 0:
+                if (self.PSPAC < 1) or (U.NO_PS < 1):
+                    continue
+                L = launch.ps_launch(self.PSPAC, U.NO_PS, U.GL, self.GLOBAL_0)
+                WPS = L["WPS"]
+                self.log("=== PS  GLOBAL %d x BATCH %d = %d" % (L["GLOBAL"], L["BATCH"], L["PACKETS"]))
+            elif II == 1:
+                if self.BGPAC < 1:
+                    continue
+                L = launch.bg_launch(self.BGPAC, int(U.AREA))
+                WBG = L["WBG"]
+                self.log("=== BG: BGPAC %d, BATCH %d, GLOBAL %d" % (L["PACKETS"], L["BATCH"], L["GLOBAL"]))
+            else:
+                if len(self.DIFFUSERAD) < 1 or self.DFPAC < 1:
+                    continue
+                L = launch.cl_launch(self.DFPAC, CELLS, self.GLOBAL_0)
+                self.log("=== DFPAC %d, GLOBAL %d, BATCH %d" % (self.DFPAC, L["GLOBAL"], L["BATCH"]))
+            first, count = self.comm.shard(L["GLOBAL"]) if self.comm else (0, L["GLOBAL"])
+            e.zero(0)
+            for IFREQ in range(NFREQ):
+                FREQ = float(FFREQ[IFREQ])
+                if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
+                    continue
+                t0 = time.time()
+                ABS, SCA = self._optical_for(IFREQ)
+                if self.with_int:
+                    e.zero(1)
+                PS = (self.LPS[:, IFREQ] * np.float32(WPS)) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
+                BG = np.float32(float(self.IBG[IFREQ]) * WBG / FREQ) if len(self.IBG) == NFREQ else np.float32(0.0)
+                FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
+                e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                if U.SEED > 0:
+                    seed = launch.launch_seed(U.SEED, IFREQ, DEVICES, ID)
+                else:
+                    seed = float(rng.random())
+                    if self.comm and self.world > 1:      # every rank must use the same streams
+                        seed = self._bcast_seed(seed)
+                if II == 2:
+                    dr_ind = IFREQ + (self.DIFFUSERAD.shape[1] - NFREQ)
+                    if dr_ind < 0 or dr_ind >= self.DIFFUSERAD.shape[1]:
+                        continue
+                    EMIT = np.zeros(CELLS, np.float32)
+                    for level in range(c.LEVELS):
+                        coeff = U.GL * PARSEC / (8.0 ** level) * U.K_DIFFUSE
+                        a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
+                        EMIT[a:b] = self.DIFFUSERAD[a:b, dr_ind] * coeff
+                    e.set_emission(EMIT, None)
+                self.timers["Tpush"] += time.time() - t0
+                t0 = time.time()
+                if II == 2:
+                    e.sim_cl(II, L["PACKETS"], L["BATCH"], seed, FF, L["GLOBAL"], gid_first=first, gid_count=count)
+                else:
+                    e.sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, FF,
+                             PSPOS=U.PSPOS[:max(U.NO_PS, 1), :3], PS=PS, XPS=self.XPS,
+                             GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+                if self.with_int and self.comm:
+                    self.comm.all_reduce_tally(e, 1)      # one all-reduce of the per-cell buffer per frequency
+                e.sync()
+                self.timers["Tkernel"] += time.time() - t0
+                self.packets += L["PACKETS"]
+                t0 = time.time()
+                if FABSORBED is not None:
+                    FABSORBED[:, IFREQ] += e.read_tally(1)
+                self.timers["Tpull"] += time.time() - t0
+                if self.verbose and self.rank == 0:
+                    print("  FREQ %3d/%3d  %10.3e   BG %12.4e  PS %12.4e   TW %10.3e" % (
+                        IFREQ + 1, NFREQ, FREQ, BG, PS[0], FF))
+            if self.comm:
+                self.comm.all_reduce_tally(e, 0)          # TABS: integrated over frequency on the device
+            t0 = time.time()
+            CTABS += e.read_tally(0)
+            self.timers["Tpull"] += time.time() - t0
+            self.log("******  CONSTANT   %10s   CTABS -> %12.4e" % (['PS', 'BG', 'DE'][II], float(np.mean(CTABS))))
+        return CTABS, FABSORBED
+
+    def _bcast_seed(self, seed):
+        t = self.comm.torch.tensor([seed], dtype=self.comm.torch.float64,
+                                   device="cuda" if self.comm.backend == "nccl" else "cpu")
+        self.comm.dist.broadcast(t, 0)
+        return float(t[0])
+
+    # ---------------------------------------------------------------------------------
+    def run(self):
+        t00 = time.time()
+        self.write_packet_info()
+        self.setup_engine()
+        CTABS, FABSORBED = self.simulate_constant_sources()
+        U = self.U
+        if self.rank == 0:
+            if len(U.file_constant_save) > 0:
+                CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549
+            if FABSORBED is not None:
+                files.scale_absorbed(FABSORBED, self.cloud, U.GL, U.NNNLIMIT)
+                files.write_absorbed(U.file_absorbed, FABSORBED)   # ASOC.py:2866-2875
+            else:
+                prefix = U.KEYS.get('prefix', ['soc'])[0] if U.KEYS.get('prefix') else 'soc'
+                CTABS.tofile(prefix + ".ctabs")
+        wall = time.time() - t00
+        if self.rank == 0 and self.verbose:
+            print("Tkernel %.3f  Tpush %.3f  Tpull %.3f" % (self.timers["Tkernel"], self.timers["Tpush"], self.timers["Tpull"]))
+            if self.timers["Tkernel"] > 0:
+                print("%.4e photon packets / s (simulation section, %d GPU%s)" % (
+                    self.packets / self.timers["Tkernel"], self.world, "s" if self.world > 1 else ""))
+            print("@@ asoc %.2f seconds WC" % wall)
+        return CTABS, FABSORBED
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 2:
+        print("Usage:  python -m soc_amd.asoc ini-file")
+        return 1
+    from .dist import Comm
+    from .lib import Engine
+    USER = User(argv[1])
+    comm = Comm()
+    eng = Engine(comm.local_rank)
+    try:
+        AbsorptionRun(USER, eng, comm).run()
+    finally:
+        eng.close()
+        comm.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,74 @@
+"""One process per GPU: work-item sharding of a logical launch and the tally all-reduce.
+
+Packets are independent, RNG streams are a function of the logical work-item id and tallies
+are additive, so the only exchange step of the path is a sum of the
+per-cell absorption buffers: one ``all_reduce`` per frequency for INT (when absorptions are
+saved per frequency) and one per source block for TABS.  On GPUs the reduction runs in place
+on the engine's tally memory through RCCL (torch.distributed backend "nccl"); the "gloo"
+backend is used on CPU-only hosts (tests).
+"""
+import os
+
+import numpy as np
+
+from .launch import shard_range
+
+
+class Comm:
+    """Rank/world bookkeeping + tally reduction.  world == 1 needs no torch at all."""
+
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        self._tensors = {}
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.torch, self.dist = torch, dist
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            self.backend = backend
+            if not dist.is_initialized():
+                if backend == "nccl":
+                    torch.cuda.set_device(self.local_rank)
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                            device_id=torch.device("cuda", self.local_rank))
+                else:
+                    dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+
+    def shard(self, GLOBAL):
+        """(first, count) of the logical work items this rank executes."""
+        return shard_range(GLOBAL, self.rank, self.world)
+
+    def attach(self, engine, cells):
+        """RCCL path: make the engine's tallies torch tensors so they are reduced in place and
+        run the kernels on torch's current stream (ordering with the collective)."""
+        if self.world > 1 and self.backend == "nccl":
+            t = self.torch
+            for which in (0, 1):
+                buf = t.zeros(cells, dtype=t.float32, device="cuda")
+                engine.bind_tally(which, buf.data_ptr())
+                self._tensors[which] = buf
+            engine.set_stream(t.cuda.current_stream().cuda_stream)
+
+    def all_reduce_tally(self, engine, which):
+        """Sum tally `which` over all ranks (result on every rank)."""
+        if self.world == 1:
+            return
+        if self.backend == "nccl":
+            self.dist.all_reduce(self._tensors[which])
+        else:
+            arr = self.torch.from_numpy(np.ascontiguousarray(engine.read_tally(which)))
+            self.dist.all_reduce(arr)
+            engine.write_tally(which, arr.numpy())
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def close(self):
+        if self.world > 1 and self.dist.is_initialized():
+            self.dist.destroy_process_group()

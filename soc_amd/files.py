@@ -1,0 +1,196 @@
+"""Readers and writers of SOC's on-disk formats: all little-endian raw
+int32/float32, no padding.  Each function cites the reference code that defines the layout."""
+import os
+
+import numpy as np
+
+from .launch import FACTOR, PARSEC
+from .synth import Cloud
+
+
+class FileError(ValueError):
+    pass
+
+
+def read_cloud(filename, kdensity=1.0, max_levels=999):
+    """Cloud file -> Cloud (ASOC_aux.py:716-803).  int32 NX,NY,NZ,LEVELS,CELLS; per level
+    int32 LCELLS + float32[LCELLS]; leaf densities are scaled by ``kdensity`` and clipped to
+    [1e-6, 1e20] when kdensity != 1 (ASOC_aux.py:779-781); links (<= 0) are left untouched."""
+    with open(filename, 'rb') as fp:
+        hdr = np.fromfile(fp, np.int32, 5)
+        if hdr.size != 5:
+            raise FileError("%s: truncated cloud header" % filename)
+        NX, NY, NZ, LEVELS, CELLS = [int(v) for v in hdr]
+        if LEVELS > max_levels:
+            raise FileError("%s has %d levels; cutting hierarchies (keyword levels) is preprocessing that this "
+                            "engine does not do" % (filename, LEVELS))
+        H = []
+        for level in range(LEVELS):
+            n = np.fromfile(fp, np.int32, 1)
+            if n.size != 1 or n[0] < 0:
+                break
+            d = np.fromfile(fp, np.float32, int(n[0]))
+            if d.size != n[0]:
+                raise FileError("%s: level %d truncated" % (filename, level))
+            if kdensity != 1.0:
+                m = d > 0.0
+                d[m] = np.clip(np.float32(kdensity) * d[m], 1.0e-6, 1e20)
+            H.append(d)
+    c = Cloud(NX, NY, NZ, H)
+    if c.CELLS != CELLS:
+        raise FileError("%s: header says %d cells, levels hold %d" % (filename, CELLS, c.CELLS))
+    return c
+
+
+def read_dust(filenames, GL):
+    """Dust files -> FFREQ, [G], [ABS], [SCA] per dust (ASOC_aux.py:557-596): text, line 2
+    grain density, line 3 grain size [cm], line 4 NFREQ, rows ``freq g Qabs Qsca``;
+    Q * GRAIN_DENSITY*pi*a^2*GL*PARSEC = optical depth per unit density per root cell."""
+    FFREQ, AFG, AFABS, AFSCA = None, [], [], []
+    for fn in filenames:
+        with open(fn) as fp:
+            lines = fp.readlines()
+        gd = float(lines[1].split()[0])
+        gs = float(lines[2].split()[0])
+        coeff = gd * np.pi * gs ** 2.0 * GL * PARSEC
+        d = np.loadtxt(fn, skiprows=4, ndmin=2)
+        f = np.asarray(d[:, 0], np.float32)
+        if FFREQ is not None and len(f) != len(FFREQ):
+            raise FileError("dusts must have the same frequency grid")
+        FFREQ = f
+        AFG.append(np.asarray(d[:, 1], np.float32))
+        AFABS.append(np.asarray(d[:, 2] * coeff, np.float32))
+        AFSCA.append(np.asarray(d[:, 3] * coeff, np.float32))
+    return FFREQ, AFG, AFABS, AFSCA
+
+
+def read_scattering_functions(filenames, NFREQ, BINS):
+    """dsc file(s) -> FDSC[ndust,NFREQ,BINS], FCSC[ndust,NFREQ,BINS] (ASOC_aux.py:619-647)."""
+    nd = len(filenames)
+    FDSC = np.zeros((nd, NFREQ, BINS), np.float32)
+    FCSC = np.zeros((nd, NFREQ, BINS), np.float32)
+    for i, fn in enumerate(filenames):
+        a = np.fromfile(fn, np.float32)
+        if a.size != 2 * NFREQ * BINS:
+            raise FileError("%s holds %d floats, expected 2*%d*%d" % (fn, a.size, NFREQ, BINS))
+        FDSC[i] = a[:NFREQ * BINS].reshape(NFREQ, BINS)
+        FCSC[i] = a[NFREQ * BINS:].reshape(NFREQ, BINS)
+    return FDSC, FCSC
+
+
+def write_scattering_functions(filename, DSC, CSC):
+    with open(filename, 'wb') as fp:
+        np.asarray(DSC, np.float32).tofile(fp)
+        np.asarray(CSC, np.float32).tofile(fp)
+
+
+def read_background_intensity(filename, NFREQ, scale=1.0):
+    """float32 I_nu[NFREQ] (ASOC_aux.py:1081-1102)"""
+    a = np.fromfile(filename, np.float32, NFREQ)
+    if a.size != NFREQ:
+        raise FileError("background intensity for %d frequencies, optical data for %d" % (a.size, NFREQ))
+    return a * np.float32(scale)
+
+
+def read_source_luminosities(filenames, NFREQ, scaling):
+    """float32 L_nu[NFREQ] per source (ASOC_aux.py:1107-1124)"""
+    LPS = np.zeros((len(filenames), NFREQ), np.float32)
+    for i, fn in enumerate(filenames):
+        a = np.fromfile(fn, np.float32, NFREQ)
+        if a.size != NFREQ:
+            raise FileError("source %d: intensity for %d frequencies, optical data for %d" % (i, a.size, NFREQ))
+        LPS[i] = a * scaling[i]
+    return LPS
+
+
+def read_abundances(filenames, cells):
+    """ABU[cells, ndust] or None when every dust has constant abundance (ASOC_aux.py:600-615)."""
+    if not any(f[0] != '#' for f in filenames):
+        return None
+    ABU = np.ones((cells, len(filenames)), np.float32)
+    for i, fn in enumerate(filenames):
+        if fn[0] != '#':
+            ABU[:, i] = np.fromfile(fn, np.float32, cells)
+    return ABU
+
+
+def mmap_diffuserad(filename, CELLS):
+    """diffuse emission file: int32 CELLS,NFREQ'; float32 [CELLS,NFREQ'] photons/Hz/cm3
+    (ASOC_aux.py:839-863)"""
+    dims = np.fromfile(filename, np.int32, 2)
+    if dims[0] != CELLS:
+        raise FileError("diffuse field has %d cells but the cloud has %d" % (dims[0], CELLS))
+    return np.memmap(filename, dtype='float32', mode='r', offset=8, shape=(int(dims[0]), int(dims[1])))
+
+
+def write_diffuserad(filename, data):
+    data = np.asarray(data, np.float32)
+    with open(filename, 'wb') as fp:
+        np.asarray(data.shape, np.int32).tofile(fp)
+        data.tofile(fp)
+
+
+def scale_absorbed(FABSORBED, cloud, GL, nnnlimit=0.0):
+    """Final scaling of the per-frequency absorptions before they are written
+    (ASOC.py:2793-2809): x FACTOR*8^level/(GL*PARSEC)/DENS; parents (and cells with density
+    <= nnnlimit) are marked -1e20.  In place; returns the array."""
+    for level in range(cloud.LEVELS):
+        a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+        coeff = (8.0 ** level) * (FACTOR / (GL * PARSEC))
+        with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+            FABSORBED[a:b, :] *= (coeff / cloud.DENS[a:b].reshape(b - a, 1)).astype(np.float32)
+        m = np.nonzero(cloud.DENS[a:b] <= nnnlimit)[0]
+        FABSORBED[a + m, :] = -1.0e20
+    return FABSORBED
+
+
+def write_absorbed(filename, FABSORBED):
+    """absorbed file: int32 CELLS,NFREQ; float32 [CELLS,NFREQ] (ASOC.py:2866-2875)"""
+    FABSORBED = np.asarray(FABSORBED, np.float32)
+    with open(filename, 'wb') as fp:
+        np.asarray(FABSORBED.shape, np.int32).tofile(fp)
+        FABSORBED.tofile(fp)
+
+
+def read_absorbed(filename):
+    dims = np.fromfile(filename, np.int32, 2)
+    return np.fromfile(filename, np.float32, offset=8).reshape(int(dims[0]), int(dims[1]))
+
+
+def analyse_external_point_sources(NX, NY, NZ, PSPOS, NO_PS, PS_METHOD):
+    """Visible cloud sides per external point source -> XPS_NSIDE[NO_PS], XPS_SIDE[3*NO_PS],
+    XPS_AREA[3*NO_PS] (ASOC_aux.py:1538-1632).  As in the reference, the "areas" are 1/nside
+    (true projected areas are not computed there either) and for PS_METHOD 5 XPS_AREA[3*i]
+    holds the cosine of the cone that contains the cloud, measured from the axis of the LAST
+    illuminated side found."""
+    XPS_NSIDE = np.zeros(max(NO_PS, 1), np.int32)
+    XPS_SIDE = np.zeros(3 * max(NO_PS, 1), np.int32)
+    XPS_AREA = np.zeros(3 * max(NO_PS, 1), np.float32)
+    axis = np.zeros(3, np.float32)
+    for i in range(NO_PS):
+        p = PSPOS[i]
+        if (0.0 <= p[0] <= NX) and (0.0 <= p[1] <= NY) and (0.0 <= p[2] <= NZ):
+            continue
+        no = 0
+        for cond, side, ax in ((p[0] > NX, 0, (-1.0, 0.0, 0.0)), (p[0] < 0.0, 1, (1.0, 0.0, 0.0)),
+                               (p[1] > NY, 2, (0.0, -1.0, 0.0)), (p[1] < 0.0, 3, (0.0, 1.0, 0.0)),
+                               (p[2] > NZ, 4, (0.0, 0.0, -1.0)), (p[2] < 0.0, 5, (0.0, 0.0, 1.0))):
+            if cond:
+                XPS_SIDE[3 * i + no] = side
+                XPS_AREA[3 * i + no] = 1.0
+                axis = np.asarray(ax, np.float32)
+                no += 1
+        XPS_NSIDE[i] = no
+        XPS_AREA[3 * i:3 * i + 3] /= no
+    if PS_METHOD == 5:
+        for i in range(NO_PS):
+            cos_theta = 0.5 * np.pi
+            for ii in range(8):
+                vec = np.zeros(3, np.float32)
+                vec[0] = NX * (ii % 2 == 0) - PSPOS[i][0]
+                vec[1] = NY * ((ii / 2) % 2 == 0) - PSPOS[i][1]
+                vec[2] = NZ * ((ii / 4) % 2 == 0) - PSPOS[i][2]
+                tmp = abs(float(np.dot(axis, vec))) / float(np.linalg.norm(vec))
+                cos_theta = min(cos_theta, tmp)
+            XPS_AREA[3 * i] = cos_theta
+    return XPS_NSIDE, XPS_SIDE, XPS_AREA

@@ -1,0 +1,80 @@
+"""An object with the method names of soc_amd.lib.Engine, backed by the CPU oracle.
+Lives in tests/: it lets the host driver (soc_amd.asoc.AbsorptionRun) and the multi-process
+sharding logic be exercised without a GPU.  Never imported by the product."""
+import numpy as np
+
+from oracle.pyoracle import Job, Oracle
+
+
+class OracleEngine:
+    def __init__(self, mode="soc"):
+        self.orc = Oracle(mode)
+        self.cloud = None
+        self.feat = dict(with_int=0, ps_method=0, use_emweight=0)
+        self.OPT = None
+        self.ABS = self.SCA = 0.0
+        self.CSC = self.DSC = None
+        self.EMIT = self.EMWEI = None
+        self.T = [None, None]
+        self.events = 0
+
+    def set_cloud(self, cloud):
+        self.cloud = cloud
+        self.CELLS = cloud.CELLS
+        self.T = [np.zeros(cloud.CELLS, np.float32), np.zeros(cloud.CELLS, np.float32)]
+
+    def set_features(self, with_int=0, ps_method=0, use_emweight=0):
+        self.feat = dict(with_int=with_int, ps_method=ps_method, use_emweight=use_emweight)
+
+    def set_optical(self, ABS, SCA):
+        self.ABS, self.SCA = ABS, SCA
+
+    def set_opt(self, OPT):
+        self.OPT = OPT
+
+    def set_scatter_table(self, DSC, CSC):
+        self.DSC, self.CSC = DSC, CSC
+
+    def set_emission(self, EMIT, EMWEI=None):
+        self.EMIT, self.EMWEI = EMIT, EMWEI
+
+    def zero(self, tag):
+        self.T[tag][:] = 0
+
+    def bind_tally(self, which, ptr):
+        raise NotImplementedError
+
+    def set_stream(self, s):
+        pass
+
+    def _job(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS=None, PS=None, XPS=None):
+        return Job(self.cloud, self.CSC, ABS=self.ABS, SCA=self.SCA, SOURCE=SOURCE, BATCH=BATCH, SEED=SEED, BG=BG,
+                   TW=TW, GLOBAL=GLOBAL, PACKETS=PACKETS, PSPOS=PSPOS if SOURCE == 0 else None,
+                   PS=PS if SOURCE == 0 else None, PS_METHOD=self.feat["ps_method"], XPS=XPS if SOURCE == 0 else None,
+                   OPT=self.OPT, EMIT=self.EMIT, EMWEI=self.EMWEI, USE_EMWEIGHT=self.feat["use_emweight"],
+                   WITH_INT=self.feat["with_int"], DSC=self.DSC)
+
+    def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None, GLOBAL=None,
+               gid_first=0, gid_count=None):
+        job = self._job(SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS, PS, XPS)
+        gid_count = GLOBAL - gid_first if gid_count is None else gid_count
+        _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        self.events += n
+
+    def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
+        job = self._job(SOURCE, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
+        gid_count = GLOBAL - gid_first if gid_count is None else gid_count
+        _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        self.events += n
+
+    def sync(self):
+        pass
+
+    def read_tally(self, which=0):
+        return self.T[which].copy()
+
+    def write_tally(self, which, values):
+        self.T[which][:] = values
+
+    def close(self):
+        pass

@@ -1,0 +1,57 @@
+"""N>1 path on CPU: two gloo ranks share one logical launch by work-item ranges and
+all-reduce the tallies; the result must equal the single-process run (same RNG streams)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np
+from soc_amd.ini import User
+from soc_amd.asoc import AbsorptionRun
+from soc_amd.dist import Comm
+from oracle_engine import OracleEngine
+comm = Comm(backend="gloo")
+os.chdir(sys.argv[2] + "/r%d" % comm.rank)
+run = AbsorptionRun(User(sys.argv[1]), OracleEngine("soc"), comm, verbose=0)
+C, F = run.run()
+np.save("ctabs_rank%d.npy" % comm.rank, C)
+comm.close()
+"""
+
+
+def test_two_rank_sharded_run_equals_single(tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_host import _write_model
+    from oracle_engine import OracleEngine
+    from soc_amd import synth
+    from soc_amd.ini import User
+    from soc_amd.asoc import AbsorptionRun
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _write_model(d, cloud, with_ps=True, with_diffuse=True)
+    for r in (0, 1):
+        os.makedirs(os.path.join(d, "r%d" % r))
+    os.makedirs(os.path.join(d, "single"))
+    os.chdir(os.path.join(d, "single"))
+    C1, F1 = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    script = os.path.join(d, "worker.py")
+    with open(script, "w") as fp:
+        fp.write(WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", script, ini, d],
+                          env=env, timeout=600)
+    for r in (0, 1):
+        C = np.load(os.path.join(d, "r%d" % r, "ctabs_rank%d.npy" % r))
+        assert np.allclose(C, C1, rtol=1e-5, atol=1e-7 * np.abs(C1).max())
+    # rank 0 wrote the absorbed file; per-frequency tallies were all-reduced before they were pulled
+    from soc_amd import files
+    A = files.read_absorbed(os.path.join(d, "abs.data"))
+    want = files.scale_absorbed(F1.copy(), cloud, 0.5) if (F1 >= 0).all() else F1
+    assert np.allclose(A, want, rtol=1e-5, atol=1e-7 * np.abs(want).max())

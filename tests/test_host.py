@@ -1,0 +1,192 @@
+"""Host side of the drop-in: ini parsing, file formats, launch arithmetic, the ASOC driver
+loop (on an oracle-backed engine) -- no GPU needed."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from soc_amd import files, launch, synth
+from soc_amd.asoc import AbsorptionRun, UnsupportedOption
+from soc_amd.ini import User
+
+MY_INI = """
+gridlength      0.01              # root grid cells have a size of 0.01 pc each
+cloud           tmp.cloud          # density field (reference to a file)
+mapping         64 64 1.0          # output 64x64 pixels, pixel size == root-grid cell size
+density         1.0e3              # scale values read from tmp.cloud
+seed           -1.0                # random seed for random numbers
+directions      0.0  0.0           # observer in direction (theta,phi)
+optical         tmp.dust           # dust optical parameters
+dsc             tmp.dsc  2500      # dust scattering function
+bgpackets       999999             # photon packages simulated from the background
+background      bg_intensity.bin   # background intensity at the
+iterations      1                  # one iteration is enough
+prefix          tmp                # prefix for output files
+absorbed        absorbed.data      # save absorptions to a file
+emitted         emitted.data       # save dust emission to a file
+noabsorbed                         # actually, we integrate absorptions on the fly and skip the *file*
+temperature     tmp.T              # save dust temperatures
+device          g                  # run calculations on a GPU
+CLT                                # temperature caclulations done on the device
+CLE                                # emission calculations done on the device
+"""
+
+
+def test_example_ini_matches_hand_derived_values():
+    """Expected attributes derived by hand from ASOC_aux.py:239-537 for soc_example.zip/my.ini."""
+    U = User(text=MY_INI)
+    assert U.GL == 0.01 and U.file_cloud == 'tmp.cloud' and U.KDENSITY == 1.0e3
+    assert U.NPIX == (64, 64) and U.MAP_DX == 1.0
+    assert U.SEED == -1.0
+    assert U.OBS_THETA == [0.0] and U.OBS_PHI == [0.0]
+    assert U.file_optical == ['tmp.dust'] and U.file_abundance == ['#']
+    assert U.file_scafunc == ['tmp.dsc'] and U.DSC_BINS == 2500
+    assert U.BGPAC == 999999 and U.file_background == 'bg_intensity.bin'
+    assert U.ITERATIONS == 1 and U.file_absorbed == 'absorbed.data' and U.file_emitted == 'emitted.data'
+    assert U.NOABSORBED == 1 and U.file_temperature == 'tmp.T' and U.DEVICES == 'g'
+    assert 'CLT' in U.KEYS and 'CLE' in U.KEYS and U.KEYS['prefix'] == ['tmp']
+    assert U.NOSOLVE == 0 and U.NOMAP == 0
+    assert U.Validate()
+
+
+def test_prefix_matching_gotchas():
+    """SURVEY.md Appendix A, "gotchas worth a unit test each"."""
+    U = User(text="density 5\ndens 7\n")                       # both hit `dens`
+    assert U.KDENSITY == 7.0
+    assert User(text="emitted x.e\n").file_emitted == 'x.e'     # emit matches emitted
+    assert User(text="scatter out.s\n").file_scattering == 'out.s'
+    U = User(text="background b.bin 2.0\nhpbg h.bin 3.0 1\n")   # share scale_background
+    assert U.scale_background == 3.0 and U.HPBG_WEIGHTED == 1 and U.file_hpbg == 'h.bin'
+    U = User(text="diffpack 500\ncellpackets 1e3\n")            # cellpac>0 overrides diffpac
+    assert U.CLPAC == 1000 and U.DFPAC == 1000
+    with pytest.raises(ValueError):
+        User(text="diffpack 1e3\n")                             # int('1e3') fails, as in the reference
+    U = User(text="cloud c\npointsource 1 2 3 ps.bin 2.5\npspackets 0\n")
+    assert U.NO_PS == 1 and U.PS_SCALING[0] == 2.5 and list(U.PSPOS[0, :3]) == [1.0, 2.0, 3.0]
+    U.Validate()
+    assert U.NO_PS == 0                                         # pspac==0 discards point sources
+    assert User(text="seed 17\n").SEED == 1.0                   # clipped to [-1,1]
+    assert User(text="bgpackets 1e8\nbgpac 2e6\n").BGPAC == 2000000
+    U = User(text="simum 0.60 0.68\nremit 10 1000\n")
+    assert abs(U.SIM_F[0] - launch.um2f(0.68)) < 1 and abs(U.SIM_F[1] - launch.um2f(0.60)) < 1
+    U = User(text="optical a.dust a.abu\noptical b.dust #\noptical c.dust\n")
+    assert U.file_abundance == ['a.abu', '#', '#']
+    U = User(text="directions 30 60\ndirewei 1 0.5\nnoabsorbed\nNOMAP\ndustem\n")
+    assert len(U.OBS_THETA) == 1 and U.DIR_WEIGHT == [1, 0.5] and U.NOMAP == 1 and U.SAVE_INTENSITY == 1
+    U = User(text="emweight 1 0.5 10 0.1 4\nlevels 3\npsmethod 2\nglobal 65536\n")
+    assert U.USE_EMWEIGHT == 1 and U.EMWEIGHT_LIM == [0.5, 10.0, 0.1] and U.EMWEIGHT_SKIP == 4
+    assert U.LEVELS == 3 and U.PS_METHOD == 2 and U.GLOBAL == 65536
+
+
+def test_launch_arithmetic_pins():
+    """C1 AREA 6144, GLOBAL 49152, BATCH 20, BGPAC 983040; C2 786432/127/99876864;
+    256^3: 3145728/318/1000341504; seed(pi/4, IFREQ 0) = 0.6004964104."""
+    for N, bg, G, B, P in ((32, 1000000, 49152, 20, 983040), (128, 100000000, 786432, 127, 99876864),
+                           (256, 1000000000, 3145728, 318, 1000341504)):
+        L = launch.bg_launch(launch.packet_counts(bg, 0, 0, 0, 6 * N * N, N ** 3)["BGPAC"], 6 * N * N)
+        assert (L["GLOBAL"], L["BATCH"], L["PACKETS"]) == (G, B, P)
+        assert L["WBG"] == math.pi / (launch.PLANCK * 8 * B)
+    assert abs(launch.launch_seed(math.pi / 4, 0) - 0.6004964104) < 1e-9
+    L = launch.ps_launch(launch.Fix(1000000000, 32), 1, 0.02)
+    assert (L["GLOBAL"], L["BATCH"], L["PACKETS"]) == (32768, 30517, 999981056)
+    assert launch.Fix(10, 8) == 16 and launch.Fix(16, 8) == 16
+    F = np.asarray([1.0, 2.0, 4.0, 8.0], np.float32)
+    assert launch.trapezoid_weight(F, 0) == 0.5 and launch.trapezoid_weight(F, 1) == 2 * 1.5 and launch.trapezoid_weight(F, 3) == 8 * 2.0
+    for G in (100, 49152, 786432, 3145729):
+        for W in (1, 2, 3, 8):
+            parts = [launch.shard_range(G, r, W) for r in range(W)]
+            assert sum(c for _, c in parts) == G
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(W - 1))
+
+
+def test_cloud_file_round_trip(tmp_path):
+    for cloud in (synth.cartesian_cloud(5, seed=1, NY=4, NZ=3), synth.octree_cloud(6, levels=3, frac=0.2, seed=2)):
+        fn = str(tmp_path / "c.cloud")
+        cloud.write(fn)
+        raw = np.fromfile(fn, np.int32, 5)
+        assert list(raw) == [cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, cloud.CELLS]
+        back = files.read_cloud(fn)
+        assert np.array_equal(back.DENS.view(np.uint32), cloud.DENS.view(np.uint32))
+        assert np.array_equal(back.OFF, cloud.OFF) and np.array_equal(back.LCELLS, cloud.LCELLS)
+        scaled = files.read_cloud(fn, kdensity=1e-9)
+        leaf = cloud.DENS > 0
+        assert np.array_equal(scaled.DENS[~leaf].view(np.uint32), cloud.DENS[~leaf].view(np.uint32))   # links untouched
+        assert (scaled.DENS[leaf] >= np.float32(1e-6)).all()                                            # clip floor
+
+
+def _write_model(d, cloud, nfreq=3, with_ps=False, with_diffuse=False, extra=""):
+    cloud.write(os.path.join(d, "m.cloud"))
+    freq = np.asarray([4.0e14, 4.677e14, 5.4e14][:nfreq])
+    with open(os.path.join(d, "m.dust"), "w") as fp:
+        fp.write("eqdust\n 1.0e-7\n 1.0e-4\n%d\n" % nfreq)
+        for f in freq:
+            fp.write(" %.5e  0.6  %.5e  %.5e\n" % (f, 3.0e-2, 9.0e-2))
+    dsc, csc = synth.hg_scattering_table(0.6, 500)
+    files.write_scattering_functions(os.path.join(d, "m.dsc"), np.tile(dsc, (nfreq, 1)), np.tile(csc, (nfreq, 1)))
+    np.asarray([1e-13, 2e-13, 1.5e-13][:nfreq], np.float32).tofile(os.path.join(d, "bg.bin"))
+    ini = ("gridlength 0.5\ncloud %s/m.cloud\noptical %s/m.dust\ndsc %s/m.dsc 500\nbackground %s/bg.bin\n"
+           "bgpackets 20000\nseed 0.7853981634\niterations 1\nnosolve\nnomap\nabsorbed %s/abs.data\n"
+           "csave %s/ctabs.bin\ndevice g\nverbose 0\n" % (d, d, d, d, d, d))
+    if with_ps:
+        np.asarray([1e20, 2e20, 1.5e20][:nfreq], np.float32).tofile(os.path.join(d, "ps.bin"))
+        ini += "pointsource 3.3 3.2 3.1 %s/ps.bin\npspackets 4000\nglobal 128\n" % d
+    if with_diffuse:
+        files.write_diffuserad(os.path.join(d, "diff.bin"),
+                               np.where(cloud.DENS > 0, 1e-30 * cloud.DENS, 0)[:, None] * np.ones((1, nfreq)))
+        ini += "diffuse %s/diff.bin\ndiffpack %d\nglobal 128\n" % (d, 2 * cloud.CELLS)
+    ini += extra
+    with open(os.path.join(d, "m.ini"), "w") as fp:
+        fp.write(ini)
+    return os.path.join(d, "m.ini")
+
+
+def test_driver_loop_on_oracle_engine(tmp_path):
+    """The II x IFREQ loop, weights, seeds and output files, with every launch independently
+    re-derived from the reference formulas here."""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _write_model(d, cloud, with_ps=True, with_diffuse=True)
+    U = User(ini)
+    run = AbsorptionRun(U, OracleEngine("soc"))
+    os.chdir(d)
+    CTABS, FABS = run.run()
+    assert list(np.fromfile(os.path.join(d, "packet.info"), np.int32)) == [run.BGPAC, run.PSPAC, run.DFPAC, run.CLPAC]
+    assert run.BGPAC == launch.Fix(launch.Fix(20000, 216), 32) and run.PSPAC == 4000
+    # independent evaluation of one block: background, all three frequencies
+    orc = Oracle("soc")
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 3, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, 216)
+    T = np.zeros(cloud.CELLS, np.float32)
+    F = np.zeros((cloud.CELLS, 3), np.float32)
+    for i in range(3):
+        job = Job(cloud, FCSC[0, i], ABS=AFABS[0][i], SCA=AFSCA[0][i], SOURCE=1, BATCH=L["BATCH"],
+                  SEED=launch.launch_seed(math.pi / 4, i), BG=np.float32(float(IBG[i]) * L["WBG"] / float(FFREQ[i])),
+                  TW=launch.trapezoid_weight(FFREQ, i), GLOBAL=L["GLOBAL"], WITH_INT=1)
+        I = np.zeros(cloud.CELLS, np.float32)
+        orc.sim(job, 0, TABS=T, INT=I)
+        F[:, i] = I
+    # the file holds PS + BG + diffuse; check the structure, then the BG block through a BG-only run
+    absd = files.read_absorbed(os.path.join(d, "abs.data"))
+    assert absd.shape == (cloud.CELLS, 3)
+    assert (absd[cloud.DENS <= 0] == np.float32(-1e20)).all() and (absd[cloud.DENS > 0] >= 0).all()
+    assert np.array_equal(np.fromfile(os.path.join(d, "ctabs.bin"), np.float32), CTABS)
+    ini2 = _write_model(d, cloud)            # background only
+    run2 = AbsorptionRun(User(ini2), OracleEngine("soc"))
+    C2, F2 = run2.run()
+    assert np.array_equal(C2, T)
+    want = files.scale_absorbed(F.copy(), cloud, 0.5)
+    assert np.allclose(files.read_absorbed(os.path.join(d, "abs.data")), want, rtol=1e-6)
+
+
+def test_unsupported_options_fail_loudly(tmp_path):
+    from oracle_engine import OracleEngine
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(4, seed=1)
+    for extra in ("mirror xX\n", "split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n", "hpbg sky.bin\n"):
+        with pytest.raises(UnsupportedOption):
+            AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
