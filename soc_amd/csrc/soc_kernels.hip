@@ -51,7 +51,12 @@ __device__ __forceinline__ void soc_normalize(float &x, float &y, float &z)
 
 __device__ __forceinline__ void soc_tally(float *buf, int oind, float v)
 {
+#if defined(SOC_EXPERIMENT_NO_TALLY)
+    // timing experiment only (never shipped): keep the value alive without touching memory
+    if (v == 1.2345e-30f) buf[oind] = v;
+#else
     __hip_atomic_fetch_add(buf + oind, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 template <typename T> struct SocReal;
@@ -251,10 +256,12 @@ struct SocWalker {
         free_path = -soc_logf(soc_rand(&rng));
     }
 
-    // one pass of the inner loop body (kernel_ASOC.c:565-683) or, when the free path ends
-    // inside the cell, the scattering block (kernel_ASOC.c:700-804 / 1545-1676)
+    // One pass of the inner loop body (kernel_ASOC.c:565-683).  Returns true when the free
+    // path ends inside the cell: the lane is then put back to the state it had at the
+    // beginning of the step (what the reference does with ind0/level0/POS0) and the
+    // scattering block is left to scatter(), which may run later -- nothing it needs is lost.
     template <bool CL_ORDER>
-    __device__ __forceinline__ void step(const SocGrid &G, const SocSim &S, const float *sCSC, const int *sOFF)
+    __device__ __forceinline__ bool step(const SocGrid &G, const SocSim &S, const int *sOFF)
     {
         const int   oind = sOFF[level] + ind;
         const int   ind0 = ind, level0 = level;
@@ -273,49 +280,81 @@ struct SocWalker {
         float tauA = ds * d0 * kabs;
         float dtau = ds * d0 * ksca;
         if (free_path < (tau + dtau)) {
-            // ---- scattering inside cell (level0, ind0) ----
-            scat++;
-            if (CL_ORDER && (scat > 20)) { ind = -1; return; }
-            float dt = free_path - tau;
-            float dx = dt / (ksca * d0);
-            tauA = dx * d0 * kabs;
-            float e = soc_expf(-tauA);
-            float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-            soc_tally(S.TABS, oind, delta * S.TW);
-            if (WINT) soc_tally(S.INT, oind, delta);
-            n_tally++;
-            n_scat++;
-            dx = soc_scale_up(dx, level0);
-            dx = __builtin_fmaxf(0.0f, dx - 2.0f * SOC_PEPS);
-            px = p0x + dx * ux;
-            py = p0y + dx * uy;
-            pz = p0z + dx * uz;
-            photons *= e;
-            free_path = -soc_logf(soc_rand(&rng));
-            ind   = ind0;
-            level = level0;
-            dens  = d0;
-            soc_scatter(ux, uy, uz, sCSC, S.BINS, &rng);
-            if (!CL_ORDER && (scat > 20)) ind = -1;
-            tau = 0.0f;
-        } else {
-            float e = soc_expf(-tauA);
-            float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-            soc_tally(S.TABS, oind, delta * S.TW);
-            if (WINT) soc_tally(S.INT, oind, delta);
-            n_tally++;
-            photons *= e;
-            tau += dtau;
-            if (!CL_ORDER) {
-                if ((level == level0) && (ind == ind0)) {   // failed step: nudge (kernel_ASOC.c:649-653)
-                    px += SOC_PEPS * ux;
-                    py += SOC_PEPS * uy;
-                    pz += SOC_PEPS * uz;
-                }
+            px = p0x;  py = p0y;  pz = p0z;
+            ind = ind0;  level = level0;  dens = d0;
+            return true;
+        }
+        float e = soc_expf(-tauA);
+        float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+        soc_tally(S.TABS, oind, delta * S.TW);
+        if (WINT) soc_tally(S.INT, oind, delta);
+        n_tally++;
+        photons *= e;
+        tau += dtau;
+        if (!CL_ORDER) {
+            if ((level == level0) && (ind == ind0)) {       // failed step: nudge (kernel_ASOC.c:649-653)
+                px += SOC_PEPS * ux;
+                py += SOC_PEPS * uy;
+                pz += SOC_PEPS * uz;
             }
         }
+        return false;
+    }
+
+    // The scattering block (kernel_ASOC.c:700-804, SimRAM_CL: 1545-1676) for a lane that
+    // step() returned true for.  Leaves ind < 0 when the packet is dropped (> 20 scatterings).
+    template <bool CL_ORDER>
+    __device__ __forceinline__ void scatter(const SocSim &S, const float *sCSC, const int *sOFF)
+    {
+        const int oind = sOFF[level] + ind;
+        float kabs, ksca;
+        if (ABU) {
+            float2 o = S.OPT[oind];
+            kabs = o.x;
+            ksca = o.y;
+        } else {
+            kabs = S.ABS;
+            ksca = S.SCA;
+        }
+        scat++;
+        if (CL_ORDER && (scat > 20)) { ind = -1; return; }
+        float dt = free_path - tau;
+        float dx = dt / (ksca * dens);
+        float tauA = dx * dens * kabs;
+        float e = soc_expf(-tauA);
+        float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+        soc_tally(S.TABS, oind, delta * S.TW);
+        if (WINT) soc_tally(S.INT, oind, delta);
+        n_tally++;
+        n_scat++;
+        dx = soc_scale_up(dx, level);
+        dx = __builtin_fmaxf(0.0f, dx - 2.0f * SOC_PEPS);
+        px = px + dx * ux;
+        py = py + dx * uy;
+        pz = pz + dx * uz;
+        photons *= e;
+        free_path = -soc_logf(soc_rand(&rng));
+        soc_scatter(ux, uy, uz, sCSC, S.BINS, &rng);
+        if (!CL_ORDER && (scat > 20)) ind = -1;
+        tau = 0.0f;
     }
 };
+
+// Lane modes of the per-lane state machine.  Rare arms (packet creation, scattering) are
+// not entered the moment ONE lane needs them -- that ran them at 1-2 active lanes on nearly
+// every iteration (measured: 927 VALU instructions per wave-iteration at 15 % lane
+// utilisation) -- but when a wave ballot shows SOC_SERVICE_LANES lanes waiting, or nobody
+// can step.  A lane's own sequence of operations (and RNG draws) is unchanged.
+enum { SOC_M_STEP = 0, SOC_M_CREATE = 1, SOC_M_SCATTER = 2, SOC_M_DONE = 3 };
+#ifndef SOC_SERVICE_LANES
+#define SOC_SERVICE_LANES 12
+#endif
+
+__device__ __forceinline__ bool soc_service_now(bool waiting, bool nobody_steps)
+{
+    unsigned long long m = __ballot(waiting);
+    return (m != 0ull) && (nobody_steps || (__popcll(m) >= SOC_SERVICE_LANES));
+}
 
 __device__ __forceinline__ void soc_stage_lds(const SocGrid &G, const SocSim &S, float *sCSC, int *sOFF, int *sLC)
 {
@@ -396,119 +435,137 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
     }
 
     int III = 0;
+    int mode = SOC_M_CREATE;
     while (true) {
-        if (w.ind < 0) {
-            if (III >= S.BATCH) break;
-            // ---------------- create packet III ----------------
-            if (S.SOURCE == 1) {
-                w.px = soc_clampf(X0 + DX * soc_rand(&w.rng), SOC_PEPS, NX - SOC_PEPS);
-                w.py = soc_clampf(Y0 + DY * soc_rand(&w.rng), SOC_PEPS, NY - SOC_PEPS);
-                w.pz = soc_clampf(Z0 + DZ * soc_rand(&w.rng), SOC_PEPS, NZ - SOC_PEPS);
-                float cos_theta = soc_sqrtf(soc_rand(&w.rng));
-                float phi       = SOC_TWOPI * soc_rand(&w.rng);
-                float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
-                float sp, cp;
-                soc_sincosf(phi, &sp, &cp);
-                float v1 = sin_theta * cp, v2 = sin_theta * sp;
-                switch (SIDE) {
-                case 0: w.ux =  cos_theta; w.uy = v1; w.uz = v2; break;
-                case 1: w.ux = -cos_theta; w.uy = v1; w.uz = v2; break;
-                case 2: w.uy =  cos_theta; w.ux = v1; w.uz = v2; break;
-                case 3: w.uy = -cos_theta; w.ux = v1; w.uz = v2; break;
-                case 4: w.uz =  cos_theta; w.ux = v1; w.uy = v2; break;
-                default: w.uz = -cos_theta; w.ux = v1; w.uy = v2; break;
-                }
-                w.photons = S.BG;
-                soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-            } else {
-                // point sources, kernel_ASOC.c:202-434
-                float phi       = SOC_TWOPI * soc_rand(&w.rng);
-                float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
-                float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
-                float sp, cp;
-                soc_sincosf(phi, &sp, &cp);
-                w.ux = sin_theta * cp;
-                w.uy = sin_theta * sp;
-                w.uz = cos_theta;
-                const int isrc = III % S.NO_PS;
-                w.photons = S.PS[isrc];
-                const float4 src = S.PSPOS[isrc];
-                w.px = src.x;  w.py = src.y;  w.pz = src.z;
-                soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                if ((w.ind < 0) || (w.ind >= G.CELLS)) {
-                    const int method = S.PS_METHOD;
-                    if (method == 0) {
-                        soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
-                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                    } else if (method == 1) {
-                        if (src.z > NZ) {
-                            if (w.uz > 0.0f) w.uz = -w.uz;
-                        } else if (src.z < 0.0f) {
-                            if (w.uz < 0.0f) w.uz = -w.uz;
-                        } else if (src.x > NX) {
-                            if (w.ux > 0.0f) w.ux = -w.ux;
-                        } else if (src.x < 0.0f) {
-                            if (w.ux < 0.0f) w.ux = -w.ux;
-                        } else if (src.y > NY) {
-                            if (w.uy > 0.0f) w.uy = -w.uy;
-                        } else if (src.y < 0.0f) {
-                            if (w.uy < 0.0f) w.uy = -w.uy;
+        const bool nobody_steps = (__ballot(mode == SOC_M_STEP) == 0ull);
+        if (soc_service_now(mode == SOC_M_CREATE, nobody_steps)) {
+            if (mode == SOC_M_CREATE) {
+                if (III >= S.BATCH) {
+                    mode = SOC_M_DONE;
+                } else {
+                // ---------------- create packet III ----------------
+                if (S.SOURCE == 1) {
+                    w.px = soc_clampf(X0 + DX * soc_rand(&w.rng), SOC_PEPS, NX - SOC_PEPS);
+                    w.py = soc_clampf(Y0 + DY * soc_rand(&w.rng), SOC_PEPS, NY - SOC_PEPS);
+                    w.pz = soc_clampf(Z0 + DZ * soc_rand(&w.rng), SOC_PEPS, NZ - SOC_PEPS);
+                    float cos_theta = soc_sqrtf(soc_rand(&w.rng));
+                    float phi       = SOC_TWOPI * soc_rand(&w.rng);
+                    float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
+                    float sp, cp;
+                    soc_sincosf(phi, &sp, &cp);
+                    float v1 = sin_theta * cp, v2 = sin_theta * sp;
+                    switch (SIDE) {
+                    case 0: w.ux =  cos_theta; w.uy = v1; w.uz = v2; break;
+                    case 1: w.ux = -cos_theta; w.uy = v1; w.uz = v2; break;
+                    case 2: w.uy =  cos_theta; w.ux = v1; w.uz = v2; break;
+                    case 3: w.uy = -cos_theta; w.ux = v1; w.uz = v2; break;
+                    case 4: w.uz =  cos_theta; w.ux = v1; w.uy = v2; break;
+                    default: w.uz = -cos_theta; w.ux = v1; w.uy = v2; break;
+                    }
+                    w.photons = S.BG;
+                    soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                } else {
+                    // point sources, kernel_ASOC.c:202-434
+                    float phi       = SOC_TWOPI * soc_rand(&w.rng);
+                    float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
+                    float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
+                    float sp, cp;
+                    soc_sincosf(phi, &sp, &cp);
+                    w.ux = sin_theta * cp;
+                    w.uy = sin_theta * sp;
+                    w.uz = cos_theta;
+                    const int isrc = III % S.NO_PS;
+                    w.photons = S.PS[isrc];
+                    const float4 src = S.PSPOS[isrc];
+                    w.px = src.x;  w.py = src.y;  w.pz = src.z;
+                    soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                    if ((w.ind < 0) || (w.ind >= G.CELLS)) {
+                        const int method = S.PS_METHOD;
+                        if (method == 0) {
+                            soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
+                            soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                        } else if (method == 1) {
+                            if (src.z > NZ) {
+                                if (w.uz > 0.0f) w.uz = -w.uz;
+                            } else if (src.z < 0.0f) {
+                                if (w.uz < 0.0f) w.uz = -w.uz;
+                            } else if (src.x > NX) {
+                                if (w.ux > 0.0f) w.ux = -w.ux;
+                            } else if (src.x < 0.0f) {
+                                if (w.ux < 0.0f) w.ux = -w.ux;
+                            } else if (src.y > NY) {
+                                if (w.uy > 0.0f) w.uy = -w.uy;
+                            } else if (src.y < 0.0f) {
+                                if (w.uy < 0.0f) w.uy = -w.uy;
+                            }
+                            soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
+                            w.photons *= 0.5f;
+                            soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                        } else if (method == 2) {
+                            int k = (int)soc_floorf(soc_rand(&w.rng) * S.XPS_NSIDE[isrc] * 0.999999f);
+                            w.photons /= S.XPS_AREA[3 * isrc + k];
+                            const int side = S.XPS_SIDE[3 * isrc + k];
+                            float a = soc_rand(&w.rng), b = soc_rand(&w.rng);
+                            if (side == 0) { w.px = NX - SOC_PEPS;  w.py = a * NY;  w.pz = b * NZ;  b = NY * NZ; }
+                            if (side == 1) { w.px = SOC_PEPS;       w.py = a * NY;  w.pz = b * NZ;  b = NY * NZ; }
+                            if (side == 2) { w.py = NY - SOC_PEPS;  w.px = a * NX;  w.pz = b * NZ;  b = NX * NZ; }
+                            if (side == 3) { w.py = SOC_PEPS;       w.px = a * NX;  w.pz = b * NZ;  b = NX * NZ; }
+                            if (side == 4) { w.pz = NZ - SOC_PEPS;  w.px = a * NX;  w.py = b * NY;  b = NX * NY; }
+                            if (side == 5) { w.pz = SOC_PEPS;       w.px = a * NX;  w.py = b * NY;  b = NX * NY; }
+                            w.ux = w.px - src.x;  w.uy = w.py - src.y;  w.uz = w.pz - src.z;
+                            float v1 = soc_sqrtf(w.ux * w.ux + w.uy * w.uy + w.uz * w.uz);
+                            soc_normalize(w.ux, w.uy, w.uz);
+                            float v2 = (side < 2) ? soc_fabsf(w.ux) : ((side < 4) ? soc_fabsf(w.uy) : soc_fabsf(w.uz));
+                            w.photons *= v2 * b / (4.0f * SOC_PI * v1 * v1);
+                            soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                        } else if (method == 4) {
+                            float v1 = src.z - NZ;
+                            float ct = v1 / soc_sqrtf(v1 * v1 + 0.25f * NX * NX + 0.25f * NY * NY);
+                            w.photons *= 0.5f * (1.0f - ct);
+                            ct = 1.0f - soc_rand(&w.rng) * (1.0f - ct);
+                            v1 = SOC_TWOPI * soc_rand(&w.rng);
+                            float s1, c1;
+                            soc_sincosf(v1, &s1, &c1);
+                            w.ux = soc_sqrtf(1.0f - ct * ct) * c1;
+                            w.uy = soc_sqrtf(1.0f - ct * ct) * s1;
+                            w.uz = -ct;
+                            soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
+                            soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                        } else if (method == 5) {
+                            float ct = S.XPS_AREA[3 * isrc];
+                            w.photons *= 0.5f * (1.0f - ct);
+                            ct = 1.0f - soc_rand(&w.rng) * (1.0f - ct);
+                            float v1 = SOC_TWOPI * soc_rand(&w.rng);
+                            const int side = S.XPS_SIDE[3 * isrc];
+                            float s1, c1;
+                            soc_sincosf(v1, &s1, &c1);
+                            float a = soc_sqrtf(1.0f - ct * ct) * c1;
+                            float b = soc_sqrtf(1.0f - ct * ct) * s1;
+                            if (side < 2)      { w.uy = a;  w.uz = b;  w.ux = (side == 0) ? -ct : +ct; }
+                            else if (side < 4) { w.ux = a;  w.uz = b;  w.uy = (side == 2) ? -ct : +ct; }
+                            else               { w.ux = a;  w.uy = b;  w.uz = (side == 4) ? -ct : +ct; }
+                            soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
+                            soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
                         }
-                        soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
-                        w.photons *= 0.5f;
-                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                    } else if (method == 2) {
-                        int k = (int)soc_floorf(soc_rand(&w.rng) * S.XPS_NSIDE[isrc] * 0.999999f);
-                        w.photons /= S.XPS_AREA[3 * isrc + k];
-                        const int side = S.XPS_SIDE[3 * isrc + k];
-                        float a = soc_rand(&w.rng), b = soc_rand(&w.rng);
-                        if (side == 0) { w.px = NX - SOC_PEPS;  w.py = a * NY;  w.pz = b * NZ;  b = NY * NZ; }
-                        if (side == 1) { w.px = SOC_PEPS;       w.py = a * NY;  w.pz = b * NZ;  b = NY * NZ; }
-                        if (side == 2) { w.py = NY - SOC_PEPS;  w.px = a * NX;  w.pz = b * NZ;  b = NX * NZ; }
-                        if (side == 3) { w.py = SOC_PEPS;       w.px = a * NX;  w.pz = b * NZ;  b = NX * NZ; }
-                        if (side == 4) { w.pz = NZ - SOC_PEPS;  w.px = a * NX;  w.py = b * NY;  b = NX * NY; }
-                        if (side == 5) { w.pz = SOC_PEPS;       w.px = a * NX;  w.py = b * NY;  b = NX * NY; }
-                        w.ux = w.px - src.x;  w.uy = w.py - src.y;  w.uz = w.pz - src.z;
-                        float v1 = soc_sqrtf(w.ux * w.ux + w.uy * w.uy + w.uz * w.uz);
-                        soc_normalize(w.ux, w.uy, w.uz);
-                        float v2 = (side < 2) ? soc_fabsf(w.ux) : ((side < 4) ? soc_fabsf(w.uy) : soc_fabsf(w.uz));
-                        w.photons *= v2 * b / (4.0f * SOC_PI * v1 * v1);
-                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                    } else if (method == 4) {
-                        float v1 = src.z - NZ;
-                        float ct = v1 / soc_sqrtf(v1 * v1 + 0.25f * NX * NX + 0.25f * NY * NY);
-                        w.photons *= 0.5f * (1.0f - ct);
-                        ct = 1.0f - soc_rand(&w.rng) * (1.0f - ct);
-                        v1 = SOC_TWOPI * soc_rand(&w.rng);
-                        float s1, c1;
-                        soc_sincosf(v1, &s1, &c1);
-                        w.ux = soc_sqrtf(1.0f - ct * ct) * c1;
-                        w.uy = soc_sqrtf(1.0f - ct * ct) * s1;
-                        w.uz = -ct;
-                        soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
-                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                    } else if (method == 5) {
-                        float ct = S.XPS_AREA[3 * isrc];
-                        w.photons *= 0.5f * (1.0f - ct);
-                        ct = 1.0f - soc_rand(&w.rng) * (1.0f - ct);
-                        float v1 = SOC_TWOPI * soc_rand(&w.rng);
-                        const int side = S.XPS_SIDE[3 * isrc];
-                        float s1, c1;
-                        soc_sincosf(v1, &s1, &c1);
-                        float a = soc_sqrtf(1.0f - ct * ct) * c1;
-                        float b = soc_sqrtf(1.0f - ct * ct) * s1;
-                        if (side < 2)      { w.uy = a;  w.uz = b;  w.ux = (side == 0) ? -ct : +ct; }
-                        else if (side < 4) { w.ux = a;  w.uz = b;  w.uy = (side == 2) ? -ct : +ct; }
-                        else               { w.ux = a;  w.uy = b;  w.uz = (side == 4) ? -ct : +ct; }
-                        soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
-                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
                     }
                 }
+                    III++;
+                    w.begin();
+                    mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+                }
             }
-            III++;
-            w.begin();
         }
-        if (w.ind >= 0) w.template step<false>(G, S, sCSC, sOFF);
+        if (soc_service_now(mode == SOC_M_SCATTER, nobody_steps)) {
+            if (mode == SOC_M_SCATTER) {
+                w.template scatter<false>(S, sCSC, sOFF);
+                mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+            }
+        }
+        if (__ballot(mode != SOC_M_DONE) == 0ull) break;
+        if (mode == SOC_M_STEP) {
+            if (w.template step<false>(G, S, sOFF)) mode = SOC_M_SCATTER;
+            else if (w.ind < 0) mode = SOC_M_CREATE;
+        }
     }
     soc_flush_stats(S, w.n_tally, (unsigned int)III, w.n_scat);
 }
@@ -542,74 +599,89 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
     int   IRAY = 0, batch = -1;
     float PWEI = 1.0f;
     unsigned int n_pkt = 0;
-    bool  done = false;
+    int   mode = SOC_M_CREATE;
 
     while (true) {
-        if (w.ind < 0) {
-            if (IRAY >= batch) {                           // next emitting cell (kernel_ASOC.c:1318-1355)
-                IRAY = 0;
-                PWEI = 1.0f;
-                while (true) {
-                    ICELL += S.GLOBAL;
-                    if (ICELL >= G.CELLS) { done = true; break; }
-                    if (S.USE_EMWEIGHT > 0) {
-                        PWEI = S.EMWEI[ICELL];
-                        if ((PWEI < 1e-10f) || (G.DENS[ICELL] <= 0.0f)) continue;
-                        batch = (int)soc_floorf(PWEI);
-                        if (batch < 1) {
-                            batch = 1;
-                            PWEI  = (float)(1.0 / (double)(PWEI + 1.0e-30f));
+        const bool nobody_steps = (__ballot(mode == SOC_M_STEP) == 0ull);
+        if (soc_service_now(mode == SOC_M_CREATE, nobody_steps)) {
+            if (mode == SOC_M_CREATE) {
+                if (IRAY >= batch) {                       // next emitting cell (kernel_ASOC.c:1318-1355)
+                    IRAY = 0;
+                    PWEI = 1.0f;
+                    while (true) {
+                        ICELL += S.GLOBAL;
+                        if (ICELL >= G.CELLS) { mode = SOC_M_DONE; break; }
+                        if (S.USE_EMWEIGHT > 0) {
+                            PWEI = S.EMWEI[ICELL];
+                            if ((PWEI < 1e-10f) || (G.DENS[ICELL] <= 0.0f)) continue;
+                            batch = (int)soc_floorf(PWEI);
+                            if (batch < 1) {
+                                batch = 1;
+                                PWEI  = (float)(1.0 / (double)(PWEI + 1.0e-30f));
+                            } else {
+                                PWEI = (float)(1.0 / (double)(batch + 1.0e-9f));
+                            }
                         } else {
-                            PWEI = (float)(1.0 / (double)(batch + 1.0e-9f));
+                            batch = S.BATCH;
+                            PWEI  = 1.0f / (batch + 1.0e-9f);
                         }
-                    } else {
-                        batch = S.BATCH;
-                        PWEI  = 1.0f / (batch + 1.0e-9f);
+                        break;
                     }
-                    break;
                 }
-                if (done) break;
-            }
-            int ind = (int)ICELL;
-            IRAY += 1;
-            int level;
-            for (level = 0; level < G.LEVELS - 1; level++) {
-                ind -= sLC[level];
-                if (ind < 0) {
-                    ind += sLC[level];
-                    break;
+                if (mode != SOC_M_DONE) {
+                    int ind = (int)ICELL;
+                    IRAY += 1;
+                    int level;
+                    for (level = 0; level < G.LEVELS - 1; level++) {
+                        ind -= sLC[level];
+                        if (ind < 0) {
+                            ind += sLC[level];
+                            break;
+                        }
+                    }
+                    float X0, Y0, Z0;
+                    if (level == 0) {
+                        X0 = (ind % NX);
+                        Y0 = ((ind / NX) % NY);
+                        Z0 = (ind / (NX * NY));
+                    } else {
+                        int sid = ind % 8;
+                        X0 = (sid % 2);
+                        Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;
+                        Z0 = (sid / 4);
+                    }
+                    w.level   = level;
+                    w.ind     = ind;
+                    w.dens    = G.DENS[sOFF[level] + ind];
+                    w.photons = S.EMIT[sOFF[level] + ind] * PWEI;
+                    w.px = X0 + soc_rand(&w.rng);
+                    w.py = Y0 + soc_rand(&w.rng);
+                    w.pz = Z0 + soc_rand(&w.rng);
+                    float phi       = SOC_TWOPI * soc_rand(&w.rng);
+                    float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
+                    float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
+                    float sp, cp;
+                    soc_sincosf(phi, &sp, &cp);
+                    w.ux = sin_theta * cp;
+                    w.uy = sin_theta * sp;
+                    w.uz = cos_theta;
+                    n_pkt++;
+                    w.begin();
+                    mode = SOC_M_STEP;
                 }
             }
-            float X0, Y0, Z0;
-            if (level == 0) {
-                X0 = (ind % NX);
-                Y0 = ((ind / NX) % NY);
-                Z0 = (ind / (NX * NY));
-            } else {
-                int sid = ind % 8;
-                X0 = (sid % 2);
-                Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;
-                Z0 = (sid / 4);
-            }
-            w.level   = level;
-            w.ind     = ind;
-            w.dens    = G.DENS[sOFF[level] + ind];
-            w.photons = S.EMIT[sOFF[level] + ind] * PWEI;
-            w.px = X0 + soc_rand(&w.rng);
-            w.py = Y0 + soc_rand(&w.rng);
-            w.pz = Z0 + soc_rand(&w.rng);
-            float phi       = SOC_TWOPI * soc_rand(&w.rng);
-            float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
-            float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
-            float sp, cp;
-            soc_sincosf(phi, &sp, &cp);
-            w.ux = sin_theta * cp;
-            w.uy = sin_theta * sp;
-            w.uz = cos_theta;
-            n_pkt++;
-            w.begin();
         }
-        if (w.ind >= 0) w.template step<true>(G, S, sCSC, sOFF);
+        if (soc_service_now(mode == SOC_M_SCATTER, nobody_steps)) {
+            if (mode == SOC_M_SCATTER) {
+                w.template scatter<true>(S, sCSC, sOFF);
+                mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+            }
+        }
+        if (__ballot(mode != SOC_M_DONE) == 0ull) break;
+        if (mode == SOC_M_STEP) {
+            if (w.template step<true>(G, S, sOFF)) mode = SOC_M_SCATTER;
+            else if (w.ind < 0) mode = SOC_M_CREATE;
+        }
     }
     soc_flush_stats(S, w.n_tally, n_pkt, w.n_scat);
 }
