@@ -198,6 +198,10 @@ def main():
     else:
         packets_total = packets_rank
 
+    passes = eng.last_passes()
+    kernel_name = ("soc_brick_step<scalar-opacity,TABS-only> x %d passes (+ soc_brick_scan, soc_brick_scatter): "
+                   "time is the HIP-event span of all kernels of one step" % passes) if passes else \
+        "soc_sim_pb_kernel<Cartesian,float,scalar-opacity,TABS-only>"
     if rank == 0:
         kavg_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
         alg_bytes = events_rank / max(args.steps, 1) * BYTES_PER_TALLY_EVENT
@@ -222,7 +226,7 @@ def main():
                            else "work-item ranges of one launch + 1 RCCL all-reduce of TABS per step")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "soc_sim_pb_kernel<Cartesian,float,scalar-opacity,TABS-only>",
+                         "kernel": kernel_name,
                          "kernel_ms": kavg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

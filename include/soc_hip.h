@@ -56,6 +56,13 @@ int soc_set_grid(soc_ctx *ctx, int NX, int NY, int NZ, int LEVELS, const int32_t
  *   use_emweight : USE_EMWEIGHT 0 or 1 (SimRAM_CL)                                         */
 int soc_set_features(soc_ctx *ctx, int with_int, int ps_method, int use_emweight);
 
+/* how launches are executed (no counterpart in the reference; results are the same packets):
+ *   mode 0  direct: one lane per work item, one global float atomic per tally event
+ *   mode 1  brick sweep: packets sorted by brick of 2^brick_log2 root cells per edge, tallies
+ *           accumulated in LDS and flushed per brick (Cartesian grids, SimRAM_PB)
+ *   mode -1 automatic (default): brick sweep where it applies, direct otherwise          */
+int soc_set_exec(soc_ctx *ctx, int mode, int brick_log2);
+
 /* replaces the per-frequency uploads of ABS, SCA (ASOC.py:1171-1175); ndust must be 1
  * (the host sums the species, ASOC.py:1166-1170) */
 int soc_set_optical(soc_ctx *ctx, const float *ABS, const float *SCA, int ndust);
@@ -109,6 +116,9 @@ int soc_read_par(soc_ctx *ctx, int32_t *out, int64_t n);
 /* counters accumulated by the kernels since the last reset:
  * out[0] tally events, out[1] packets created, out[2] scattering events */
 int soc_stats(soc_ctx *ctx, uint64_t out[3], int reset);
+
+/* number of brick-sweep passes of the last launch (0 if it ran in direct mode) */
+int soc_last_passes(soc_ctx *ctx);
 
 /* HIP-event timing on the handle's stream: bracket launches, then read elapsed ms */
 int soc_timer_start(soc_ctx *ctx);

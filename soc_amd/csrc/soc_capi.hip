@@ -44,6 +44,8 @@ struct soc_ctx {
     unsigned long long *dStats = nullptr;
     // features
     int with_int = 0, ps_method = 0, use_emweight = 0;
+    // execution
+    int exec_mode = -1, brick_log2 = 4, last_passes = 0;
 };
 
 static std::string g_create_err;
@@ -128,6 +130,7 @@ void soc_destroy(soc_ctx *c)
     if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    soc_brick_release(c->device);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -211,6 +214,18 @@ int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
     c->use_emweight = use_emweight;
     return SOC_OK;
 }
+
+int soc_set_exec(soc_ctx *c, int mode, int brick_log2)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (mode < -1 || mode > 1 || brick_log2 < 2 || brick_log2 > 4)
+        return fail(c, SOC_ERR_ARG, "soc_set_exec: mode %d (-1,0,1), brick_log2 %d (2..4)", mode, brick_log2);
+    c->exec_mode = mode;
+    c->brick_log2 = brick_log2;
+    return SOC_OK;
+}
+
+int soc_last_passes(soc_ctx *c) { return c ? c->last_passes : 0; }
 
 int soc_set_optical(soc_ctx *c, const float *ABS, const float *SCA, int ndust)
 {
@@ -370,6 +385,19 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         S.XPS_NSIDE = c->dXPS_NSIDE; S.XPS_SIDE = c->dXPS_SIDE; S.XPS_AREA = c->dXPS_AREA;
     } else {
         S.NO_PS = 1;
+    }
+    c->last_passes = 0;
+    // brick sweep: Cartesian grids with enough work items to fill the chip
+    const int B = 1 << c->brick_log2;
+    const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
+    bool bricks = (c->exec_mode != 0) && !V.octree && nb <= 8192 && c->device < 16;
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8;
+    if (c->exec_mode == 1 && !bricks)
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (octree or > 8192 bricks)");
+    if (bricks) {
+        hipError_t e = soc_brick_run_pb(c->device, c->G, S, V, c->brick_log2, c->stream, &c->last_passes);
+        if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
+        return SOC_OK;
     }
     HIPCHK(c, soc_launch_sim_pb(c->G, S, V, c->stream));
     return SOC_OK;

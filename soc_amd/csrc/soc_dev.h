@@ -53,4 +53,10 @@ hipError_t soc_launch_trace(const SocGrid &G, const SocVariant &V, const float *
                             int maxsteps, int *levels, int *inds, float *dss, float *endpos, int *nsteps,
                             hipStream_t st);
 
+
+// brick-sweep execution (soc_brick.hip): LDS-resident tallies, packets sorted by brick
+hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &S, const SocVariant &V, int LB,
+                            hipStream_t st, int *passes_out);
+void soc_brick_release(int device);
+
 #endif

@@ -27,6 +27,8 @@ API = {
     "soc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "soc_set_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _I, _F]),
     "soc_set_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "soc_set_exec": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "soc_last_passes": (C.c_int, [C.c_void_p]),
     "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
     "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
     "soc_set_scatter_table": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
@@ -134,6 +136,13 @@ class Engine:
 
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self._chk(self.lib.soc_set_features(self.h, int(with_int), int(ps_method), int(use_emweight)))
+
+    def set_exec(self, mode=-1, brick_log2=4):
+        """0 direct kernel, 1 brick sweep (LDS tallies), -1 automatic."""
+        self._chk(self.lib.soc_set_exec(self.h, int(mode), int(brick_log2)))
+
+    def last_passes(self):
+        return int(self.lib.soc_last_passes(self.h))
 
     def set_optical(self, ABS, SCA):
         a = np.asarray([ABS], np.float32).ravel()

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True):
+def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mode=0, brick_log2=4):
     """Execute ``job`` (oracle.pyoracle.Job) through the C ABI.  Returns (TABS, INT, stats)."""
     cl = job.cloud
     eng.set_cloud(cl)
@@ -10,6 +10,7 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True):
     eng.set_scatter_table(job.DSC, job.CSC)
     eng.set_optical(job.ABS, job.SCA)
     eng.set_opt(job.OPT)
+    eng.set_exec(exec_mode, brick_log2)
     if zero:
         eng.zero(0)
         eng.zero(1)
