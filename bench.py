@@ -51,15 +51,28 @@ def c2_workload():
                 cloud=cloud, DSC=dsc, CSC=csc, ABS=C2_ABS, SCA=C2_SCA, launch=L, SEED=0.7853981634)
 
 
+def host_cores():
+    """CPU threads this process may really use: scheduler affinity capped by the cgroup quota
+    (the GPU box exposes 256 hardware threads but grants a 16-CPU share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(work, budget_s=15.0):
     """Time the reference's own kernel (x86 build of kernel_ASOC.c, oracle/_ref) -- or, where
     that build is absent, the C restatement -- on an evenly strided sample of the work items
     of the same launch, on all host cores available to this process."""
     from oracle.pyoracle import Job, Oracle, Ref
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
+    ncores = host_cores()
     L = work["launch"]
     job = Job(work["cloud"], work["CSC"], ABS=work["ABS"], SCA=work["SCA"], SOURCE=1, BATCH=L["BATCH"],
               SEED=launch.launch_seed(work["SEED"], 0), BG=1.0, TW=1.0, GLOBAL=L["GLOBAL"], DSC=work["DSC"])

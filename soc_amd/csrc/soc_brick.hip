@@ -33,7 +33,7 @@
 #define SOC_BRICK_T 256          // threads per workgroup (scatter kernel; step kernel uses A.T)
 #define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk
 
-enum { SOC_BM_STEP = 0, SOC_BM_CREATE = 1, SOC_BM_SCATTER = 2, SOC_BM_FETCH = 3, SOC_BM_IDLE = 4 };
+enum { SOC_BM_STEP = 0, SOC_BM_CREATE = 1, SOC_BM_SCATTER = 2, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
 
 struct __align__(16) SocPacket {
     float px, py, pz, ux;
@@ -122,27 +122,28 @@ __global__ void soc_brick_init(const SocGrid G, const SocSim S, SocBrickArgs A, 
     if (t <= (uint32_t)A.NB) hist[t] = 0;
 }
 
-template <bool ABU, bool WINT>
+template <bool ABU, bool WINT, bool SD>
 __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const SocSim S, const SocBrickArgs A)
 {
     if ((int)blockIdx.x >= *A.ndesc) return;
     const SocDesc D = A.desc[blockIdx.x];
     const int BV = 1 << (3 * A.LB);
+    const int nthr = (int)blockDim.x;
     long long t0 = 0, t1 = 0, t2 = 0;
     if (A.dbg) t0 = wall_clock64();
 
     extern __shared__ float lds[];
     float *sT   = lds;                                   // [BV] TABS of this brick
-    float *sD   = sT + BV;                               // [BV] densities of this brick
-    float *sI   = sD + BV;                               // [BV] INT (only with WINT)
-    int   *sH   = (int *)(sI + (WINT ? BV : 0));         // [NB+1]
+    float *sD   = sT + BV;                               // [BV] densities of this brick (SD)
+    float *sI   = sD + (SD ? BV : 0);                    // [BV] INT (WINT)
+    int   *sH   = (int *)(sI + (WINT ? BV : 0));         // [NB+1] arrivals per brick, next pass
     int   *sCtl = sH + A.NB + 1;                         // [0] next packet, [1..3] stats, [4] = 0 (OFF[0])
-    for (int i = threadIdx.x; i < BV; i += (int)blockDim.x) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
-    {
+    for (int i = threadIdx.x; i < BV; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
+    if (SD) {
         // stage the brick's densities: no global access is left inside the step loop
         const int Bq = 1 << A.LB, Mq = Bq - 1;
         const int bx = D.brick % A.NBX, by = (D.brick / A.NBX) % A.NBY, bz = D.brick / (A.NBX * A.NBY);
-        for (int i = threadIdx.x; i < BV; i += (int)blockDim.x) {
+        for (int i = threadIdx.x; i < BV; i += nthr) {
             float d = 0.0f;
             if (D.brick >= 0) {
                 const int ix = bx * Bq + (i & Mq), iy = by * Bq + ((i >> A.LB) & Mq), iz = bz * Bq + (i >> (2 * A.LB));
@@ -151,29 +152,46 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
             sD[i] = d;
         }
     }
-    for (int i = threadIdx.x; i <= A.NB; i += (int)blockDim.x) sH[i] = 0;
+    for (int i = threadIdx.x; i <= A.NB; i += nthr) sH[i] = 0;
     if (threadIdx.x < 5) sCtl[threadIdx.x] = 0;
     __syncthreads();
-
     if (A.dbg) t1 = wall_clock64();
-    const int NX = G.NX, NY = G.NY, NZ = G.NZ;
-    const int mybrick = D.brick;
+
+    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
+    const float fNX = (float)NX, fNY = (float)NY, fNZ = (float)NZ;
+    const int   mybrick = D.brick, LB = A.LB, M = (1 << A.LB) - 1;
     SocBrickLane w;
-    w.level = 0;
-    int   mode = SOC_BM_FETCH, slot = 0, III = 0, lid = 0, nvisit = 0;
+    w.level = 0;  w.ind = -1;  w.scat = 0;
+    w.px = w.py = w.pz = w.ux = w.uy = w.uz = 0.0f;
+    w.photons = w.free_path = w.tau = w.dens = 0.0f;
+    w.rng.x = w.rng.c = 0u;
+    int   mode = SOC_BM_SWAP, next_mode = 0, slot = 0, III = 0, lid = 0, nvisit = 0, key = 0;
+    bool  have = false;
     uint32_t wid = 0;
     unsigned int n_tally = 0, n_scat = 0, n_pkt = 0;
     const int *sOFF0 = sCtl + 4;                          // OFF[0] == 0: Cartesian grids only
 
     while (true) {
-        // ---- fetch: lanes without a packet take the next one of the chunk ----
+        bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
+        // ---- swap: write back packets that are through with this brick, take the next ones ----
         {
-            unsigned long long m = __ballot(mode == SOC_BM_FETCH);
-            const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
+            const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
             if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
-                if (mode == SOC_BM_FETCH) {
+                if (mode == SOC_BM_SWAP) {
+                    if (have) {
+                        SocPacket p;
+                        p.px = w.px;  p.py = w.py;  p.pz = w.pz;  p.ux = w.ux;  p.uy = w.uy;  p.uz = w.uz;
+                        p.photons = w.photons;  p.free_path = w.free_path;  p.tau = w.tau;  p.dens = w.dens;
+                        p.rx = w.rng.x;  p.rc = w.rng.c;
+                        p.ind = w.ind;  p.III = III;  p.lid = lid;
+                        p.misc = (uint32_t)(w.scat & 0xff) | ((uint32_t)next_mode << 8);
+                        A.pk[wid] = p;
+                        A.keyq[D.start + slot] = (uint32_t)key;
+                        atomicAdd(&sH[key], 1);
+                    }
                     slot = atomicAdd(&sCtl[0], 1);
-                    if (slot >= D.count) {
+                    have = slot < D.count;
+                    if (!have) {
                         mode = SOC_BM_IDLE;
                     } else {
                         wid = A.idq[D.start + slot];
@@ -184,20 +202,18 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
                         w.ind = p.ind;  III = p.III;  lid = p.lid;
                         w.scat = (int)(p.misc & 0xffu);
                         mode = (int)((p.misc >> 8) & 0xffu);
-                        w.dens = (mybrick >= 0) ? sD[lid] : 0.0f;
+                        w.dens = SD ? ((mybrick >= 0) ? sD[lid] : 0.0f) : p.dens;
                         nvisit = 0;
                     }
                 }
+                nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
             }
         }
-        const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
-        bool leave = false;
-        int  key = 0;
         // ---- create the work item's next packet ----
         if (soc_service_now(mode == SOC_BM_CREATE, nobody_steps)) {
             if (mode == SOC_BM_CREATE) {
                 if (III >= S.BATCH) {
-                    leave = true;  key = A.NB;                               // work item finished
+                    mode = SOC_BM_SWAP;  key = A.NB;  next_mode = SOC_BM_CREATE;     // work item finished
                 } else {
                     const int id = (int)(S.gid0 + wid);
                     const SocSurfElem E = soc_surface_element(G, S, id);
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
                         int b;
                         soc_cell_brick(A, w.px, w.py, w.pz, b, lid);
                         mode = SOC_BM_STEP;
-                        if (b != mybrick) { leave = true;  key = b; }
+                        if (b != mybrick) { mode = SOC_BM_SWAP;  key = b;  next_mode = SOC_BM_STEP; }
                     }                                                        // else: missed the cloud, create again
                 }
             }
@@ -244,19 +260,6 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
                 if (w.scat > 20) w.ind = -1;
             }
         }
-        // ---- packets that left the brick (or finished) go back to memory ----
-        if (leave) {
-            SocPacket p;
-            p.px = w.px;  p.py = w.py;  p.pz = w.pz;  p.ux = w.ux;  p.uy = w.uy;  p.uz = w.uz;
-            p.photons = w.photons;  p.free_path = w.free_path;  p.tau = w.tau;  p.dens = w.dens;
-            p.rx = w.rng.x;  p.rc = w.rng.c;
-            p.ind = w.ind;  p.III = III;  p.lid = lid;
-            p.misc = (uint32_t)(w.scat & 0xff) | ((uint32_t)mode << 8);
-            A.pk[wid] = p;
-            A.keyq[D.start + slot] = (uint32_t)key;
-            atomicAdd(&sH[key], 1);
-            mode = SOC_BM_FETCH;
-        }
         if (__ballot(mode != SOC_BM_IDLE) == 0ull) break;
         // ---- one cell step (kernel_ASOC.c:565-683, LEVELS == 1) ----
         if (mode == SOC_BM_STEP) {
@@ -273,55 +276,44 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
             w.py += ds * w.uy;
             w.pz += ds * w.uz;
             ds = soc_scale_down(ds, 0);
-            int nb = mybrick, nlid = lid;
-            if ((w.px <= 0.0f) || (w.px >= NX) || (w.py <= 0.0f) || (w.py >= NY) || (w.pz <= 0.0f) || (w.pz >= NZ)) {
-                w.ind = -1;
-            } else {
-                const int ix = (int)soc_floorf(w.px), iy = (int)soc_floorf(w.py), iz = (int)soc_floorf(w.pz);
-                w.ind  = iz * NX * NY + iy * NX + ix;
-                const int M = (1 << A.LB) - 1;
-                nb   = ((iz >> A.LB) * A.NBY + (iy >> A.LB)) * A.NBX + (ix >> A.LB);
-                nlid = ((iz & M) << (2 * A.LB)) | ((iy & M) << A.LB) | (ix & M);
-                w.dens = (nb == mybrick) ? sD[nlid] : 0.0f;      // outside the brick: the next owner reloads it
-            }
-            float tauA = ds * d0 * kabs;
-            float dtau = ds * d0 * ksca;
+            // new cell, without branches: inside <=> 0 < p < N on every axis (same outcome as the
+            // reference's "<= 0 || >= N" exit test for every finite position)
+            const bool inside = (w.px > 0.0f) & (w.px < fNX) & (w.py > 0.0f) & (w.py < fNY) & (w.pz > 0.0f) & (w.pz < fNZ);
+            const int ix = inside ? (int)soc_floorf(w.px) : 0;
+            const int iy = inside ? (int)soc_floorf(w.py) : 0;
+            const int iz = inside ? (int)soc_floorf(w.pz) : 0;
+            const int nind = iz * NX * NY + iy * NX + ix;
+            const int nb   = ((iz >> LB) * A.NBY + (iy >> LB)) * A.NBX + (ix >> LB);
+            const int nlid = ((iz & M) << (2 * LB)) | ((iy & M) << LB) | (ix & M);
+            const bool stay = inside & (nb == mybrick);
+            float ndens;
+            if (SD) ndens = sD[stay ? nlid : 0];
+            else    ndens = G.DENS[nind];
+            const float tauA = ds * d0 * kabs;
+            const float dtau = ds * d0 * ksca;
             if (w.free_path < (w.tau + dtau)) {
-                w.px = p0x;  w.py = p0y;  w.pz = p0z;
-                w.ind = oind;  w.dens = d0;
+                w.px = p0x;  w.py = p0y;  w.pz = p0z;                        // back to the start of the step
                 mode = SOC_BM_SCATTER;
             } else {
-                float e = soc_expf(-tauA);
-                float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
+                const float e = soc_expf(-tauA);
+                const float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
                 atomicAdd(&sT[lid0], delta * S.TW);
                 if (WINT) atomicAdd(&sI[lid0], delta);
                 n_tally++;
                 w.photons *= e;
                 w.tau += dtau;
-                if (w.ind == oind) {                                         // failed step: nudge
-                    w.px += SOC_PEPS * w.ux;
-                    w.py += SOC_PEPS * w.uy;
-                    w.pz += SOC_PEPS * w.uz;
-                }
+                w.ind = inside ? nind : -1;
+                w.dens = ndens;
                 lid = nlid;
+                const bool failed = (w.ind == oind);                         // failed step: nudge
+                w.px += failed ? (SOC_PEPS * w.ux) : 0.0f;
+                w.py += failed ? (SOC_PEPS * w.uy) : 0.0f;
+                w.pz += failed ? (SOC_PEPS * w.uz) : 0.0f;
                 nvisit++;
-                if (w.ind < 0) {
-                    mode = SOC_BM_CREATE;
-                } else if (nb != mybrick || nvisit >= A.KCAP) {
-                    // left the brick -- or used up this pass's step budget: the packet goes back to the
-                    // queue of the brick it is in, so the pass length is bounded by KCAP steps per lane
-                    // store right away (cheap, no wait): handled at the top of the next iteration
-                    SocPacket p;
-                    p.px = w.px;  p.py = w.py;  p.pz = w.pz;  p.ux = w.ux;  p.uy = w.uy;  p.uz = w.uz;
-                    p.photons = w.photons;  p.free_path = w.free_path;  p.tau = w.tau;  p.dens = w.dens;
-                    p.rx = w.rng.x;  p.rc = w.rng.c;
-                    p.ind = w.ind;  p.III = III;  p.lid = lid;
-                    p.misc = (uint32_t)(w.scat & 0xff) | ((uint32_t)SOC_BM_STEP << 8);
-                    A.pk[wid] = p;
-                    A.keyq[D.start + slot] = (uint32_t)nb;
-                    atomicAdd(&sH[nb], 1);
-                    mode = SOC_BM_FETCH;
-                }
+                // out of the cloud -> next packet; out of the brick, or this pass's step budget used
+                // up -> back to the queue of the brick it is in (bounds the pass length)
+                if (!inside)                              mode = SOC_BM_CREATE;
+                else if (!stay || nvisit >= A.KCAP)     { mode = SOC_BM_SWAP;  key = nb;  next_mode = SOC_BM_STEP; }
             }
         }
     }
@@ -333,9 +325,9 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
     atomicAdd(&sCtl[3], (int)n_scat);
     __syncthreads();
     if (mybrick >= 0) {
-        const int B = 1 << A.LB, M = B - 1;
+        const int B = 1 << A.LB;
         const int bx = mybrick % A.NBX, by = (mybrick / A.NBX) % A.NBY, bz = mybrick / (A.NBX * A.NBY);
-        for (int i = threadIdx.x; i < BV; i += (int)blockDim.x) {
+        for (int i = threadIdx.x; i < BV; i += nthr) {
             const float v = sT[i];
             const float vi = WINT ? sI[i] : 0.0f;
             if (v != 0.0f || vi != 0.0f) {
@@ -346,7 +338,7 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
             }
         }
     }
-    for (int i = threadIdx.x; i <= A.NB; i += (int)blockDim.x) {
+    for (int i = threadIdx.x; i <= A.NB; i += nthr) {
         const int c = sH[i];
         if (c) atomicAdd(&A.hist[i], c);
     }
@@ -541,7 +533,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &Sin, con
 
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
     const int BV = 1 << (3 * LB);
-    const size_t lds_step = (size_t)(BV * (V.wint ? 3 : 2) + A.NB + 1 + 8) * 4;
+    bool use_sd = false;      // LDS copy of the brick densities: measured no gain (268 vs 274 ms at C2), costs LDS
+    if (const char *e = getenv("SOC_BRICK_SD")) use_sd = atoi(e) != 0;
+    const size_t lds_step = (size_t)(BV * (1 + (use_sd ? 1 : 0) + (V.wint ? 1 : 0)) + A.NB + 1 + 8) * 4;
     const size_t lds_scat = (size_t)A.NB * 4;
 
     soc_brick_init<<<(max(count, (uint32_t)A.NB + 1) + 255) / 256, 256, 0, st>>>(G, S, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
@@ -560,12 +554,16 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &Sin, con
             A.idq = bb.idq[cur];  A.idq_next = bb.idq[1 - cur];
             A.desc = bb.desc[cur];  A.ndesc = bb.ndesc + cur;
             A.desc_next = bb.desc[1 - cur];  A.ndesc_next = bb.ndesc + (1 - cur);
-            const int key = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
+            const int key = (V.abu ? 4 : 0) | (V.wint ? 2 : 0) | (use_sd ? 1 : 0);
             switch (key) {
-            case 0: soc_brick_step<false, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 1: soc_brick_step<false, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 2: soc_brick_step<true, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            default: soc_brick_step<true, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 0: soc_brick_step<false, false, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 1: soc_brick_step<false, false, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 2: soc_brick_step<false, true, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 3: soc_brick_step<false, true, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 4: soc_brick_step<true, false, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 5: soc_brick_step<true, false, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            case 6: soc_brick_step<true, true, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
+            default: soc_brick_step<true, true, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
             }
             soc_brick_scan<<<1, 1024, 0, st>>>(A);
             soc_brick_scatter<<<maxdesc, SOC_BRICK_T, lds_scat, st>>>(A);
