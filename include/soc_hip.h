@@ -124,6 +124,29 @@ int soc_last_passes(soc_ctx *ctx);
 int soc_timer_start(soc_ctx *ctx);
 int soc_timer_stop(soc_ctx *ctx, float *elapsed_ms);
 
+/* ---- stochastically heated grains: A2E.py / kernel_A2E.c ---- */
+
+/* replaces the per-size uploads of A2E.py:338-371 (AF, Iw, L1, L2, Tdown, EA, Ibeg) and the
+ * -D NE -D NFREQ build of A2E.py:283-304.  L1/L2 are [NE*NE] indexed l*NE+u, Iw holds noIw
+ * weights in (l, u, i) loop order, EA is [NFREQ*NE]. */
+int soc_a2e_set_size(soc_ctx *ctx, int NE, int NFREQ, int noIw, const float *Iw, const int32_t *L1,
+                     const int32_t *L2, const float *Tdown, const float *EA, const int32_t *Ibeg, const float *AF);
+
+/* replaces enqueue_copy(ABS_buf) + DoSolve(...) + enqueue_copy(emit, EMIT_buf) for one batch of
+ * cells (A2E.py:387-412 -> kernel_A2E.c:2-104): AABS, AEMIT are [batch*NFREQ] host arrays */
+int soc_a2e_solve(soc_ctx *ctx, int batch, const float *AABS, float *AEMIT);
+/* the same in three steps with the batch resident on the device (timing the kernel alone) */
+int soc_a2e_upload(soc_ctx *ctx, int batch, const float *AABS);
+int soc_a2e_run(soc_ctx *ctx, int batch);
+int soc_a2e_download(soc_ctx *ctx, int batch, float *AEMIT);
+
+/* replaces kernel_T(...) = EqTemperature for one batch (A2E.py:511-530 -> kernel_A2E.c:110-154);
+ * TTT holds NIP temperatures, ABS is [batch*NFREQ] (already multiplied by AF on the host),
+ * outputs T[batch] and EMIT[batch*NFREQ] */
+int soc_a2e_eqtemp(soc_ctx *ctx, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
+                   float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
+                   const float *ABS, float *T, float *EMIT);
+
 /* ---- verification probes (used by the parity tests only) ---- */
 /* RNG stream states and first draws of logical work items [gid_first, gid_first+n)
  * (MWC64X_SeedStreams + MWC64X_NextUint, mwc64x_rng.cl:35-48) */

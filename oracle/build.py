@@ -31,8 +31,8 @@ def _newer(target, sources):
 def build_oracle(force=False):
     """Compile both math modes of the CPU restatement.  Returns {mode: path}."""
     os.makedirs(BUILD_DIR, exist_ok=True)
-    srcs = [os.path.join(HERE, "soc_oracle.c"), os.path.join(HERE, "soc_oracle_index.inc"),
-            os.path.join(REPO, "soc_amd", "csrc", "soc_math.h")]
+    srcs = [os.path.join(HERE, "soc_oracle.c"), os.path.join(HERE, "a2e_oracle.c"),
+            os.path.join(HERE, "soc_oracle_index.inc"), os.path.join(REPO, "soc_amd", "csrc", "soc_math.h")]
     out = {}
     for mode, flag in (("soc", []), ("libm", ["-DSOC_ORACLE_LIBM"])):
         so = os.path.join(BUILD_DIR, "liborc_%s.so" % mode)
@@ -41,7 +41,7 @@ def build_oracle(force=False):
             continue
         cmd = ["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                "-fno-fast-math", "-mfma", "-msse4.1", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] \
-            + flag + ["-o", so, srcs[0], "-lm"]
+            + flag + ["-o", so, srcs[0], srcs[1], "-lm"]
         subprocess.check_call(cmd)
     return out
 
@@ -80,7 +80,8 @@ def build_ref(tag, force=False, **model):
     shim = os.path.join(HERE, "ref_shim.cpp")
     stamp = so + ".defs"
     defs = ref_defs(**model)
-    if (not force and _newer(so, [shim, os.path.abspath(__file__), ksrc]) and os.path.exists(stamp)
+    if (not force and _newer(so, [shim, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
+            and os.path.exists(stamp)
             and open(stamp).read() == " ".join(defs)):
         return so
     kobj = os.path.join(REF_DIR, "k_%s.o" % tag)
@@ -95,6 +96,43 @@ def build_ref(tag, force=False, **model):
     with open(stamp, "w") as fp:
         fp.write(" ".join(defs))
     return so
+
+
+def build_ref_a2e(tag, NE, NFREQ, LOCAL, CELLS, NIP=5000, force=False):
+    """kernel_A2E.c (DoSolve, EqTemperature) for one (NE, NFREQ, LOCAL, CELLS) -> oracle/_ref/refa2e_<tag>.so.
+    -D list: A2E.py:283-286."""
+    so = os.path.join(REF_DIR, "refa2e_%s.so" % tag)
+    ksrc = os.path.join(REFERENCE, "kernel_A2E.c")
+    if not os.path.exists(ksrc):
+        return so if os.path.exists(so) else None
+    os.makedirs(REF_DIR, exist_ok=True)
+    drv = os.path.join(HERE, "ref_a2e.cpp")
+    defs = ["-DNE=%d" % NE, "-DLOCAL=%d" % LOCAL, "-DNFREQ=%d" % NFREQ, "-DCELLS=%d" % CELLS, "-DNIP=%d" % NIP,
+            "-DFACTOR=1.0000e+20f", "-DDUMP_TDUST=0"]
+    stamp = so + ".defs"
+    if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
+            and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
+        return so
+    kobj = os.path.join(REF_DIR, "ka2e_%s.o" % tag)
+    sobj = os.path.join(REF_DIR, "da2e_%s.o" % tag)
+    common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
+    subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
+                           "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
+    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    os.remove(kobj)
+    os.remove(sobj)
+    with open(stamp, "w") as fp:
+        fp.write(" ".join(defs))
+    return so
+
+
+def a2e_ref_models():
+    return {
+        "ne16": dict(NE=16, NFREQ=12, LOCAL=8, CELLS=40, NIP=500),
+        "ne64": dict(NE=64, NFREQ=40, LOCAL=8, CELLS=64, NIP=5000),
+        "ne128": dict(NE=128, NFREQ=50, LOCAL=8, CELLS=8192, NIP=5000),
+    }
 
 
 def ref_models():
@@ -126,6 +164,8 @@ def build_all_refs(force=False):
     out = {}
     for tag, model in ref_models().items():
         out[tag] = build_ref(tag, force=force, **model)
+    for tag, model in a2e_ref_models().items():
+        out["a2e_" + tag] = build_ref_a2e(tag, force=force, **model)
     return out
 
 

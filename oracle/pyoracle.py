@@ -327,3 +327,89 @@ class Ref:
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sim(C.byref(a), kind, gid0, gid1, stride, nthreads)
         return TABS, INT
+
+
+# ---------------------------------------------------------------------------------------
+# A2E (stochastic heating): oracle restatement and x86 builds of kernel_A2E.c
+# ---------------------------------------------------------------------------------------
+
+def a2e_oracle_dosolve(orc, NE, NFREQ, size, AF, AABS):
+    """size: dict with Iw, L1, L2, Tdown, EA, Ibeg (one grain size of a solver file)."""
+    L = orc.lib
+    L.orc_a2e_dosolve.restype = C.c_int
+    L.orc_a2e_dosolve.argtypes = [C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F, _F, _F]
+    AABS = np.ascontiguousarray(AABS, np.float32)
+    batch = AABS.shape[0]
+    out = np.zeros((batch, NFREQ), np.float32)
+    arrs = [np.ascontiguousarray(size[k], t) for k, t in (("Iw", np.float32), ("L1", np.int32), ("L2", np.int32),
+                                                           ("Tdown", np.float32), ("EA", np.float32), ("Ibeg", np.int32))]
+    AF = np.ascontiguousarray(AF, np.float32)
+    rc = L.orc_a2e_dosolve(batch, NE, NFREQ, _fp(arrs[0]), _ip(arrs[1]), _ip(arrs[2]), _fp(arrs[3]), _fp(arrs[4]),
+                           _ip(arrs[5]), _fp(AF), _fp(AABS), _fp(out))
+    assert rc == 0
+    return out
+
+
+def a2e_oracle_eqtemp(orc, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+    L = orc.lib
+    L.orc_a2e_eqtemp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, _F, _F, _F, _F, _F, _F]
+    ABS = np.ascontiguousarray(ABS, np.float32)
+    batch, NFREQ = ABS.shape
+    T = np.zeros(batch, np.float32)
+    E = np.zeros((batch, NFREQ), np.float32)
+    FREQ, KABS, TTT = (np.ascontiguousarray(a, np.float32) for a in (FREQ, KABS, TTT))
+    L.orc_a2e_eqtemp(batch, icell, CELLS, NFREQ, NIP, np.float32(FACTOR), np.float32(kE), np.float32(oplgkE),
+                     np.float32(Emin), _fp(FREQ), _fp(KABS), _fp(TTT), _fp(ABS), _fp(T), _fp(E))
+    return T, E
+
+
+class RefA2E:
+    """x86 build of kernel_A2E.c for one (NE, NFREQ, LOCAL, CELLS, NIP): oracle/_ref/refa2e_<tag>.so"""
+
+    def __init__(self, tag):
+        self.model = _build.a2e_ref_models()[tag]
+        path = _build.build_ref_a2e(tag, **self.model)
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("reference build a2e %s not available" % tag)
+        self.lib = C.CDLL(path)
+        self.lib.ref_dosolve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F, _F, _F, _F]
+        self.lib.ref_eqtemp.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F]
+
+    @staticmethod
+    def available(tag):
+        try:
+            RefA2E(tag)
+            return True
+        except (FileNotFoundError, OSError, KeyError):
+            return False
+
+    def dosolve(self, size, AF, AABS, GLOBAL=None):
+        m = self.model
+        NE, NFREQ, LOCAL = m["NE"], m["NFREQ"], m["LOCAL"]
+        AABS = np.ascontiguousarray(AABS, np.float32)
+        batch = AABS.shape[0]
+        GLOBAL = GLOBAL or ((batch + LOCAL - 1) // LOCAL) * LOCAL
+        assert AABS.shape[1] == NFREQ and GLOBAL % LOCAL == 0
+        absb = np.zeros((GLOBAL, NFREQ), np.float32)
+        absb[:batch] = AABS
+        out = np.zeros((GLOBAL, NFREQ), np.float32)
+        LL = np.zeros(GLOBAL * ((NE * NE - NE) // 2), np.float32)
+        arrs = [np.ascontiguousarray(size[k], t) for k, t in (("Iw", np.float32), ("L1", np.int32), ("L2", np.int32),
+                                                               ("Tdown", np.float32), ("EA", np.float32), ("Ibeg", np.int32))]
+        AF = np.ascontiguousarray(AF, np.float32)
+        self.lib.ref_dosolve(GLOBAL, LOCAL, batch, 0, _fp(arrs[0]), _ip(arrs[1]), _ip(arrs[2]), _fp(arrs[3]),
+                             _fp(arrs[4]), _ip(arrs[5]), _fp(AF), _fp(absb), _fp(out), _fp(LL))
+        return out[:batch]
+
+    def eqtemp(self, icell, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+        m = self.model
+        ABS = np.ascontiguousarray(ABS, np.float32)
+        batch, NFREQ = ABS.shape
+        assert NFREQ == m["NFREQ"] and len(TTT) == m["NIP"]
+        T = np.zeros(batch, np.float32)
+        E = np.zeros((batch, NFREQ), np.float32)
+        FREQ, KABS, TTT = (np.ascontiguousarray(a, np.float32) for a in (FREQ, KABS, TTT))
+        self.lib.ref_eqtemp(batch, icell, np.float32(kE), np.float32(oplgkE), np.float32(Emin), _fp(FREQ), _fp(KABS),
+                            _fp(TTT), _fp(ABS), _fp(T), _fp(E))
+        return T, E

@@ -14,93 +14,7 @@
 // tests/test_oracle_vs_ref.py demand bit-identical results.
 //
 // Must be compiled with the same clang that compiles the kernels (ext_vector_type ABI).
-#include <cmath>
-#include <cstddef>
-#include <cstdint>
-#include <cstring>
-#include <thread>
-#include <vector>
-
-typedef float float3 __attribute__((ext_vector_type(3)));
-typedef unsigned int uint;
-
-static thread_local size_t g_gid = 0, g_gsize = 1;
-
-// ---- 1. OpenCL built-ins ---------------------------------------------------------------
-#define CLNAME(n) asm(n)
-size_t cl_get_global_id(uint) CLNAME("_Z13get_global_idj");
-size_t cl_get_global_id(uint) { return g_gid; }
-size_t cl_get_global_size(uint) CLNAME("_Z15get_global_sizej");
-size_t cl_get_global_size(uint) { return g_gsize; }
-size_t cl_get_local_id(uint) CLNAME("_Z12get_local_idj");
-size_t cl_get_local_id(uint) { return 0; }
-size_t cl_get_group_id(uint) CLNAME("_Z12get_group_idj");
-size_t cl_get_group_id(uint) { return g_gid; }
-
-uint cl_atomic_cmpxchg(volatile uint *p, uint cmp, uint val) CLNAME("_Z14atomic_cmpxchgPU8CLglobalVjjj");
-uint cl_atomic_cmpxchg(volatile uint *p, uint cmp, uint val)
-{
-    uint expected = cmp;
-    __atomic_compare_exchange_n(p, &expected, val, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
-    return expected;
-}
-
-float cl_cos(float x) CLNAME("_Z3cosf");
-float cl_cos(float x) { return cosf(x); }
-float cl_sin(float x) CLNAME("_Z3sinf");
-float cl_sin(float x) { return sinf(x); }
-float cl_exp(float x) CLNAME("_Z3expf");
-float cl_exp(float x) { return expf(x); }
-float cl_log(float x) CLNAME("_Z3logf");
-float cl_log(float x) { return logf(x); }
-float cl_log10(float x) CLNAME("_Z5log10f");
-float cl_log10(float x) { return log10f(x); }
-float cl_acos(float x) CLNAME("_Z4acosf");
-float cl_acos(float x) { return acosf(x); }
-float cl_fabs(float x) CLNAME("_Z4fabsf");
-float cl_fabs(float x) { return fabsf(x); }
-float cl_sqrt(float x) CLNAME("_Z4sqrtf");
-float cl_sqrt(float x) { return sqrtf(x); }
-float cl_floor(float x) CLNAME("_Z5floorf");
-float cl_floor(float x) { return floorf(x); }
-float cl_fmod(float x, float y) CLNAME("_Z4fmodff");
-float cl_fmod(float x, float y) { return fmodf(x, y); }
-float cl_max(float a, float b) CLNAME("_Z3maxff");
-float cl_max(float a, float b) { return fmaxf(a, b); }
-float cl_min(float a, float b) CLNAME("_Z3minff");
-float cl_min(float a, float b) { return fminf(a, b); }
-float cl_pown(float x, int n) CLNAME("_Z4pownfi");
-float cl_pown(float x, int n) { return powf(x, (float)n); }
-float cl_ldexp(float x, int n) CLNAME("_Z5ldexpfi");
-float cl_ldexp(float x, int n) { return ldexpf(x, n); }
-float cl_clampf(float x, float lo, float hi) CLNAME("_Z5clampfff");
-float cl_clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-int cl_clampi(int x, int lo, int hi) CLNAME("_Z5clampiii");
-int cl_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
-uint cl_mad_hi(uint a, uint b, uint c) CLNAME("_Z6mad_hijjj");
-uint cl_mad_hi(uint a, uint b, uint c) { return (uint)(((uint64_t)a * b) >> 32) + c; }
-float cl_sincos(float x, float *c) CLNAME("_Z6sincosfPU9CLprivatef");
-float cl_sincos(float x, float *c) { *c = cosf(x); return sinf(x); }
-float3 cl_normalize(float3 v) CLNAME("_Z9normalizeDv3_f");
-float3 cl_normalize(float3 v)
-{
-    float s = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    float3 r;
-    r.x = v.x * s;  r.y = v.y * s;  r.z = v.z * s;
-    return r;
-}
-float cl_distance(float3 a, float3 b) CLNAME("_Z8distanceDv3_fS_");
-float cl_distance(float3 a, float3 b)
-{
-    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return sqrtf(dx * dx + dy * dy + dz * dz);
-}
-double cl_floord(double x) CLNAME("_Z5floord");
-double cl_floord(double x) { return floor(x); }
-double cl_fmodd(double x, double y) CLNAME("_Z4fmoddd");
-double cl_fmodd(double x, double y) { return fmod(x, y); }
-float cl_atan2(float y, float x) CLNAME("_Z5atan2ff");
-float cl_atan2(float y, float x) { return atan2f(y, x); }
+#include "ref_builtins.inc"
 
 // ---- 2. reference symbols (kernel_ASOC.c, kernel_ASOC_aux.c, mwc64x_rng.cl) --------------
 struct mwc_state { uint x, c; };

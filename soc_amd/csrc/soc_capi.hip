@@ -46,6 +46,10 @@ struct soc_ctx {
     int with_int = 0, ps_method = 0, use_emweight = 0;
     // execution
     int exec_mode = -1, brick_log2 = 4, last_passes = 0;
+    // A2E
+    int a2e_NE = 0, a2e_NFREQ = 0, a2e_npair = 0, a2e_cap = 0, a2e_noIw = 0;
+    float *aIw = nullptr, *aTdown = nullptr, *aEA = nullptr, *aAF = nullptr, *aABS = nullptr, *aEMIT = nullptr;
+    int   *aFirst = nullptr, *aLast = nullptr, *aIwOff = nullptr, *aDst = nullptr, *aIbeg = nullptr;
 };
 
 static std::string g_create_err;
@@ -124,7 +128,8 @@ void soc_destroy(soc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dPSPOS, c->dPS,
-                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats };
+                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats,
+                     c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
     if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
@@ -509,6 +514,144 @@ int soc_timer_stop(soc_ctx *c, float *elapsed_ms)
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (elapsed_ms) *elapsed_ms = ms;
+    return SOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// A2E: stochastically heated grains
+// ---------------------------------------------------------------------------------------
+
+int soc_a2e_set_size(soc_ctx *c, int NE, int NFREQ, int noIw, const float *Iw, const int32_t *L1,
+                     const int32_t *L2, const float *Tdown, const float *EA, const int32_t *Ibeg, const float *AF)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (NE < 3 || NE > 280 || NFREQ < 2 || noIw < 0 || !Iw || !L1 || !L2 || !Tdown || !EA || !Ibeg || !AF)
+        return fail(c, SOC_ERR_ARG, "soc_a2e_set_size: bad arguments (3 <= NE <= 280, NFREQ >= 2)");
+    // pair tables in the reference's (l, u) loop order; validate every window on the host
+    const int npair = (NE * NE - NE) / 2;
+    std::vector<int> first(npair), last(npair), off(npair), dst(npair);
+    long long iw = 0;
+    int e = 0;
+    for (int l = 0; l < NE - 1; l++) {
+        for (int u = l + 1; u < NE; u++, e++) {
+            const int i0 = L1[l * NE + u], i1 = L2[l * NE + u];
+            if (i1 >= i0 && (i0 < 0 || i1 >= NFREQ))
+                return fail(c, SOC_ERR_ARG, "soc_a2e_set_size: window [%d,%d] of pair (l=%d,u=%d) outside 0..%d", i0, i1, l, u, NFREQ - 1);
+            first[e] = i0;  last[e] = i1;  off[e] = (int)iw;  dst[e] = (u * u - u) / 2 + l;
+            if (i1 >= i0) iw += i1 - i0 + 1;
+        }
+    }
+    if (iw != noIw) return fail(c, SOC_ERR_ARG, "soc_a2e_set_size: windows need %lld weights, noIw = %d", iw, noIw);
+    for (int f = 0; f < NFREQ; f++)
+        if (Ibeg[f] < 0 || Ibeg[f] > NE) return fail(c, SOC_ERR_ARG, "soc_a2e_set_size: Ibeg[%d] = %d", f, Ibeg[f]);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, dev_alloc(&c->aIw, (size_t)noIw));
+    HIPCHK(c, dev_alloc(&c->aFirst, (size_t)npair));
+    HIPCHK(c, dev_alloc(&c->aLast, (size_t)npair));
+    HIPCHK(c, dev_alloc(&c->aIwOff, (size_t)npair));
+    HIPCHK(c, dev_alloc(&c->aDst, (size_t)npair));
+    HIPCHK(c, dev_alloc(&c->aTdown, (size_t)NE));
+    HIPCHK(c, dev_alloc(&c->aEA, (size_t)NE * NFREQ));
+    HIPCHK(c, dev_alloc(&c->aIbeg, (size_t)NFREQ));
+    HIPCHK(c, dev_alloc(&c->aAF, (size_t)NFREQ));
+    if (noIw) HIPCHK(c, hipMemcpy(c->aIw, Iw, (size_t)noIw * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aFirst, first.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aLast, last.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aIwOff, off.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aDst, dst.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aTdown, Tdown, (size_t)NE * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aEA, EA, (size_t)NE * NFREQ * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aIbeg, Ibeg, (size_t)NFREQ * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->aAF, AF, (size_t)NFREQ * 4, hipMemcpyHostToDevice));
+    if (NFREQ != c->a2e_NFREQ) c->a2e_cap = 0;
+    c->a2e_NE = NE;  c->a2e_NFREQ = NFREQ;  c->a2e_npair = npair;  c->a2e_noIw = noIw;
+    return SOC_OK;
+}
+
+static int a2e_reserve(soc_ctx *c, int batch)
+{
+    if (c->a2e_NE == 0) return fail(c, SOC_ERR_STATE, "A2E: call soc_a2e_set_size first");
+    if (batch < 1) return fail(c, SOC_ERR_ARG, "A2E: batch = %d", batch);
+    if (batch > c->a2e_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->aABS, (size_t)batch * c->a2e_NFREQ));
+        HIPCHK(c, dev_alloc(&c->aEMIT, (size_t)batch * c->a2e_NFREQ));
+        c->a2e_cap = batch;
+    }
+    return SOC_OK;
+}
+
+int soc_a2e_upload(soc_ctx *c, int batch, const float *AABS)
+{
+    if (!c || !AABS) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int r = a2e_reserve(c, batch);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->aABS, AABS, (size_t)batch * c->a2e_NFREQ * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_a2e_run(soc_ctx *c, int batch)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->a2e_NE == 0 || batch < 1 || batch > c->a2e_cap) return fail(c, SOC_ERR_STATE, "soc_a2e_run: upload a batch first");
+    SocA2EArgs A{};
+    A.NE = c->a2e_NE;  A.NFREQ = c->a2e_NFREQ;  A.npair = c->a2e_npair;  A.batch = batch;
+    A.Iw = c->aIw;  A.pair_first = c->aFirst;  A.pair_last = c->aLast;  A.pair_iw = c->aIwOff;  A.pair_dst = c->aDst;
+    A.Tdown = c->aTdown;  A.EA = c->aEA;  A.Ibeg = c->aIbeg;  A.AF = c->aAF;  A.AABS = c->aABS;  A.AEMIT = c->aEMIT;
+    HIPCHK(c, soc_launch_a2e_dosolve(A, c->stream));
+    return SOC_OK;
+}
+
+int soc_a2e_download(soc_ctx *c, int batch, float *AEMIT)
+{
+    if (!c || !AEMIT) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (batch < 1 || batch > c->a2e_cap) return fail(c, SOC_ERR_ARG, "soc_a2e_download: batch = %d", batch);
+    HIPCHK(c, hipMemcpyAsync(AEMIT, c->aEMIT, (size_t)batch * c->a2e_NFREQ * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_a2e_solve(soc_ctx *c, int batch, const float *AABS, float *AEMIT)
+{
+    int r = soc_a2e_upload(c, batch, AABS);
+    if (r) return r;
+    r = soc_a2e_run(c, batch);
+    if (r) return r;
+    return soc_a2e_download(c, batch, AEMIT);
+}
+
+int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
+                   float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
+                   const float *ABS, float *T, float *EMIT)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (batch < 1 || NFREQ < 2 || NIP < 2 || !FREQ || !KABS || !TTT || !ABS || !T || !EMIT)
+        return fail(c, SOC_ERR_ARG, "soc_a2e_eqtemp: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    const size_t n = (size_t)2 * NFREQ + NIP + (size_t)2 * batch * NFREQ + batch;
+    HIPCHK(c, hipMalloc((void **)&d, n * 4));
+    float *dF = d, *dK = dF + NFREQ, *dT3 = dK + NFREQ, *dA = dT3 + NIP, *dE = dA + (size_t)batch * NFREQ, *dT = dE + (size_t)batch * NFREQ;
+    hipError_t e = hipMemcpy(dF, FREQ, (size_t)NFREQ * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dK, KABS, (size_t)NFREQ * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dT3, TTT, (size_t)NIP * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dA, ABS, (size_t)batch * NFREQ * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dE, 0, ((size_t)batch * NFREQ + batch) * 4);
+    SocEqTArgs A{};
+    A.batch = batch;  A.icell = icell;  A.CELLS = CELLS;  A.NFREQ = NFREQ;  A.NIP = NIP;
+    A.FACTOR = FACTOR;  A.kE = kE;  A.oplgkE = oplgkE;  A.Emin = Emin;
+    A.FREQ = dF;  A.KABS = dK;  A.TTT = dT3;  A.ABS = dA;  A.T = dT;  A.EMIT = dE;
+    if (e == hipSuccess) e = soc_launch_a2e_eqtemp(A, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(T, dT, (size_t)batch * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(EMIT, dE, (size_t)batch * NFREQ * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_a2e_eqtemp: %s", hipGetErrorString(e));
     return SOC_OK;
 }
 

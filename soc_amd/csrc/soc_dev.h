@@ -54,6 +54,32 @@ hipError_t soc_launch_trace(const SocGrid &G, const SocVariant &V, const float *
                             hipStream_t st);
 
 
+// stochastic-heating solver (soc_a2e.hip)
+struct SocA2EArgs {
+    int NE, NFREQ, npair, batch;
+    const float *Iw;                 // integration weights, in (l,u,i) loop order
+    const int   *pair_first;         // [npair] L1[l*NE+u]
+    const int   *pair_last;          // [npair] L2[l*NE+u]
+    const int   *pair_iw;            // [npair] offset of the pair's first weight in Iw
+    const int   *pair_dst;           // [npair] (u*u-u)/2 + l
+    const float *Tdown;              // [NE]
+    const float *EA;                 // [NFREQ*NE]
+    const int   *Ibeg;               // [NFREQ]
+    const float *AF;                 // [NFREQ]
+    const float *AABS;               // [batch*NFREQ]
+    float       *AEMIT;              // [batch*NFREQ]
+};
+
+struct SocEqTArgs {
+    int batch, icell, CELLS, NFREQ, NIP;
+    float FACTOR, kE, oplgkE, Emin;
+    const float *FREQ, *KABS, *TTT, *ABS;
+    float *T, *EMIT;
+};
+
+hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st);
+hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
+
 // brick-sweep execution (soc_brick.hip): LDS-resident tallies, packets sorted by brick
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &S, const SocVariant &V, int LB,
                             hipStream_t st, int *passes_out);

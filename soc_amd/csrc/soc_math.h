@@ -129,6 +129,21 @@ SOC_HD float soc_logf(float x)
     return r;
 }
 
+// log10(x) and integer power x^n (n >= 0): used by the equilibrium-temperature lookup
+// (kernel_A2E.c:136-137 calls the OpenCL built-ins log10 and pown)
+SOC_HD float soc_log10f(float x) { return soc_logf(x) * 0.43429448190325182765f; }
+SOC_HD float soc_pownf(float x, int n)
+{
+    float r = 1.0f, b = x;
+    unsigned int e = (unsigned int)(n < 0 ? -n : n);
+    while (e) {                                       // binary exponentiation, fixed operation order
+        if (e & 1u) r = r * b;
+        b = b * b;
+        e >>= 1;
+    }
+    return (n < 0) ? (1.0f / r) : r;
+}
+
 // sin and cos together.  Three-term Cody-Waite reduction: accurate for |x| < ~1e4,
 // which covers every call on the path (arguments lie in [-2 pi, 2 pi]).
 SOC_HD void soc_sincosf(float x, float *s, float *c)

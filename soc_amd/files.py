@@ -194,3 +194,34 @@ def analyse_external_point_sources(NX, NY, NZ, PSPOS, NO_PS, PS_METHOD):
                 cos_theta = min(cos_theta, tmp)
             XPS_AREA[3 * i] = cos_theta
     return XPS_NSIDE, XPS_SIDE, XPS_AREA
+
+
+def read_solver(filename):
+    """``*.solver`` file -> dict (layout: A2E_pre.py:180-290, read as A2E.py:116-127, 354-370 does)."""
+    with open(filename, 'rb') as fp:
+        NFREQ = int(np.fromfile(fp, np.int32, 1)[0])
+        FREQ = np.fromfile(fp, np.float32, NFREQ)
+        GD = np.fromfile(fp, np.float32, 1)[0]
+        NSIZE = int(np.fromfile(fp, np.int32, 1)[0])
+        SIZE_A = np.fromfile(fp, np.float32, NSIZE)
+        S_FRAC = np.clip(np.fromfile(fp, np.float32, NSIZE), 1.0e-32, 1.0e30)
+        NE = int(np.fromfile(fp, np.int32, 1)[0])
+        SK_ABS = np.fromfile(fp, np.float32, NSIZE * NFREQ).reshape(NSIZE, NFREQ)
+        sizes = []
+        for isize in range(NSIZE):
+            n = np.fromfile(fp, np.int32, 1)
+            if n.size != 1:
+                break                      # files written for equilibrium sizes only stop early
+            noIw = int(n[0])
+            s = dict(Iw=np.fromfile(fp, np.float32, noIw), L1=np.fromfile(fp, np.int32, NE * NE),
+                     L2=np.fromfile(fp, np.int32, NE * NE), Tdown=np.fromfile(fp, np.float32, NE),
+                     EA=np.fromfile(fp, np.float32, NE * NFREQ), Ibeg=np.fromfile(fp, np.int32, NFREQ))
+            if s["Ibeg"].size != NFREQ:
+                raise FileError("%s: size %d truncated" % (filename, isize))
+            sizes.append(s)
+    return dict(NFREQ=NFREQ, FREQ=FREQ, GD=GD, NSIZE=NSIZE, SIZE_A=SIZE_A, S_FRAC=S_FRAC, NE=NE, SK_ABS=SK_ABS, sizes=sizes)
+
+
+def write_emitted(filename, EMITTED):
+    """emitted file: int32 CELLS,NFREQ; float32 [CELLS,NFREQ] (A2E.py:151-156)"""
+    write_absorbed(filename, EMITTED)

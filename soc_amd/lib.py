@@ -47,6 +47,13 @@ API = {
     "soc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "soc_timer_start": (C.c_int, [C.c_void_p]),
     "soc_timer_stop": (C.c_int, [C.c_void_p, _F]),
+    "soc_a2e_set_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F]),
+    "soc_a2e_solve": (C.c_int, [C.c_void_p, C.c_int, _F, _F]),
+    "soc_a2e_upload": (C.c_int, [C.c_void_p, C.c_int, _F]),
+    "soc_a2e_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_a2e_download": (C.c_int, [C.c_void_p, C.c_int, _F]),
+    "soc_a2e_eqtemp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, _F, _F, _F, _F, _F, _F]),
     "soc_probe_rng": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int, _U, _U]),
     "soc_probe_math": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_int64]),
     "soc_probe_trace": (C.c_int, [C.c_void_p, _F, _F, C.c_int, _I, _I, _F, _F, _I]),
@@ -236,6 +243,48 @@ class Engine:
         ms = C.c_float()
         self._chk(self.lib.soc_timer_stop(self.h, C.byref(ms)))
         return float(ms.value)
+
+    # ---- A2E ----
+    def a2e_set_size(self, NE, NFREQ, size, AF):
+        """size: dict with Iw, L1, L2, Tdown, EA, Ibeg of one grain size (solver file)."""
+        a = {k: np.ascontiguousarray(size[k], t) for k, t in (("Iw", np.float32), ("L1", np.int32), ("L2", np.int32),
+                                                                ("Tdown", np.float32), ("EA", np.float32), ("Ibeg", np.int32))}
+        AF = np.ascontiguousarray(AF, np.float32)
+        if a["L1"].size != NE * NE or a["L2"].size != NE * NE or a["Tdown"].size != NE or a["EA"].size != NE * NFREQ \
+                or a["Ibeg"].size != NFREQ or AF.size != NFREQ:
+            raise SocError("a2e_set_size: array sizes do not match NE=%d NFREQ=%d" % (NE, NFREQ))
+        self._a2e_nfreq = NFREQ
+        self._chk(self.lib.soc_a2e_set_size(self.h, int(NE), int(NFREQ), int(a["Iw"].size), _f(a["Iw"]), _i(a["L1"]),
+                                            _i(a["L2"]), _f(a["Tdown"]), _f(a["EA"]), _i(a["Ibeg"]), _f(AF)))
+
+    def a2e_solve(self, AABS):
+        AABS = np.ascontiguousarray(AABS, np.float32)
+        out = np.zeros_like(AABS)
+        self._chk(self.lib.soc_a2e_solve(self.h, AABS.shape[0], _f(AABS), _f(out)))
+        return out
+
+    def a2e_upload(self, AABS):
+        AABS = np.ascontiguousarray(AABS, np.float32)
+        self._chk(self.lib.soc_a2e_upload(self.h, AABS.shape[0], _f(AABS)))
+
+    def a2e_run(self, batch):
+        self._chk(self.lib.soc_a2e_run(self.h, int(batch)))
+
+    def a2e_download(self, batch):
+        out = np.zeros((batch, self._a2e_nfreq), np.float32)
+        self._chk(self.lib.soc_a2e_download(self.h, int(batch), _f(out)))
+        return out
+
+    def a2e_eqtemp(self, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+        ABS = np.ascontiguousarray(ABS, np.float32)
+        batch, NFREQ = ABS.shape
+        FREQ, KABS, TTT = (np.ascontiguousarray(a, np.float32) for a in (FREQ, KABS, TTT))
+        T = np.zeros(batch, np.float32)
+        E = np.zeros((batch, NFREQ), np.float32)
+        self._chk(self.lib.soc_a2e_eqtemp(self.h, batch, int(icell), int(CELLS), NFREQ, int(NIP), np.float32(FACTOR),
+                                          np.float32(kE), np.float32(oplgkE), np.float32(Emin), _f(FREQ), _f(KABS),
+                                          _f(TTT), _f(ABS), _f(T), _f(E)))
+        return T, E
 
     # ---- probes ----
     def probe_rng(self, SEED, gid_first, n, ndraw):

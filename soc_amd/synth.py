@@ -134,3 +134,84 @@ def hg_scattering_table(g, bins=2500):
         s = 1.0 / (1.0 - g) - 2.0 * g * u / (1.0 - g * g)
         csc = (1.0 + g * g - 1.0 / (s * s)) / (2.0 * g)
     return dsc.astype(np.float32), np.clip(csc, -1.0, 1.0).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------
+# synthetic stochastic-heating solver data (input of A2E, SURVEY.md 5.4 "solver" layout)
+# ---------------------------------------------------------------------------------------
+
+def synth_solver(NFREQ=50, NE=128, NSIZE=3, seed=5):
+    """A synthetic ``*.solver`` data set in the layout A2E_pre.py writes (A2E_pre.py:180-290) and
+    A2E.py reads (A2E.py:116-127, 354-370).  The reference ships no GSET dust files, so the
+    arrays are built from a simple enthalpy-grid model: transition l->u is fed by the
+    frequencies whose photon energy matches E_u - E_l within the bin width; cooling goes
+    u -> u-1; emission per enthalpy bin is Planck-like.  Returns a dict of numpy arrays."""
+    rng = np.random.default_rng(seed)
+    h = 6.62606957e-27
+    FREQ = np.logspace(np.log10(1.5e11), np.log10(2.0e15), NFREQ).astype(np.float32)
+    SIZE_A = np.logspace(-7.5, -6.0, NSIZE).astype(np.float32)
+    S_FRAC = (np.ones(NSIZE) / NSIZE).astype(np.float32)
+    GD = np.float32(1.0e-10)
+    SK_ABS = (1e-22 * (FREQ[None, :] / 1e13) ** 1.5 * (SIZE_A[:, None] / 1e-7) ** 2 / NSIZE).astype(np.float32)
+    sizes = []
+    for isize in range(NSIZE):
+        E = h * 1.0e11 * (h * 4.0e15 / (h * 1.0e11)) ** (np.arange(NE) / (NE - 1.0))     # enthalpy bins [erg]
+        W = np.gradient(E)
+        L1 = np.ones((NE, NE), np.int32)
+        L2 = np.zeros((NE, NE), np.int32)
+        Iw = []
+        hnu = h * FREQ.astype(np.float64)
+        for l in range(NE - 1):
+            for u in range(l + 1, NE):
+                dE = E[u] - E[l]
+                m = np.nonzero((hnu >= dE - 0.75 * W[u]) & (hnu <= dE + 0.75 * W[u]))[0]
+                if len(m) > 0:
+                    L1[l, u], L2[l, u] = m[0], m[-1]
+                    w = rng.uniform(0.5, 1.5, len(m)) * 1.0e-3 / len(m)
+                    if rng.random() < 0.02:
+                        w[0] = -w[0]                    # the reference clamps negative sums with max(I, 0)
+                    Iw.extend(w)
+        Tdown = (1.0e-2 * (1.0 + np.arange(NE)) ** 1.5 * rng.uniform(0.9, 1.1, NE)).astype(np.float32)
+        T_of_bin = 5.0 + 600.0 * (np.arange(NE) / (NE - 1.0)) ** 2
+        x = np.clip(4.79924335e-11 * FREQ[:, None].astype(np.float64) / T_of_bin[None, :], 0, 80)
+        EA = (1e-30 * FREQ[:, None].astype(np.float64) ** 2 / (np.exp(x) - 1.0 + 1e-30)
+              * SK_ABS[isize][:, None] * 1e20).astype(np.float32)                       # [NFREQ, NE]
+        Ibeg = np.zeros(NFREQ, np.int32)
+        for j in range(NFREQ):
+            nz = np.nonzero(EA[j] > 1e-30 * EA[j].max())[0]
+            Ibeg[j] = nz[0] if len(nz) else NE - 1
+        sizes.append(dict(Iw=np.asarray(Iw, np.float32), L1=L1.reshape(-1), L2=L2.reshape(-1), Tdown=Tdown,
+                          EA=EA.reshape(-1), Ibeg=Ibeg))
+    return dict(NFREQ=NFREQ, FREQ=FREQ, GD=GD, NSIZE=NSIZE, SIZE_A=SIZE_A, S_FRAC=S_FRAC, NE=NE, SK_ABS=SK_ABS,
+                sizes=sizes)
+
+
+def write_solver(filename, sol):
+    """int32 NFREQ; f32 FREQ; f32 GD; int32 NSIZE; f32 SIZE_A; f32 S_FRAC; int32 NE; f32 SK_ABS[NSIZE,NFREQ];
+    per size: int32 noIw; f32 Iw; int32 L1[NE*NE]; int32 L2[NE*NE]; f32 Tdown[NE]; f32 EA[NFREQ*NE]; int32 Ibeg[NFREQ]"""
+    with open(filename, "wb") as fp:
+        np.asarray([sol["NFREQ"]], np.int32).tofile(fp)
+        np.asarray(sol["FREQ"], np.float32).tofile(fp)
+        np.asarray([sol["GD"]], np.float32).tofile(fp)
+        np.asarray([sol["NSIZE"]], np.int32).tofile(fp)
+        np.asarray(sol["SIZE_A"], np.float32).tofile(fp)
+        np.asarray(sol["S_FRAC"], np.float32).tofile(fp)
+        np.asarray([sol["NE"]], np.int32).tofile(fp)
+        np.asarray(sol["SK_ABS"], np.float32).tofile(fp)
+        for s in sol["sizes"]:
+            np.asarray([len(s["Iw"])], np.int32).tofile(fp)
+            np.asarray(s["Iw"], np.float32).tofile(fp)
+            np.asarray(s["L1"], np.int32).tofile(fp)
+            np.asarray(s["L2"], np.int32).tofile(fp)
+            np.asarray(s["Tdown"], np.float32).tofile(fp)
+            np.asarray(s["EA"], np.float32).tofile(fp)
+            np.asarray(s["Ibeg"], np.int32).tofile(fp)
+
+
+def a2e_absorption_fraction(sol, isize):
+    """AF of A2E.py:338-341: share of the absorptions taken by one size, per grain."""
+    K_ABS = np.sum(sol["SK_ABS"], axis=0)
+    S_FRAC = np.clip(sol["S_FRAC"], 1.0e-32, 1.0e30)
+    AF = np.asarray(sol["SK_ABS"][isize, :], np.float64) / np.asarray(K_ABS, np.float64)
+    AF /= S_FRAC[isize] * sol["GD"]
+    return np.asarray(np.clip(AF, 1.0e-32, 1.0e+100), np.float32)

@@ -90,5 +90,42 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sims.npz"), **out)
 
 
+def a2e_case(tag):
+    """Seeded inputs of one A2E golden case (shared with tests/test_a2e.py)."""
+    from oracle import build as ob
+    m = ob.a2e_ref_models()[tag]
+    sol = synth.synth_solver(NFREQ=m["NFREQ"], NE=m["NE"], NSIZE=2, seed=5)
+    rng = np.random.default_rng(1)
+    batch = min(m["CELLS"], 37)
+    ABS = (rng.lognormal(0, 1, (batch, m["NFREQ"])) * 1e-3 * (sol["FREQ"][None, :] / 1e13) ** -1.0).astype(np.float32)
+    return m, sol, ABS
+
+
+def a2e_main():
+    from oracle.pyoracle import RefA2E
+    sys.path.insert(0, REPO)
+    from soc_amd import a2e as a2e_host
+    out = {}
+    for tag in ("ne16", "ne64", "ne128"):
+        m, sol, ABS = a2e_case(tag)
+        r = RefA2E(tag)
+        for isize in range(2):
+            AF = synth.a2e_absorption_fraction(sol, isize)
+            out["%s_s%d_emit" % (tag, isize)] = r.dosolve(sol["sizes"][isize], AF, ABS)
+        out[tag + "_abs"] = ABS
+    # EqTemperature on the ne64 build (NIP 5000)
+    m, sol, ABS = a2e_case("ne64")
+    Emin, kE, oplgkE, TTT, KABS = a2e_host.eq_table(sol, 1)
+    AF = synth.a2e_absorption_fraction(sol, 1)
+    tmp = np.asarray(ABS * AF, np.float32)
+    T, E = RefA2E("ne64").eqtemp(0, kE, oplgkE, Emin, sol["FREQ"], KABS, TTT, tmp)
+    out.update(eq_T=T, eq_emit=E, eq_TTT=TTT, eq_scal=np.asarray([Emin, kE, oplgkE], np.float64), eq_abs=tmp, eq_kabs=KABS)
+    np.savez_compressed(os.path.join(HERE, "a2e.npz"), **out)
+    print("a2e golden: T range", T.min(), T.max())
+
+
 if __name__ == "__main__":
+    if "--a2e" in sys.argv:
+        a2e_main()
+        sys.exit(0)
     main()

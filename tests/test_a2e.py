@@ -1,0 +1,149 @@
+"""A2E (stochastically heated grains): oracle pinned to the reference's DoSolve/EqTemperature
+(bit-exact in libm mode), file formats, and -- on the GPU -- the HIP kernels against the oracle.
+
+Tolerances on the GPU: EqTemperature is one lane per cell with the shared math header ->
+bit-identical to the oracle's soc mode.  DoSolve keeps the reference's summation order
+everywhere except the forward-substitution dot products (wave butterfly instead of a serial
+loop): all terms are >= 0, so the bound is n*eps per sum; rtol 5e-5 is asserted."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import RefA2E, a2e_oracle_dosolve, a2e_oracle_eqtemp
+from soc_amd import files, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_golden import a2e_case  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "a2e.npz"))
+
+
+@pytest.mark.parametrize("tag", ["ne16", "ne64", "ne128"])
+def test_dosolve_oracle_bit_exact_vs_reference_golden(tag, oracle_libm, oracle_soc):
+    m, sol, ABS = a2e_case(tag)
+    assert np.array_equal(ABS, GOLD[tag + "_abs"])
+    for isize in range(2):
+        AF = synth.a2e_absorption_fraction(sol, isize)
+        for orc in (oracle_libm, oracle_soc):          # DoSolve has no transcendentals: both modes identical
+            e = a2e_oracle_dosolve(orc, m["NE"], m["NFREQ"], sol["sizes"][isize], AF, ABS)
+            assert np.array_equal(e.view(np.uint32), GOLD["%s_s%d_emit" % (tag, isize)].view(np.uint32))
+            assert np.isfinite(e).all() and (e >= 0).all() and e.max() > 0
+
+
+def test_eqtemp_oracle_vs_reference_golden(oracle_libm, oracle_soc):
+    m, sol, ABS = a2e_case("ne64")
+    Emin, kE, oplgkE = GOLD["eq_scal"]
+    T, E = a2e_oracle_eqtemp(oracle_libm, 0, m["CELLS"], m["NIP"], 1e20, kE, oplgkE, Emin, sol["FREQ"], GOLD["eq_kabs"],
+                             GOLD["eq_TTT"], GOLD["eq_abs"])
+    assert np.array_equal(T.view(np.uint32), GOLD["eq_T"].view(np.uint32))
+    assert np.array_equal(E.view(np.uint32), GOLD["eq_emit"].view(np.uint32))
+    T2, E2 = a2e_oracle_eqtemp(oracle_soc, 0, m["CELLS"], m["NIP"], 1e20, kE, oplgkE, Emin, sol["FREQ"], GOLD["eq_kabs"],
+                               GOLD["eq_TTT"], GOLD["eq_abs"])
+    assert np.allclose(T2, GOLD["eq_T"], rtol=2e-5)     # soc_pownf/soc_log10f vs libm powf/log10f
+    ok = GOLD["eq_emit"] > 1e-30 * GOLD["eq_emit"].max()
+    assert np.allclose(E2[ok], GOLD["eq_emit"][ok], rtol=2e-3)   # Wien tail amplifies dT/T by h nu / kT
+
+
+@pytest.mark.skipif(not RefA2E.available("ne16"), reason="reference builds (oracle/_ref) not present")
+def test_dosolve_live_vs_reference_random_inputs(oracle_libm):
+    m, sol, _ = a2e_case("ne16")
+    rng = np.random.default_rng(9)
+    ABS = (rng.lognormal(0, 2, (40, m["NFREQ"])) * 1e-2).astype(np.float32)
+    ABS[3] = 0.0                                       # a cell without absorptions
+    AF = synth.a2e_absorption_fraction(sol, 0)
+    a = a2e_oracle_dosolve(oracle_libm, m["NE"], m["NFREQ"], sol["sizes"][0], AF, ABS)
+    b = RefA2E("ne16").dosolve(sol["sizes"][0], AF, ABS)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_solver_file_round_trip(tmp_path):
+    sol = synth.synth_solver(NFREQ=12, NE=16, NSIZE=3, seed=2)
+    fn = str(tmp_path / "x.solver")
+    synth.write_solver(fn, sol)
+    back = files.read_solver(fn)
+    assert back["NFREQ"] == 12 and back["NE"] == 16 and back["NSIZE"] == 3 and len(back["sizes"]) == 3
+    assert np.array_equal(back["FREQ"], sol["FREQ"]) and np.array_equal(back["SK_ABS"], sol["SK_ABS"])
+    for a, b in zip(back["sizes"], sol["sizes"]):
+        for k in ("Iw", "L1", "L2", "Tdown", "EA", "Ibeg"):
+            assert np.array_equal(a[k], b[k])
+    # windows and weight count are consistent (what soc_a2e_set_size validates on the host)
+    for s in sol["sizes"]:
+        L1, L2 = s["L1"].reshape(16, 16), s["L2"].reshape(16, 16)
+        n = sum(max(0, L2[l, u] - L1[l, u] + 1) for l in range(15) for u in range(l + 1, 16))
+        assert n == len(s["Iw"])
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["ne16", "ne64", "ne128"])
+def test_gpu_dosolve_vs_oracle_and_golden(tag, engine, oracle_soc):
+    m, sol, ABS = a2e_case(tag)
+    for isize in range(2):
+        AF = synth.a2e_absorption_fraction(sol, isize)
+        want = a2e_oracle_dosolve(oracle_soc, m["NE"], m["NFREQ"], sol["sizes"][isize], AF, ABS)
+        engine.a2e_set_size(m["NE"], m["NFREQ"], sol["sizes"][isize], AF)
+        got = engine.a2e_solve(ABS)
+        assert np.isfinite(got).all()
+        assert np.allclose(got, want, rtol=5e-5, atol=1e-30)
+        assert np.allclose(got, GOLD["%s_s%d_emit" % (tag, isize)], rtol=5e-5, atol=1e-30)
+
+
+@pytest.mark.gpu
+def test_gpu_dosolve_ragged_and_edge_inputs(engine, oracle_soc):
+    m, sol, _ = a2e_case("ne64")
+    rng = np.random.default_rng(4)
+    ABS = (rng.lognormal(0, 2, (131, m["NFREQ"])) * 1e-2).astype(np.float32)
+    ABS[0] = 0.0
+    ABS[1] *= 1e12                                     # triggers the 1e-20 rescaling branch
+    AF = synth.a2e_absorption_fraction(sol, 1)
+    want = a2e_oracle_dosolve(oracle_soc, m["NE"], m["NFREQ"], sol["sizes"][1], AF, ABS)
+    engine.a2e_set_size(m["NE"], m["NFREQ"], sol["sizes"][1], AF)
+    got = engine.a2e_solve(ABS)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert np.allclose(got[ok], want[ok], rtol=5e-5, atol=1e-30)
+    one = engine.a2e_solve(ABS[5:6])                   # batch of one cell
+    assert np.allclose(one[0], want[5], rtol=5e-5, atol=1e-30)
+    from soc_amd.lib import SocError
+    bad = dict(sol["sizes"][1])
+    bad["L2"] = bad["L2"].copy()
+    bad["L2"][1] = 10 ** 6
+    with pytest.raises(SocError, match="outside"):
+        engine.a2e_set_size(m["NE"], m["NFREQ"], bad, AF)
+
+
+@pytest.mark.gpu
+def test_gpu_eqtemp_bit_identical_to_oracle(engine, oracle_soc):
+    m, sol, ABS = a2e_case("ne64")
+    Emin, kE, oplgkE = GOLD["eq_scal"]
+    T, E = a2e_oracle_eqtemp(oracle_soc, 0, m["CELLS"], m["NIP"], 1e20, kE, oplgkE, Emin, sol["FREQ"], GOLD["eq_kabs"],
+                             GOLD["eq_TTT"], GOLD["eq_abs"])
+    Tg, Eg = engine.a2e_eqtemp(0, m["CELLS"], m["NIP"], 1e20, kE, oplgkE, Emin, sol["FREQ"], GOLD["eq_kabs"],
+                               GOLD["eq_TTT"], GOLD["eq_abs"])
+    assert np.array_equal(Tg.view(np.uint32), T.view(np.uint32))
+    assert np.array_equal(Eg.view(np.uint32), E.view(np.uint32))
+    assert np.allclose(Tg, GOLD["eq_T"], rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_a2e_host_program(engine, oracle_soc, tmp_path):
+    """files in -> files out, stochastic + equilibrium sizes, against an oracle-driven evaluation."""
+    from soc_amd import a2e
+    sol = synth.synth_solver(NFREQ=12, NE=16, NSIZE=3, seed=2)
+    rng = np.random.default_rng(3)
+    ABS = (rng.lognormal(0, 1, (300, 12)) * 1e-3).astype(np.float32)
+    E, _ = a2e.run(engine, sol, ABS, NSTOCH=2, batch=128, verbose=False)
+    A = ABS.copy()
+    A[:, 11] = np.clip(A[:, 11], 0.0, 0.2 * A[:, 10])
+    want = np.zeros_like(E)
+    for isize in range(2):
+        want += a2e_oracle_dosolve(oracle_soc, 16, 12, sol["sizes"][isize], synth.a2e_absorption_fraction(sol, isize), A)
+    Emin, kE, oplgkE, TTT, KABS = a2e.eq_table(sol, 2)
+    AF = synth.a2e_absorption_fraction(sol, 2)
+    T, e2 = a2e_oracle_eqtemp(oracle_soc, 0, 300, a2e.NIP, 1e20, kE, oplgkE, Emin, sol["FREQ"], KABS, TTT,
+                              np.asarray(A * AF, np.float32))
+    want += e2 * (sol["GD"] * sol["S_FRAC"][2])
+    assert np.allclose(E, want, rtol=5e-5, atol=1e-30 * want.max())
