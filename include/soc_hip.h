@@ -71,8 +71,8 @@ int soc_set_optical(soc_ctx *ctx, const float *ABS, const float *SCA, int ndust)
  * OPT[CELLS][2] = (abs, sca) per cell; NULL switches back to scalar ABS/SCA */
 int soc_set_opt(soc_ctx *ctx, const float *OPT);
 
-/* replaces the DSC/CSC row uploads (ASOC.py:1234-1243); DSC may be NULL (unused by the
- * absorption kernels); BINS = USER.DSC_BINS */
+/* replaces the DSC/CSC row uploads (ASOC.py:1234-1243, ASOCS.py:625-626); DSC may be NULL
+ * (unused by the absorption kernels, required by soc_sca_sim_ps/pb); BINS = USER.DSC_BINS */
 int soc_set_scatter_table(soc_ctx *ctx, const float *DSC, const float *CSC, int BINS);
 
 /* replaces the EMIT / EMWEI uploads (ASOC.py:1276, 1291); arrays of CELLS floats */
@@ -123,6 +123,46 @@ int soc_last_passes(soc_ctx *ctx);
 /* HIP-event timing on the handle's stream: bracket launches, then read elapsed ms */
 int soc_timer_start(soc_ctx *ctx);
 int soc_timer_stop(soc_ctx *ctx, float *elapsed_ms);
+
+/* ---- scattered-light images: ASOCS.py / kernel_ASOC_sca.c ---- */
+
+/* replaces the ODIR/RA/DE buffers and the NDIR, NPIX, MAP_DX, MAPCENTRE scalars of every
+ * kernel_ASOC_sca.c launch (ASOCS.py:247-262, 655-708) and the -D FFS= build option
+ * (ASOCS.py:139).  ODIR, RA, DE hold 4 floats per direction (cl float3), as returned by
+ * set_observer_directions (ASOC_aux.py:1129-1183); CENTRE = 3 floats.  Allocates the image
+ * OUT[NDIR][NPIX_Y][NPIX_X] on the device (ASOCS.py:246).  Healpix output (NDIR<0) is not
+ * supported. */
+int soc_sca_set_view(soc_ctx *ctx, int NDIR, const float *ODIR, const float *RA, const float *DE,
+                     int NPIX_X, int NPIX_Y, float MAP_DX, const float *CENTRE, int FFS);
+
+/* replaces zero_out (kernel_ASOC_sca.c:14-35; ASOCS.py:515, 781) */
+int soc_sca_zero(soc_ctx *ctx);
+
+/* replaces the kernel_PS launch (ASOCS.py:665-671 -> SimRAM_PS, kernel_ASOC_sca.c:1462-1489):
+ * point sources.  XPS_* are the int32/float32 arrays of AnalyseExternalPointSources exactly as
+ * ASOCS.py uploads them; the reference kernel declares the two integer arrays as float and
+ * that reading is reproduced.  Work-item range as in soc_sim_pb. */
+int soc_sca_sim_ps(soc_ctx *ctx, int PACKETS, int BATCH, float SEED, float BG, const float *PSPOS, const float *PS,
+                   int NO_PS, const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
+                   int GLOBAL, int gid_first, int gid_count);
+
+/* replaces the kernel_PB launch (ASOCS.py:681-688 -> SimRAM_PB, kernel_ASOC_sca.c:471-501):
+ * SOURCE 1 = isotropic background (what ASOCS.py uses it for), 0 = point sources */
+int soc_sca_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, const float *PSPOS,
+                   const float *PS, int NO_PS, const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE,
+                   const float *XPS_AREA, int GLOBAL, int gid_first, int gid_count);
+
+/* replaces the kernel_CL launches (ASOCS.py:692-698, 862-868 -> SimRAM_CL,
+ * kernel_ASOC_sca.c:1098-1122); uses EMIT/EMWEI from soc_set_emission() */
+int soc_sca_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count);
+
+/* replaces cl.enqueue_copy(OUT, OUT_buf) (ASOCS.py:715, 874); n = NDIR*NPIX_Y*NPIX_X */
+int soc_sca_read_out(soc_ctx *ctx, float *out, int64_t n);
+
+/* device address of the image, or bind caller-owned device memory as the image (for an RCCL
+ * all-reduce over the GPUs that shared a launch) */
+void *soc_sca_out_ptr(soc_ctx *ctx);
+int   soc_sca_bind_out(soc_ctx *ctx, void *device_ptr);
 
 /* ---- stochastically heated grains: A2E.py / kernel_A2E.c ---- */
 

@@ -127,6 +127,67 @@ def build_ref_a2e(tag, NE, NFREQ, LOCAL, CELLS, NIP=5000, force=False):
     return so
 
 
+def sca_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0, USE_EMWEIGHT=0, FFS=1, GL=0.01):
+    """The -D list of ASOCS.py:133-147 for one model."""
+    AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
+    d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=0, PS_METHOD=PS_METHOD, CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS),
+             WITH_ABU=WITH_ABU, FACTOR="1.0000e+20f", AXY="%.5ff" % (NX * NY / AREA), AXZ="%.5ff" % (NX * NZ / AREA),
+             AYZ="%.5ff" % (NY * NZ / AREA), LEVELS=LEVELS, LENGTH="%.5ef" % (GL * 3.08567758e18), POLSTAT=0,
+             SW_A="0.000e+00f", SW_B="0.000e+00f", STEP_WEIGHT=-1, DIR_WEIGHT=-1, DW_A="0.000e+00f", LEVEL_THRESHOLD=0,
+             POLRED=0, WITH_COLDEN=0, MINLOS="-1.000e+00f", MAXLOS="1.000e+10f", FFS=FFS, BG_METHOD=0,
+             USE_EMWEIGHT=USE_EMWEIGHT, HPBG_WEIGHTED=0, WITH_MSF=0, NDUST=1, OPT_IS_HALF=0, WITH_ROI_LOAD=0, ROI_NSIDE=16,
+             MIRROR=0, NVIDIA=0)
+    return ["-D%s=%s" % (k, v) for k, v in d.items()]
+
+
+def build_ref_sca(tag, force=False, **model):
+    """kernel_ASOC_sca.c for one model -> oracle/_ref/refsca_<tag>.so"""
+    so = os.path.join(REF_DIR, "refsca_%s.so" % tag)
+    ksrc = os.path.join(REFERENCE, "kernel_ASOC_sca.c")
+    if not os.path.exists(ksrc):
+        return so if os.path.exists(so) else None
+    os.makedirs(REF_DIR, exist_ok=True)
+    drv = os.path.join(HERE, "ref_sca.cpp")
+    defs = sca_defs(**model)
+    stamp = so + ".defs"
+    if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
+            and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
+        return so
+    kobj = os.path.join(REF_DIR, "ksca_%s.o" % tag)
+    sobj = os.path.join(REF_DIR, "dsca_%s.o" % tag)
+    common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
+    # SimRAM_CL reads the local `idust` without ever setting it when WITH_MSF==0
+    # (kernel_ASOC_sca.c:1151, used in DSC[idust*BINS+...] :1385): undefined behaviour that GPU
+    # compilers resolve to 0.  -ftrivial-auto-var-init=zero gives the x86 build the same value.
+    subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
+                           "-ftrivial-auto-var-init=zero", "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
+    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    os.remove(kobj)
+    os.remove(sobj)
+    with open(stamp, "w") as fp:
+        fp.write(" ".join(defs))
+    return so
+
+
+def sca_ref_models():
+    sys.path.insert(0, REPO)
+    from soc_amd import synth
+    oct8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    return {
+        "c8": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512),
+        "c8noffs": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, FFS=0),
+        "c8abu": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ABU=1),
+        "c8ps": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2),
+        "c8ps1": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2, PS_METHOD=1),
+        "c8ps2": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2, PS_METHOD=2),
+        "c8ps4": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=1, PS_METHOD=4),
+        "c8ps5": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2, PS_METHOD=5),
+        "oct8": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
+        "oct8emw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=1),
+    }
+
+
 def a2e_ref_models():
     return {
         "ne16": dict(NE=16, NFREQ=12, LOCAL=8, CELLS=40, NIP=500),
@@ -166,6 +227,8 @@ def build_all_refs(force=False):
         out[tag] = build_ref(tag, force=force, **model)
     for tag, model in a2e_ref_models().items():
         out["a2e_" + tag] = build_ref_a2e(tag, force=force, **model)
+    for tag, model in sca_ref_models().items():
+        out["sca_" + tag] = build_ref_sca(tag, force=force, **model)
     return out
 
 

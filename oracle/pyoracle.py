@@ -34,6 +34,9 @@ class OrcModel(C.Structure):
         ("PSPOS", _F), ("PS", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F),
         ("EMIT", _F), ("EMWEI", _F), ("TABS", _F), ("INT", _F),
         ("threaded", C.c_int),
+        ("NDIR", C.c_int), ("NPIX_X", C.c_int), ("NPIX_Y", C.c_int), ("FFS", C.c_int),
+        ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
+        ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("DSC", _F), ("OUT", _F), ("XPS_AS_FLOAT", C.c_int),
     ]
 
 
@@ -206,7 +209,7 @@ class Oracle:
     def math(self, fn, x):
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
-        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6)[fn]
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, expm1=8, pow15=9, logd=10)[fn]
         self.lib.orc_math_eval(code, _fp(x), _fp(y), x.size)
         return y
 
@@ -413,3 +416,95 @@ class RefA2E:
         self.lib.ref_eqtemp(batch, icell, np.float32(kE), np.float32(oplgkE), np.float32(Emin), _fp(FREQ), _fp(KABS),
                             _fp(TTT), _fp(ABS), _fp(T), _fp(E))
         return T, E
+
+
+# ---------------------------------------------------------------------------------------
+# scattered light (kernel_ASOC_sca.c): oracle + x86 builds of the reference
+# ---------------------------------------------------------------------------------------
+
+class ScaView:
+    """Observer set-up of one scattered-light launch: directions, image size, pixel, centre."""
+
+    def __init__(self, ODIR, RA, DE, NPIX=(16, 16), MAP_DX=1.0, CENTRE=(4.0, 4.0, 4.0), FFS=1):
+        self.ODIR, self.RA, self.DE = (np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (ODIR, RA, DE))
+        self.NDIR = len(self.ODIR)
+        self.NPIX = (int(NPIX[0]), int(NPIX[1]))
+        self.MAP_DX = np.float32(MAP_DX)
+        self.CENTRE = tuple(np.float32(c) for c in CENTRE)
+        self.FFS = int(FFS)
+
+    def out_size(self):
+        return self.NDIR * self.NPIX[0] * self.NPIX[1]
+
+
+class SArgs(C.Structure):
+    _fields_ = [("SOURCE", C.c_int), ("PACKETS", C.c_int), ("BATCH", C.c_int), ("GLOBAL", C.c_int), ("NDIR", C.c_int),
+                ("NPIX_X", C.c_int), ("NPIX_Y", C.c_int),
+                ("SEED", C.c_float), ("BG", C.c_float), ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
+                ("ABS", _F), ("SCA", _F), ("PSPOS", _F), ("PS", _F), ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
+                ("DENS", _F), ("EMIT", _F), ("DSC", _F), ("CSC", _F), ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("OUT", _F),
+                ("OPT", _F), ("EMWEI", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F)]
+
+
+def oracle_sim_sca(orc, job, view, kind=0, gid0=0, gid1=None, nthreads=1, stride=1, OUT=None):
+    """kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS (sca versions).  Returns (OUT, contributions)."""
+    L = orc.lib
+    L.orc_sim_sca.restype = C.c_long
+    L.orc_sim_sca.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    m = orc._model(job)
+    OUT = np.zeros(view.out_size(), np.float32) if OUT is None else OUT
+    m.NDIR, m.NPIX_X, m.NPIX_Y, m.FFS = view.NDIR, view.NPIX[0], view.NPIX[1], view.FFS
+    m.MAP_DX, m.CX, m.CY, m.CZ = view.MAP_DX, view.CENTRE[0], view.CENTRE[1], view.CENTRE[2]
+    m.ODIRS, m.ORA, m.ODE, m.DSC, m.OUT = _fp(view.ODIR), _fp(view.RA), _fp(view.DE), _fp(job.DSC), _fp(OUT)
+    m.XPS_AS_FLOAT = 1
+    gid1 = job.GLOBAL if gid1 is None else gid1
+    n = L.orc_sim_sca(C.byref(m), kind, gid0, gid1, stride, nthreads)
+    return OUT, int(n)
+
+
+class RefSca:
+    """x86 build of kernel_ASOC_sca.c for one model: oracle/_ref/refsca_<tag>.so"""
+
+    def __init__(self, tag):
+        self.model = _build.sca_ref_models()[tag]
+        path = _build.build_ref_sca(tag, **self.model)
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("reference build sca %s not available" % tag)
+        self.lib = C.CDLL(path)
+        self.lib.ref_sca_sim.argtypes = [C.POINTER(SArgs), C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.ref_sca_parents.argtypes = [_F, _I, _I, _I]
+
+    @staticmethod
+    def available(tag):
+        try:
+            RefSca(tag)
+            return True
+        except (FileNotFoundError, OSError, KeyError):
+            return False
+
+    def sim(self, job, view, kind=0, gid0=0, gid1=None, stride=1, OUT=None):
+        m, cl = self.model, job.cloud
+        assert (cl.NX, cl.NY, cl.NZ, cl.LEVELS, cl.CELLS) == (m["NX"], m["NY"], m["NZ"], m["LEVELS"], m["CELLS"])
+        assert job.BINS == m.get("BINS", 2500) and view.FFS == m.get("FFS", 1)
+        assert int(job.OPT is not None) == m.get("WITH_ABU", 0) and job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
+        assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1)) and job.PS_METHOD == m.get("PS_METHOD", 0)
+        PAR = np.zeros(max(1, cl.CELLS - cl.NX * cl.NY * cl.NZ), np.int32)
+        self.lib.ref_sca_parents(_fp(job.DENS), _ip(job.LCELLS), _ip(job.OFF), _ip(PAR))
+        OUT = np.zeros(view.out_size(), np.float32) if OUT is None else OUT
+        ABS = np.asarray([job.ABS], np.float32)
+        SCA = np.asarray([job.SCA], np.float32)
+        a = SArgs()
+        a.SOURCE, a.PACKETS, a.BATCH, a.GLOBAL, a.NDIR = job.SOURCE, job.PACKETS, job.BATCH, job.GLOBAL, view.NDIR
+        a.NPIX_X, a.NPIX_Y = view.NPIX
+        a.SEED, a.BG, a.MAP_DX = job.SEED, job.BG, view.MAP_DX
+        a.CX, a.CY, a.CZ = view.CENTRE
+        a.ABS, a.SCA, a.PSPOS, a.PS = _fp(ABS), _fp(SCA), _fp(job.PSPOS), _fp(job.PS)
+        a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
+        a.DENS, a.EMIT, a.DSC, a.CSC = _fp(job.DENS), _fp(job.EMIT), _fp(job.DSC), _fp(job.CSC)
+        a.ODIRS, a.ORA, a.ODE, a.OUT = _fp(view.ODIR), _fp(view.RA), _fp(view.DE), _fp(OUT)
+        a.OPT = _fp(job.OPT) if job.OPT is not None else None
+        a.EMWEI = _fp(job.EMWEI)
+        a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
+        gid1 = job.GLOBAL if gid1 is None else gid1
+        self.lib.ref_sca_sim(C.byref(a), kind, gid0, gid1, stride)
+        return OUT

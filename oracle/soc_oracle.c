@@ -32,6 +32,7 @@
 #ifdef SOC_ORACLE_LIBM
 #  define M_EXP(x)   expf(x)
 #  define M_LOG(x)   logf(x)
+#  define M_LOGD(x)  log(x)
 #  define M_SIN(x)   sinf(x)
 #  define M_COS(x)   cosf(x)
 #  define M_ACOS(x)  acosf(x)
@@ -41,11 +42,14 @@
 #  define M_LDEXP_DN(x, l) ldexpf((x), -(l))
 #  define M_LDEXP_UP(x, l) ldexpf((x), (l))
 #  define M_FLOOR(x) floorf(x)
+#  define M_EXPM1(x) expm1f(x)
+#  define M_POW15(x) powf((x), 1.5f)
 static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
 #else
 #  include "../soc_amd/csrc/soc_math.h"
 #  define M_EXP(x)   soc_expf(x)
 #  define M_LOG(x)   soc_logf(x)
+#  define M_LOGD(x)  soc_logd(x)
 #  define M_SIN(x)   soc_sinf(x)
 #  define M_COS(x)   soc_cosf(x)
 #  define M_ACOS(x)  soc_acosf(x)
@@ -55,6 +59,8 @@ static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = co
 #  define M_LDEXP_DN(x, l) soc_scale_down((x), (l))
 #  define M_LDEXP_UP(x, l) soc_scale_up((x), (l))
 #  define M_FLOOR(x) soc_floorf(x)
+#  define M_EXPM1(x) soc_expm1f(x)
+#  define M_POW15(x) soc_pow15f(x)
 static inline void M_SINCOS(float x, float *s, float *c) { soc_sincosf(x, s, c); }
 #endif
 
@@ -90,7 +96,23 @@ typedef struct {
     const float *EMIT, *EMWEI;
     float *TABS, *INT;
     int   threaded;                   /* !=0: tallies use atomic adds (OpenMP build)      */
+    /* scattered-light kernels (kernel_ASOC_sca.c): observers and image buffer */
+    int   NDIR, NPIX_X, NPIX_Y, FFS;
+    float MAP_DX, CX, CY, CZ;         /* CENTRE                                           */
+    const float *ODIRS, *ORA, *ODE;   /* 4 floats per direction (OpenCL float3)           */
+    const float *DSC;                 /* [BINS] discrete scattering function              */
+    float *OUT;                       /* [NDIR*NPIX_Y*NPIX_X]                             */
+    int   XPS_AS_FLOAT;               /* sca kernels declare XPS_NSIDE/XPS_SIDE as float* */
 } orc_model;
+
+/* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
+ * the host uploads int32 arrays (ASOCS.py:267-268, AnalyseExternalPointSources): the kernel
+ * sees the integer bit patterns as (denormal) floats.  Restated as compiled. */
+static inline float xps_value(const orc_model *M, const int *a, int i)
+{
+    if (M->XPS_AS_FLOAT) { union { int i; float f; } v;  v.i = a[i];  return v.f; }
+    return (float)a[i];
+}
 
 /* ================================ RNG ================================================== */
 
@@ -407,25 +429,16 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
 
 /* ================================ SimRAM_PB ============================================ */
 
-/* One work item of SimRAM_PB (kernel_ASOC.c:15-824).  Returns tally events. */
-static long sim_pb_workitem(const orc_model *M, int id)
+/* surface element of a background work item (kernel_ASOC.c:109-138) */
+typedef struct { int SIDE; float X0, Y0, Z0, DX, DY, DZ; } surf_t;
+
+static void pb_surface_element(const orc_model *M, int id, surf_t *E)
 {
     const int NX = M->NX, NY = M->NY, NZ = M->NZ;
     const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
-    const int SOURCE = M->SOURCE, BATCH = M->BATCH, NO_PS = M->NO_PS;
-    int   oind = 0, level = 0, SIDE = 0;
-    float phi, cos_theta, sin_theta;
-    f3    DIR = {0.0f, 0.0f, 0.0f}, POS = {0.0f, 0.0f, 0.0f};
-    float PHOTONS = 0.0f, X0 = 0, Y0 = 0, Z0 = 0, DX = 0, DY = 0, DZ = 0, v1, v2;
-    rng_t rng;
-    long  nt = 0;
-    int   ind = -1, level0;
-
-    seed_workitem(&rng, M->SEED, (uint64_t)id);
-
-    if ((SOURCE == 1) && (id >= (8 * AREA))) return 0;
-    if (SOURCE == 3) return 0;
-
+    const int SOURCE = M->SOURCE;
+    int   ind, SIDE = 0;
+    float X0 = 0, Y0 = 0, Z0 = 0, DX = 0, DY = 0, DZ = 0;
     if (SOURCE == 1) {
         ind = id % AREA;
         DX = 1.0f; DY = 1.0f; DZ = 1.0f;
@@ -457,137 +470,170 @@ static long sim_pb_workitem(const orc_model *M, int id)
         }
     }
 
-    for (int III = 0; III < BATCH; III++) {
-        if (SOURCE == 0) {
-            phi       = TWOPI * Rand(&rng);
-            cos_theta = 0.999997f - 1.999995f * Rand(&rng);
-            sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
-            DIR.x = sin_theta * M_COS(phi);
-            DIR.y = sin_theta * M_SIN(phi);
-            DIR.z = cos_theta;
-            level0  = III % NO_PS;
-            PHOTONS = M->PS[level0];
-            f3 SRC = { M->PSPOS[4 * level0], M->PSPOS[4 * level0 + 1], M->PSPOS[4 * level0 + 2] };
-            POS = SRC;
-            IndexG(M, &POS, &level, &ind);
-            if ((ind < 0) || (ind >= M->CELLS)) {
-                if (M->PS_METHOD == 0) {
-                    Surface(M, &POS, &DIR);
-                    IndexG(M, &POS, &level, &ind);
-                }
-                if (M->PS_METHOD == 1) {
-                    POS = SRC;
-                    if (POS.z > NZ) {
-                        if (DIR.z > 0.0f) DIR.z = -DIR.z;
+    E->SIDE = SIDE;  E->X0 = X0;  E->Y0 = Y0;  E->Z0 = Z0;  E->DX = DX;  E->DY = DY;  E->DZ = DZ;
+}
+
+/* creation of packet III of a SimRAM_PB work item: point sources (kernel_ASOC.c:202-434) or
+ * background (kernel_ASOC.c:439-464); identical in kernel_ASOC_sca.c:640-836 */
+static void pb_create(const orc_model *M, const surf_t *E, int III, rng_t *rng, f3 *pPOS, f3 *pDIR, float *pPHOTONS,
+                      int *plevel, int *pind)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const int SOURCE = M->SOURCE, NO_PS = M->NO_PS;
+    const int SIDE = E->SIDE;
+    const float X0 = E->X0, Y0 = E->Y0, Z0 = E->Z0, DX = E->DX, DY = E->DY, DZ = E->DZ;
+    f3    POS = *pPOS, DIR = *pDIR;
+    float PHOTONS = *pPHOTONS, phi, cos_theta, sin_theta, v1, v2;
+    int   level = *plevel, ind = *pind, oind = 0, level0;
+    if (SOURCE == 0) {
+        phi       = TWOPI * Rand(rng);
+        cos_theta = 0.999997f - 1.999995f * Rand(rng);
+        sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+        DIR.x = sin_theta * M_COS(phi);
+        DIR.y = sin_theta * M_SIN(phi);
+        DIR.z = cos_theta;
+        level0  = III % NO_PS;
+        PHOTONS = M->PS[level0];
+        f3 SRC = { M->PSPOS[4 * level0], M->PSPOS[4 * level0 + 1], M->PSPOS[4 * level0 + 2] };
+        POS = SRC;
+        IndexG(M, &POS, &level, &ind);
+        if ((ind < 0) || (ind >= M->CELLS)) {
+            if (M->PS_METHOD == 0) {
+                Surface(M, &POS, &DIR);
+                IndexG(M, &POS, &level, &ind);
+            }
+            if (M->PS_METHOD == 1) {
+                POS = SRC;
+                if (POS.z > NZ) {
+                    if (DIR.z > 0.0f) DIR.z = -DIR.z;
+                } else {
+                    if (POS.z < 0.0f) {
+                        if (DIR.z < 0.0f) DIR.z = -DIR.z;
                     } else {
-                        if (POS.z < 0.0f) {
-                            if (DIR.z < 0.0f) DIR.z = -DIR.z;
+                        if (POS.x > NX) {
+                            if (DIR.x > 0.0f) DIR.x = -DIR.x;
                         } else {
-                            if (POS.x > NX) {
-                                if (DIR.x > 0.0f) DIR.x = -DIR.x;
+                            if (POS.x < 0.0f) {
+                                if (DIR.x < 0.0f) DIR.x = -DIR.x;
                             } else {
-                                if (POS.x < 0.0f) {
-                                    if (DIR.x < 0.0f) DIR.x = -DIR.x;
+                                if (POS.y > NY) {
+                                    if (DIR.y > 0.0f) DIR.y = -DIR.y;
                                 } else {
-                                    if (POS.y > NY) {
-                                        if (DIR.y > 0.0f) DIR.y = -DIR.y;
-                                    } else {
-                                        if (POS.y < 0.0f) {
-                                            if (DIR.y < 0.0f) DIR.y = -DIR.y;
-                                        }
+                                    if (POS.y < 0.0f) {
+                                        if (DIR.y < 0.0f) DIR.y = -DIR.y;
                                     }
                                 }
                             }
                         }
                     }
-                    Surface(M, &POS, &DIR);
-                    PHOTONS *= 0.5f;
-                    IndexG(M, &POS, &level, &ind);
                 }
-                if (M->PS_METHOD == 2) {
-                    POS = SRC;
-                    ind = M_FLOOR(Rand(&rng) * M->XPS_NSIDE[level0] * 0.999999f);
-                    PHOTONS /= M->XPS_AREA[3 * level0 + ind];
-                    ind = M->XPS_SIDE[3 * level0 + ind];
-                    float a = Rand(&rng), b = Rand(&rng);
-                    if (ind == 0) { POS.x = NX - PEPS;  POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
-                    if (ind == 1) { POS.x = PEPS;       POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
-                    if (ind == 2) { POS.y = NY - PEPS;  POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
-                    if (ind == 3) { POS.y = PEPS;       POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
-                    if (ind == 4) { POS.z = NZ - PEPS;  POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
-                    if (ind == 5) { POS.z = PEPS;       POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
-                    DIR.x = POS.x - SRC.x;  DIR.y = POS.y - SRC.y;  DIR.z = POS.z - SRC.z;
-                    v1 = M_SQRT(DIR.x * DIR.x + DIR.y * DIR.y + DIR.z * DIR.z);   /* distance() */
-                    normalize3(&DIR);
-                    v2 = (ind < 2) ? (fabsf(DIR.x)) : ((ind < 4) ? (fabsf(DIR.y)) : (fabsf(DIR.z)));
-                    PHOTONS *= v2 * b / (4.0f * PI_F * v1 * v1);
-                    IndexG(M, &POS, &level, &ind);
-                }
-                if (M->PS_METHOD == 4) {
-                    v1 = SRC.z - NZ;
-                    cos_theta = v1 / M_SQRT(v1 * v1 + 0.25f * NX * NX + 0.25f * NY * NY);
-                    PHOTONS *= 0.5f * (1.0f - cos_theta);
-                    cos_theta = 1.0f - Rand(&rng) * (1.0f - cos_theta);
-                    v1 = TWOPI * Rand(&rng);
-                    DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
-                    DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
-                    DIR.z = -cos_theta;
-                    Surface(M, &POS, &DIR);
-                    IndexG(M, &POS, &level, &ind);
-                }
-                if (M->PS_METHOD == 5) {
-                    cos_theta = M->XPS_AREA[3 * level0];
-                    PHOTONS *= 0.5f * (1.0f - cos_theta);
-                    cos_theta = 1.0f - Rand(&rng) * (1.0f - cos_theta);
-                    v1   = TWOPI * Rand(&rng);
-                    oind = M->XPS_SIDE[3 * level0];
-                    if (oind < 2) {
-                        DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                Surface(M, &POS, &DIR);
+                PHOTONS *= 0.5f;
+                IndexG(M, &POS, &level, &ind);
+            }
+            if (M->PS_METHOD == 2) {
+                POS = SRC;
+                ind = M_FLOOR(Rand(rng) * xps_value(M, M->XPS_NSIDE, level0) * 0.999999f);
+                PHOTONS /= M->XPS_AREA[3 * level0 + ind];
+                ind = (int)xps_value(M, M->XPS_SIDE, 3 * level0 + ind);
+                float a = Rand(rng), b = Rand(rng);
+                if (ind == 0) { POS.x = NX - PEPS;  POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
+                if (ind == 1) { POS.x = PEPS;       POS.y = a * NY;  POS.z = b * NZ;  b = NY * NZ; }
+                if (ind == 2) { POS.y = NY - PEPS;  POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
+                if (ind == 3) { POS.y = PEPS;       POS.x = a * NX;  POS.z = b * NZ;  b = NX * NZ; }
+                if (ind == 4) { POS.z = NZ - PEPS;  POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
+                if (ind == 5) { POS.z = PEPS;       POS.x = a * NX;  POS.y = b * NY;  b = NX * NY; }
+                DIR.x = POS.x - SRC.x;  DIR.y = POS.y - SRC.y;  DIR.z = POS.z - SRC.z;
+                v1 = M_SQRT(DIR.x * DIR.x + DIR.y * DIR.y + DIR.z * DIR.z);   /* distance() */
+                normalize3(&DIR);
+                v2 = (ind < 2) ? (fabsf(DIR.x)) : ((ind < 4) ? (fabsf(DIR.y)) : (fabsf(DIR.z)));
+                PHOTONS *= v2 * b / (4.0f * PI_F * v1 * v1);
+                IndexG(M, &POS, &level, &ind);
+            }
+            if (M->PS_METHOD == 4) {
+                v1 = SRC.z - NZ;
+                cos_theta = v1 / M_SQRT(v1 * v1 + 0.25f * NX * NX + 0.25f * NY * NY);
+                PHOTONS *= 0.5f * (1.0f - cos_theta);
+                cos_theta = 1.0f - Rand(rng) * (1.0f - cos_theta);
+                v1 = TWOPI * Rand(rng);
+                DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                DIR.z = -cos_theta;
+                Surface(M, &POS, &DIR);
+                IndexG(M, &POS, &level, &ind);
+            }
+            if (M->PS_METHOD == 5) {
+                cos_theta = M->XPS_AREA[3 * level0];
+                PHOTONS *= 0.5f * (1.0f - cos_theta);
+                cos_theta = 1.0f - Rand(rng) * (1.0f - cos_theta);
+                v1   = TWOPI * Rand(rng);
+                oind = (int)xps_value(M, M->XPS_SIDE, 3 * level0);
+                if (oind < 2) {
+                    DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                    DIR.z = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                    if (oind == 0) DIR.x = -cos_theta;
+                    else           DIR.x = +cos_theta;
+                } else {
+                    if (oind < 4) {
+                        DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
                         DIR.z = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
-                        if (oind == 0) DIR.x = -cos_theta;
-                        else           DIR.x = +cos_theta;
+                        if (oind == 2) DIR.y = -cos_theta;
+                        else           DIR.y = +cos_theta;
                     } else {
-                        if (oind < 4) {
-                            DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
-                            DIR.z = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
-                            if (oind == 2) DIR.y = -cos_theta;
-                            else           DIR.y = +cos_theta;
-                        } else {
-                            DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
-                            DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
-                            if (oind == 4) DIR.z = -cos_theta;
-                            else           DIR.z = +cos_theta;
-                        }
+                        DIR.x = M_SQRT(1.0f - cos_theta * cos_theta) * M_COS(v1);
+                        DIR.y = M_SQRT(1.0f - cos_theta * cos_theta) * M_SIN(v1);
+                        if (oind == 4) DIR.z = -cos_theta;
+                        else           DIR.z = +cos_theta;
                     }
-                    Surface(M, &POS, &DIR);
-                    IndexG(M, &POS, &level, &ind);
                 }
+                Surface(M, &POS, &DIR);
+                IndexG(M, &POS, &level, &ind);
             }
         }
-        if (SOURCE == 1) {
-            POS.x = clampf(X0 + DX * Rand(&rng), PEPS, NX - PEPS);
-            POS.y = clampf(Y0 + DY * Rand(&rng), PEPS, NY - PEPS);
-            POS.z = clampf(Z0 + DZ * Rand(&rng), PEPS, NZ - PEPS);
-            cos_theta = M_SQRT(Rand(&rng));
-            phi       = TWOPI * Rand(&rng);
-            sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
-            v1 = sin_theta * M_COS(phi);
-            v2 = sin_theta * M_SIN(phi);
-            switch (SIDE) {
-            case 0: DIR.x =  cos_theta; DIR.y = v1; DIR.z = v2; break;
-            case 1: DIR.x = -cos_theta; DIR.y = v1; DIR.z = v2; break;
-            case 2: DIR.y =  cos_theta; DIR.x = v1; DIR.z = v2; break;
-            case 3: DIR.y = -cos_theta; DIR.x = v1; DIR.z = v2; break;
-            case 4: DIR.z =  cos_theta; DIR.x = v1; DIR.y = v2; break;
-            case 5: DIR.z = -cos_theta; DIR.x = v1; DIR.y = v2; break;
-            }
-            PHOTONS = M->BG;
-            IndexG(M, &POS, &level, &ind);
+    }
+    if (SOURCE == 1) {
+        POS.x = clampf(X0 + DX * Rand(rng), PEPS, NX - PEPS);
+        POS.y = clampf(Y0 + DY * Rand(rng), PEPS, NY - PEPS);
+        POS.z = clampf(Z0 + DZ * Rand(rng), PEPS, NZ - PEPS);
+        cos_theta = M_SQRT(Rand(rng));
+        phi       = TWOPI * Rand(rng);
+        sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+        v1 = sin_theta * M_COS(phi);
+        v2 = sin_theta * M_SIN(phi);
+        switch (SIDE) {
+        case 0: DIR.x =  cos_theta; DIR.y = v1; DIR.z = v2; break;
+        case 1: DIR.x = -cos_theta; DIR.y = v1; DIR.z = v2; break;
+        case 2: DIR.y =  cos_theta; DIR.x = v1; DIR.z = v2; break;
+        case 3: DIR.y = -cos_theta; DIR.x = v1; DIR.z = v2; break;
+        case 4: DIR.z =  cos_theta; DIR.x = v1; DIR.y = v2; break;
+        case 5: DIR.z = -cos_theta; DIR.x = v1; DIR.y = v2; break;
         }
+        PHOTONS = M->BG;
+        IndexG(M, &POS, &level, &ind);
+    }
+    *pPOS = POS;  *pDIR = DIR;  *pPHOTONS = PHOTONS;  *plevel = level;  *pind = ind;
+}
+
+/* One work item of SimRAM_PB (kernel_ASOC.c:15-824).  Returns tally events. */
+static long sim_pb_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
+    const int SOURCE = M->SOURCE, BATCH = M->BATCH;
+    int   level = 0, ind = -1;
+    f3    DIR = {0.0f, 0.0f, 0.0f}, POS = {0.0f, 0.0f, 0.0f};
+    float PHOTONS = 0.0f;
+    rng_t rng;
+    surf_t E;
+    long  nt = 0;
+
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    if ((SOURCE == 1) && (id >= (8 * AREA))) return 0;
+    if (SOURCE == 3) return 0;
+    pb_surface_element(M, id, &E);
+    for (int III = 0; III < BATCH; III++) {
+        pb_create(M, &E, III, &rng, &POS, &DIR, &PHOTONS, &level, &ind);
         nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0);
-        /* NOTE: in the reference ind/level persist across III; walk_packet leaves ind<0 or
-           consumed, and every branch above overwrites (level, ind) through IndexG before
-           use, so carrying them is unnecessary. */
         ind = -1;
     }
     return nt;
@@ -663,6 +709,212 @@ static long sim_cl_workitem(const orc_model *M, int id)
         DIR.y = sin_theta * M_SIN(phi);
         DIR.z = cos_theta;
         nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 1);
+    }
+}
+
+/* ================================ scattered light: kernel_ASOC_sca.c ==================== */
+
+#define MAX_SCATTERINGS 30            /* kernel_ASOC_sca.c:5 */
+
+static inline void out_add(const orc_model *M, int i, float v)
+{
+    if (M->threaded) {
+#pragma omp atomic
+        M->OUT[i] += v;
+    } else {
+        M->OUT[i] += v;
+    }
+}
+
+/* Everything after packet creation in the sca kernels: forced first scattering
+ * (kernel_ASOC_sca.c:888-910 / 1232-1258), the tau-only walk (:922-946), the scattering
+ * block with peel-off towards NDIR observers (:951-1047) and the new direction (:1056-1080).
+ * variant 0 = SimRAM_PB; 1 = SimRAM_CL: no random draw when nothing lies along the line of
+ * sight (:1249-1252) and a +-0.9999 clamp of cos(theta) (:1349); 2 = SimRAM_PS: the forced
+ * first free path is evaluated in fp32, -log(1.0f - W*u) (:1742), where PB/CL promote to
+ * double through the literal 1.0 (:906, :1256).
+ * Returns the number of peel-off contributions added to OUT. */
+static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS, int level, int ind, int variant)
+{
+    const int is_cl = (variant == 1);
+    const float *DENS = M->DENS;
+    const int *OFF = M->OFF;
+    const float ABS = M->ABS, SCA = M->SCA;
+    const float CLAMP = is_cl ? 0.9999f : 0.999f;
+    int   oind = 0, ind0 = -1, level0 = 0, scatterings, i, j;
+    float ds, free_path, tau, dtau, delta, dx, cos_theta, W;
+    f3    POS0, ODIR;
+    long  nadd = 0;
+
+    if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+    if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+    if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+    normalize3(&DIR);
+    if (M->FFS > 0) {
+        POS0 = POS;  ind0 = ind;  level0 = level;
+        tau = 0.0f;
+        while (ind0 >= 0) {
+            oind = OFF[level0] + ind0;
+            ds   = GetStep(M, &POS0, &DIR, &level0, &ind0);
+            if (M->WITH_ABU) tau += ds * DENS[oind] * M->OPT[2 * (long)oind + 1];
+            else             tau += ds * DENS[oind] * SCA;
+        }
+        if (tau < 1.0e-22f) {
+            ind = -1;
+            if (is_cl) return 0;
+        }
+        if (variant == 2) {
+            W = -M_EXPM1(-tau);
+            free_path = -M_LOG(1.0f - W * Rand(rng));
+        } else {
+            W = 1.0f - M_EXP(-tau);
+            free_path = -M_LOGD(1.0 - W * Rand(rng));
+        }
+        PHOTONS *= W;
+    } else {
+        free_path = -M_LOG(Rand(rng));
+    }
+    scatterings = 0;
+    while (ind >= 0) {
+        tau = 0.0f;
+        while (ind >= 0) {
+            ind0 = ind;  level0 = level;  POS0 = POS;
+            oind = OFF[level0] + ind0;
+            ds   = GetStep(M, &POS, &DIR, &level, &ind);
+            if (M->WITH_ABU) dtau = ds * DENS[oind] * M->OPT[2 * (long)oind + 1];
+            else             dtau = ds * DENS[oind] * SCA;
+            if (free_path < (tau + dtau)) {
+                ind = ind0;                       /* level keeps its post-step value: reference quirk */
+                break;
+            }
+            tau += dtau;
+        }
+        if (ind < 0) break;
+        scatterings++;
+        dtau = free_path - tau;
+        if (M->WITH_ABU) dx = dtau / (M->OPT[2 * (long)oind + 1] * DENS[oind]);
+        else             dx = dtau / (SCA * DENS[oind]);
+        dx = M_LDEXP_UP(dx, level);
+        POS0.x = POS0.x + dx * DIR.x;
+        POS0.y = POS0.y + dx * DIR.y;
+        POS0.z = POS0.z + dx * DIR.z;
+        if (M->WITH_ABU) PHOTONS *= M_EXP(-free_path * M->OPT[2 * (long)oind] / M->OPT[2 * (long)oind + 1]);
+        else             PHOTONS *= M_EXP(-free_path * ABS / SCA);
+        for (int idir = 0; idir < M->NDIR; idir++) {
+            POS = POS0;  ind = ind0;  level = level0;
+            tau = 0.0f;
+            ODIR.x = M->ODIRS[4 * idir];  ODIR.y = M->ODIRS[4 * idir + 1];  ODIR.z = M->ODIRS[4 * idir + 2];
+            while (ind >= 0) {
+                oind = OFF[level] + ind;
+                ds   = GetStep(M, &POS, &ODIR, &level, &ind);
+                if (M->WITH_ABU) tau += ds * DENS[oind] * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
+                else             tau += ds * DENS[oind] * (ABS + SCA);
+            }
+            cos_theta = clampf(DIR.x * ODIR.x + DIR.y * ODIR.y + DIR.z * ODIR.z, -CLAMP, +CLAMP);
+            if (is_cl) {
+                /* kernel_ASOC_aux.c:1 has "#define HG_TEST 0" and SimRAM_CL tests "#ifdef HG_TEST"
+                 * (:1387): the reference as shipped takes the analytic branch -- Henyey-Greenstein
+                 * with g=0.65 and the factor (1-exp(-tau)) [tau>TAULIM] or tau*(1-tau/2) -- and
+                 * never reads DSC.  Restated as compiled. */
+                const float G = 0.65f;
+                const float fraction = (1.0f / (4.0f * PI_F)) * (1.0f - G * G) / M_POW15(1.0f + G * G - 2.0f * G * cos_theta);
+                delta = PHOTONS * fraction * ((tau > TAULIM) ? (1.0f - M_EXP(-tau)) : (tau * (1.0f - 0.5f * tau)));
+            } else {
+                delta = PHOTONS * M_EXP(-tau) * M->DSC[clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
+            }
+            POS.x -= M->CX;  POS.y -= M->CY;  POS.z -= M->CZ;
+            i = (0.5f * M->NPIX_X - 0.00005f) + (POS.x * M->ORA[4 * idir] + POS.y * M->ORA[4 * idir + 1] + POS.z * M->ORA[4 * idir + 2]) / M->MAP_DX;
+            j = (0.5f * M->NPIX_Y - 0.00005f) + (POS.x * M->ODE[4 * idir] + POS.y * M->ODE[4 * idir + 1] + POS.z * M->ODE[4 * idir + 2]) / M->MAP_DX;
+            if ((i >= 0) && (j >= 0) && (i < M->NPIX_X) && (j < M->NPIX_Y)) {
+                i += idir * M->NPIX_X * M->NPIX_Y + j * M->NPIX_X;
+                out_add(M, i, delta);
+                nadd++;
+            }
+        }
+        POS = POS0;  ind = ind0;  level = level0;
+        Scatter(&DIR, M->CSC, M->BINS, rng);
+        free_path = -M_LOG(Rand(rng));
+        if (scatterings == MAX_SCATTERINGS) { ind = -1; continue; }
+    }
+    return nadd;
+}
+
+/* One work item of the sca SimRAM_PB (kernel_ASOC_sca.c:471-1094); SimRAM_PS (:1462-1938) is
+ * its SOURCE==0 path with the launch arguments of ASOCS.py:655-665. */
+static long sim_sca_pb_workitem(const orc_model *M, int id, int variant)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
+    int   level = 0, ind = -1;
+    f3    DIR = {0.0f, 0.0f, 0.0f}, POS = {0.0f, 0.0f, 0.0f};
+    float PHOTONS = 0.0f;
+    rng_t rng;
+    surf_t E;
+    long  n = 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    if ((M->SOURCE == 1) && (id >= (8 * AREA))) return 0;
+    pb_surface_element(M, id, &E);
+    for (int III = 0; III < M->BATCH; III++) {
+        pb_create(M, &E, III, &rng, &POS, &DIR, &PHOTONS, &level, &ind);
+        n += walk_packet_sca(M, &rng, POS, DIR, PHOTONS, level, ind, variant);
+        ind = -1;
+    }
+    return n;
+}
+
+/* One work item of the sca SimRAM_CL (kernel_ASOC_sca.c:1098-1461) */
+static long sim_sca_cl_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, CELLS = M->CELLS, GLOBAL = M->GLOBAL, LEVELS = M->LEVELS;
+    const int *LCELLS = M->LCELLS, *OFF = M->OFF;
+    int   level = 0, batch = -1, ICELL = id - GLOBAL, IRAY = 0, ind;
+    float phi, cos_theta, sin_theta, PHOTONS, X0, Y0, Z0, PWEI = 1.0f;
+    f3    DIR, POS;
+    rng_t rng;
+    long  n = 0;
+    if (id >= CELLS) return 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    while (1) {
+        if (IRAY >= batch) {
+            IRAY = 0;
+            PWEI = 1.0f;
+            while (1) {
+                ICELL += GLOBAL;
+                if (ICELL >= CELLS) return n;
+                if (M->USE_EMWEIGHT > 0) {
+                    PWEI = M->EMWEI[ICELL];
+                    if ((PWEI < 1e-10f) || (M->DENS[ICELL] <= 0.0f)) continue;
+                    batch = (int)M_FLOOR(PWEI);
+                    if (batch < 1) { batch = 1;  PWEI = 1.0 / (PWEI + 1.0e-30f); }
+                    else           { PWEI = 1.0 / (batch + 1.0e-9f); }
+                } else {
+                    batch = M->BATCH;
+                    PWEI = 1.0f / (batch + 1.0e-9f);
+                }
+                break;
+            }
+        }
+        ind = ICELL;
+        IRAY += 1;
+        for (level = 0; level < LEVELS - 1; level++) {
+            ind -= LCELLS[level];
+            if (ind < 0) { ind += LCELLS[level]; break; }
+        }
+        if (level == 0) {
+            X0 = (ind % NX);  Y0 = ((ind / NX) % NY);  Z0 = (ind / (NX * NY));
+        } else {
+            int sid = ind % 8;
+            X0 = (sid % 2);  Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;  Z0 = (sid / 4);
+        }
+        PHOTONS = M->EMIT[OFF[level] + ind] * PWEI;
+        POS.x = X0 + Rand(&rng);  POS.y = Y0 + Rand(&rng);  POS.z = Z0 + Rand(&rng);
+        phi       = TWOPI * Rand(&rng);
+        cos_theta = 0.999997f - 1.999995f * Rand(&rng);
+        sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+        DIR.x = sin_theta * M_COS(phi);
+        DIR.y = sin_theta * M_SIN(phi);
+        DIR.z = cos_theta;
+        n += walk_packet_sca(M, &rng, POS, DIR, PHOTONS, level, ind, 1);
     }
 }
 
@@ -783,6 +1035,28 @@ EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int stride, int 
     return total;
 }
 
+/* scattered-light kernels: work items gid0, gid0+stride, ... of the sca SimRAM_PB (kind 0),
+ * SimRAM_CL (kind 1) or SimRAM_PS (kind 2, needs SOURCE == 0); returns the number of image contributions */
+EXPORT long orc_sim_sca(orc_model *M, int kind, int gid0, int gid1, int stride, int nthreads)
+{
+    long total = 0;
+    if (stride < 1) stride = 1;
+    if (nthreads <= 1) {
+        M->threaded = 0;
+        for (int id = gid0; id < gid1; id += stride)
+            total += (kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind);
+    } else {
+        M->threaded = 1;
+        const long n = ((long)gid1 - gid0 + stride - 1) / stride;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
+        for (long k = 0; k < n; k++) {
+            int id = (int)(gid0 + k * stride);
+            total += (kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind);
+        }
+    }
+    return total;
+}
+
 /* math probes for tests/test_math.py */
 EXPORT void orc_math_eval(int fn, const float *x, float *y, long n)
 {
@@ -795,6 +1069,9 @@ EXPORT void orc_math_eval(int fn, const float *x, float *y, long n)
         case 4: y[i] = M_ACOS(x[i]); break;
         case 5: y[i] = M_SQRT(x[i]); break;
         case 6: y[i] = M_FMOD1(x[i]); break;
+        case 8: y[i] = M_EXPM1(x[i]); break;
+        case 9: y[i] = M_POW15(x[i]); break;
+        case 10: y[i] = (float)M_LOGD((double)x[i]); break;
         default: y[i] = 0.0f;
         }
     }

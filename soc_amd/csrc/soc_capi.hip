@@ -26,6 +26,12 @@ struct soc_ctx {
     // tables / per-frequency data
     float *dCSC = nullptr, *dDSC = nullptr;
     int    BINS = 0;
+    bool   have_dsc = false;
+    // scattered-light view (soc_sca_*)
+    SocSca view{};
+    float4 *dODIR = nullptr, *dORA = nullptr, *dODE = nullptr;
+    float  *dOUT = nullptr;
+    bool    own_OUT = false, have_view = false;
     float  ABS = 0.0f, SCA = 0.0f;
     bool   have_optical = false;
     float2 *dOPT = nullptr;
@@ -128,11 +134,12 @@ void soc_destroy(soc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dPSPOS, c->dPS,
-                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats,
+                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
     if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
+    if (c->own_OUT && c->dOUT) (void)hipFree(c->dOUT);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     soc_brick_release(c->device);
@@ -268,7 +275,9 @@ int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BI
         HIPCHK(c, dev_alloc(&c->dCSC, (size_t)BINS));
         HIPCHK(c, dev_alloc(&c->dDSC, (size_t)BINS));
         c->BINS = BINS;
+        c->have_dsc = false;
     }
+    if (DSC) c->have_dsc = true;
     HIPCHK(c, hipMemcpyAsync(c->dCSC, CSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
     if (DSC) HIPCHK(c, hipMemcpyAsync(c->dDSC, DSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffer may be reused by the caller
@@ -342,6 +351,54 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     V.wint = c->with_int;
 }
 
+// Point sources of one launch -> device.  xps_as_float: the scattered-light kernels declare
+// XPS_NSIDE and XPS_SIDE as "__global float *" (kernel_ASOC_sca.c:495-496, :1486-1487) while
+// ASOCS.py uploads the int32 arrays of AnalyseExternalPointSources (ASOCS.py:267-268), so the
+// reference reads the integer bit patterns as floats: floor(u*asfloat(nside)*0.999999f) and
+// (int)asfloat(side).  The values the reference kernel ends up with are computed here.
+static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *PSPOS, const float *PS, int NO_PS,
+                          const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA, bool xps_as_float)
+{
+    if (NO_PS < 1 || !PSPOS || !PS) return fail(c, SOC_ERR_ARG, "%s: point sources need PSPOS, PS and NO_PS>=1", who);
+    if ((c->ps_method == 2 || c->ps_method == 5) && (!XPS_NSIDE || !XPS_SIDE || !XPS_AREA))
+        return fail(c, SOC_ERR_ARG, "%s: PS_METHOD %d needs XPS_NSIDE/XPS_SIDE/XPS_AREA", who, c->ps_method);
+    std::vector<int32_t> nside((size_t)NO_PS, 0), side((size_t)3 * NO_PS, 0);
+    if (XPS_NSIDE) nside.assign(XPS_NSIDE, XPS_NSIDE + NO_PS);
+    if (XPS_SIDE)  side.assign(XPS_SIDE, XPS_SIDE + 3 * NO_PS);
+    if (c->ps_method == 2) {
+        for (int i = 0; i < NO_PS; i++) {
+            if (nside[i] < 0 || nside[i] > 3) return fail(c, SOC_ERR_ARG, "%s: XPS_NSIDE[%d]=%d", who, i, nside[i]);
+            for (int k = 0; k < 3; k++)
+                if (side[3 * i + k] < 0 || side[3 * i + k] > 5) return fail(c, SOC_ERR_ARG, "%s: XPS_SIDE[%d]=%d", who, 3 * i + k, side[3 * i + k]);
+        }
+    }
+    if (xps_as_float) {
+        // 0 <= v <= 5 as a float bit pattern is a denormal: u*v*0.999999f < 1 and (int)v == 0
+        for (auto &v : nside) { float f;  memcpy(&f, &v, 4);  v = (f * 0.999999f < 1.0f) ? 0 : (int32_t)f; }
+        for (auto &v : side)  { float f;  memcpy(&f, &v, 4);  v = (int32_t)f; }
+    }
+    if (NO_PS > c->ps_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dPSPOS, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&c->dPS, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&c->dXPS_NSIDE, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&c->dXPS_SIDE, (size_t)3 * NO_PS));
+        HIPCHK(c, dev_alloc(&c->dXPS_AREA, (size_t)3 * NO_PS));
+        c->ps_cap = NO_PS;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dPSPOS, PSPOS, (size_t)NO_PS * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dPS, PS, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dXPS_NSIDE, nside.data(), (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dXPS_SIDE, side.data(), (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+    if (XPS_AREA)  HIPCHK(c, hipMemcpyAsync(c->dXPS_AREA, XPS_AREA, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+    else           HIPCHK(c, hipMemsetAsync(c->dXPS_AREA, 0, (size_t)NO_PS * 12, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    S.NO_PS = NO_PS;
+    S.PSPOS = c->dPSPOS; S.PS = c->dPS;
+    S.XPS_NSIDE = c->dXPS_NSIDE; S.XPS_SIDE = c->dXPS_SIDE; S.XPS_AREA = c->dXPS_AREA;
+    return SOC_OK;
+}
+
 int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
                const float *PSPOS, const float *PS, int NO_PS,
                const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
@@ -357,37 +414,8 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
     if (SOURCE == 0) {
-        if (NO_PS < 1 || !PSPOS || !PS) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE=0 needs PSPOS, PS and NO_PS>=1");
-        if ((c->ps_method == 2 || c->ps_method == 5) && (!XPS_NSIDE || !XPS_SIDE || !XPS_AREA))
-            return fail(c, SOC_ERR_ARG, "soc_sim_pb: PS_METHOD %d needs XPS_NSIDE/XPS_SIDE/XPS_AREA", c->ps_method);
-        if (c->ps_method == 2) {
-            for (int i = 0; i < NO_PS; i++) {
-                if (XPS_NSIDE[i] < 0 || XPS_NSIDE[i] > 3) return fail(c, SOC_ERR_ARG, "soc_sim_pb: XPS_NSIDE[%d]=%d", i, XPS_NSIDE[i]);
-                for (int k = 0; k < 3; k++)
-                    if (XPS_SIDE[3 * i + k] < 0 || XPS_SIDE[3 * i + k] > 5) return fail(c, SOC_ERR_ARG, "soc_sim_pb: XPS_SIDE[%d]=%d", 3 * i + k, XPS_SIDE[3 * i + k]);
-            }
-        }
-        if (NO_PS > c->ps_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, dev_alloc(&c->dPSPOS, (size_t)NO_PS));
-            HIPCHK(c, dev_alloc(&c->dPS, (size_t)NO_PS));
-            HIPCHK(c, dev_alloc(&c->dXPS_NSIDE, (size_t)NO_PS));
-            HIPCHK(c, dev_alloc(&c->dXPS_SIDE, (size_t)3 * NO_PS));
-            HIPCHK(c, dev_alloc(&c->dXPS_AREA, (size_t)3 * NO_PS));
-            c->ps_cap = NO_PS;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->dPSPOS, PSPOS, (size_t)NO_PS * 16, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->dPS, PS, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
-        if (XPS_NSIDE) HIPCHK(c, hipMemcpyAsync(c->dXPS_NSIDE, XPS_NSIDE, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
-        else           HIPCHK(c, hipMemsetAsync(c->dXPS_NSIDE, 0, (size_t)NO_PS * 4, c->stream));
-        if (XPS_SIDE)  HIPCHK(c, hipMemcpyAsync(c->dXPS_SIDE, XPS_SIDE, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
-        else           HIPCHK(c, hipMemsetAsync(c->dXPS_SIDE, 0, (size_t)NO_PS * 12, c->stream));
-        if (XPS_AREA)  HIPCHK(c, hipMemcpyAsync(c->dXPS_AREA, XPS_AREA, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
-        else           HIPCHK(c, hipMemsetAsync(c->dXPS_AREA, 0, (size_t)NO_PS * 12, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        S.NO_PS = NO_PS;
-        S.PSPOS = c->dPSPOS; S.PS = c->dPS;
-        S.XPS_NSIDE = c->dXPS_NSIDE; S.XPS_SIDE = c->dXPS_SIDE; S.XPS_AREA = c->dXPS_AREA;
+        r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false);
+        if (r) return r;
     } else {
         S.NO_PS = 1;
     }
@@ -422,6 +450,160 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     fill_sim(c, S, V, SOURCE, BATCH, SEED, 0.0f, TW, GLOBAL, gid_first, gid_count);
     S.NO_PS = 1;
     HIPCHK(c, soc_launch_sim_cl(c->G, S, V, c->stream));
+    return SOC_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// scattered-light images (ASOCS.py / kernel_ASOC_sca.c)
+// ------------------------------------------------------------------------------------
+
+int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, const float *DE,
+                     int NPIX_X, int NPIX_Y, float MAP_DX, const float *CENTRE, int FFS)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (NDIR < 1 || NDIR > 4096 || !ODIR || !RA || !DE || !CENTRE)
+        return fail(c, SOC_ERR_ARG, "soc_sca_set_view: need 1 <= NDIR <= 4096 observer directions (Healpix output, NDIR<0, is not supported)");
+    if (NPIX_X < 1 || NPIX_Y < 1 || (int64_t)NDIR * NPIX_X * NPIX_Y > 2147483647LL || !(MAP_DX > 0.0f))
+        return fail(c, SOC_ERR_ARG, "soc_sca_set_view: NPIX %d x %d, MAP_DX %g", NPIX_X, NPIX_Y, (double)MAP_DX);
+    for (int i = 0; i < NDIR; i++) {
+        // GetStep divides by the components of the direction: the host makes them non-zero (ASOC_aux.py:1177-1181)
+        for (int k = 0; k < 3; k++) {
+            const float v = ODIR[4 * i + k];
+            if (!(std::fabs(v) > 0.0f) || !std::isfinite(v))
+                return fail(c, SOC_ERR_ARG, "soc_sca_set_view: ODIR[%d].%c = %g (must be finite and non-zero)", i, "xyz"[k], (double)v);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t npix = (size_t)NDIR * NPIX_X * NPIX_Y;
+    const size_t old = c->have_view ? (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y : 0;
+    if (NDIR != c->view.NDIR || !c->dODIR) {
+        HIPCHK(c, dev_alloc(&c->dODIR, (size_t)NDIR));
+        HIPCHK(c, dev_alloc(&c->dORA, (size_t)NDIR));
+        HIPCHK(c, dev_alloc(&c->dODE, (size_t)NDIR));
+    }
+    if (npix != old || !c->dOUT) {
+        if (!c->own_OUT && c->dOUT && npix != old)
+            return fail(c, SOC_ERR_STATE, "soc_sca_set_view: image size changed while a caller-owned image is bound");
+        if (c->own_OUT || !c->dOUT) {
+            c->dOUT = nullptr;
+            HIPCHK(c, dev_alloc(&c->dOUT, npix));
+            c->own_OUT = true;
+            HIPCHK(c, hipMemset(c->dOUT, 0, npix * 4));
+        }
+    }
+    HIPCHK(c, hipMemcpy(c->dODIR, ODIR, (size_t)NDIR * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dORA, RA, (size_t)NDIR * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dODE, DE, (size_t)NDIR * 16, hipMemcpyHostToDevice));
+    c->view.NDIR = NDIR;  c->view.NPIX_X = NPIX_X;  c->view.NPIX_Y = NPIX_Y;  c->view.FFS = FFS ? 1 : 0;
+    c->view.MAP_DX = MAP_DX;  c->view.CX = CENTRE[0];  c->view.CY = CENTRE[1];  c->view.CZ = CENTRE[2];
+    c->view.ODIRS = c->dODIR;  c->view.ORA = c->dORA;  c->view.ODE = c->dODE;
+    c->have_view = true;
+    return SOC_OK;
+}
+
+int soc_sca_zero(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_zero: call soc_sca_set_view first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->dOUT, 0, (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y * 4, c->stream));
+    return SOC_OK;
+}
+
+static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVariant &V)
+{
+    if (!c->have_view) return fail(c, SOC_ERR_STATE, "%s: call soc_sca_set_view first", who);
+    if (kind != SOC_SCA_CL && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
+    if (c->BINS > 8000) return fail(c, SOC_ERR_ARG, "%s: BINS=%d > 8000", who, c->BINS);
+    SocSca X = c->view;
+    X.kind = kind;
+    X.DSC = c->dDSC;
+    X.OUT = c->dOUT;
+    S.TABS = nullptr;  S.INT = nullptr;
+    HIPCHK(c, soc_launch_sca(c->G, S, X, V, c->stream));
+    return SOC_OK;
+}
+
+int soc_sca_sim_ps(soc_ctx *c, int PACKETS, int BATCH, float SEED, float BG, const float *PSPOS, const float *PS, int NO_PS,
+                   const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
+                   int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sca_sim_ps", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, 0, BATCH, SEED, BG, 0.0f, GLOBAL, gid_first, gid_count);
+    r = upload_sources(c, "soc_sca_sim_ps", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true);
+    if (r) return r;
+    return sca_launch(c, "soc_sca_sim_ps", SOC_SCA_PS, S, V);
+}
+
+int soc_sca_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, const float *PSPOS, const float *PS,
+                   int NO_PS, const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
+                   int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sca_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (SOURCE != 0 && SOURCE != 1)
+        return fail(c, SOC_ERR_ARG, "soc_sca_sim_pb: SOURCE=%d (0 point sources, 1 background; ROI_LOAD is not supported)", SOURCE);
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, 0.0f, GLOBAL, gid_first, gid_count);
+    if (SOURCE == 0) {
+        r = upload_sources(c, "soc_sca_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true);
+        if (r) return r;
+    } else {
+        S.NO_PS = 1;
+    }
+    return sca_launch(c, "soc_sca_sim_pb", SOC_SCA_PB, S, V);
+}
+
+int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;  (void)SOURCE;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sca_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sca_sim_cl: call soc_set_emission first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, 2, BATCH, SEED, 0.0f, 0.0f, GLOBAL, gid_first, gid_count);
+    S.NO_PS = 1;
+    return sca_launch(c, "soc_sca_sim_cl", SOC_SCA_CL, S, V);
+}
+
+int soc_sca_read_out(soc_ctx *c, float *out, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_read_out: call soc_sca_set_view first");
+    const int64_t npix = (int64_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y;
+    if (!out || n < 0 || n > npix) return fail(c, SOC_ERR_ARG, "soc_sca_read_out: n=%lld (image has %lld values)", (long long)n, (long long)npix);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->dOUT, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+void *soc_sca_out_ptr(soc_ctx *c) { return (c && c->have_view) ? (void *)c->dOUT : nullptr; }
+
+int soc_sca_bind_out(soc_ctx *c, void *device_ptr)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_bind_out: call soc_sca_set_view first");
+    if (!device_ptr) return fail(c, SOC_ERR_ARG, "soc_sca_bind_out: NULL pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_OUT && c->dOUT) (void)hipFree(c->dOUT);
+    c->dOUT = (float *)device_ptr;
+    c->own_OUT = false;
     return SOC_OK;
 }
 

@@ -54,6 +54,18 @@ hipError_t soc_launch_trace(const SocGrid &G, const SocVariant &V, const float *
                             hipStream_t st);
 
 
+// scattered-light images (soc_sca.hip): observers and image of one launch of the
+// kernel_ASOC_sca.c kernels (argument lists :471-501, :1098-1122, :1462-1489)
+enum { SOC_SCA_PB = 0, SOC_SCA_CL = 1, SOC_SCA_PS = 2 };
+struct SocSca {
+    int   kind, NDIR, NPIX_X, NPIX_Y, FFS;
+    float MAP_DX, CX, CY, CZ;
+    const float4 *ODIRS, *ORA, *ODE;   /* [NDIR] cl float3 = 16 bytes                      */
+    const float  *DSC;                 /* [BINS] discrete scattering function              */
+    float *OUT;                        /* [NDIR*NPIX_Y*NPIX_X]                             */
+};
+hipError_t soc_launch_sca(const SocGrid &G, const SocSim &S, const SocSca &V, const SocVariant &X, hipStream_t st);
+
 // stochastic-heating solver (soc_a2e.hip)
 struct SocA2EArgs {
     int NE, NFREQ, npair, batch;

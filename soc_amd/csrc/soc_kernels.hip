@@ -245,6 +245,9 @@ __global__ void soc_math_probe_kernel(int fn, const float *x, float *y, long n)
     case 5: r = soc_sqrtf(v); break;
     case 6: r = soc_fmod1f(v); break;
     case 7: r = 1.0f / v; break;
+    case 8: r = soc_expm1f(v); break;
+    case 9: r = soc_pow15f(v); break;
+    case 10: r = (float)soc_logd((double)v); break;
     default: break;
     }
     y[i] = r;

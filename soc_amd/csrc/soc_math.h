@@ -129,6 +129,55 @@ SOC_HD float soc_logf(float x)
     return r;
 }
 
+// double-precision natural logarithm for x in (0, +inf): the scattered-light kernels write
+// log(1.0 - W*Rand) with a double literal, so the reference evaluates that one logarithm in
+// fp64 (kernel_ASOC_sca.c:906).  Argument reduction x = 2^k * (1+f), s = f/(2+f),
+// log(1+f) = f - s*(f - R(s^2)); degree-14 even polynomial, relative error < 1e-16.
+SOC_HD double soc_logd(double x)
+{
+    union { double d; uint64_t u; } v;
+    v.d = x;
+    if (!(x > 0.0)) return (x == 0.0) ? -__builtin_huge_val() : (x - x) / (x - x);
+    int k = 0;
+    if (v.u < 0x0010000000000000ULL) { x = x * 18014398509481984.0; v.d = x; k = -54; }   // subnormal
+    if (v.u >= 0x7ff0000000000000ULL) return x;
+    k += (int)(v.u >> 52) - 1023;
+    v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;                           // m in [1, 2)
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; k += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// expm1(x) for x <= 0 (the point-source scattered-light kernel writes W = -expm1(-tau),
+// kernel_ASOC_sca.c:1737): Taylor series in fma form below 0.35, exp(x)-1 beyond, where the
+// subtraction loses less than one bit.
+SOC_HD float soc_expm1f(float x)
+{
+    if (!(x > -0.35f)) return soc_expf(x) - 1.0f;
+    float p = 2.7557319224e-6f;                       // 1/9!
+    p = SOC_FMA(p, x, 2.4801587302e-5f);
+    p = SOC_FMA(p, x, 1.9841269841e-4f);
+    p = SOC_FMA(p, x, 1.3888888889e-3f);
+    p = SOC_FMA(p, x, 8.3333333333e-3f);
+    p = SOC_FMA(p, x, 4.1666666667e-2f);
+    p = SOC_FMA(p, x, 1.6666666667e-1f);
+    p = SOC_FMA(p, x, 0.5f);
+    return SOC_FMA(p * x, x, x);
+}
+
+// x^1.5 for x > 0 (Henyey-Greenstein denominator of the cell-emission peel-off,
+// kernel_ASOC_sca.c:1390): two correctly rounded operations
+SOC_HD float soc_pow15f(float x) { return x * soc_sqrtf(x); }
+
 // log10(x) and integer power x^n (n >= 0): used by the equilibrium-temperature lookup
 // (kernel_A2E.c:136-137 calls the OpenCL built-ins log10 and pown)
 SOC_HD float soc_log10f(float x) { return soc_logf(x) * 0.43429448190325182765f; }

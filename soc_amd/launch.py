@@ -97,3 +97,30 @@ def shard_range(GLOBAL, rank, world):
     first = min(GLOBAL, rank * per)
     last = min(GLOBAL, first + per)
     return first, last - first
+
+
+def set_observer_directions(OBS_THETA, OBS_PHI):
+    """Observer directions and image axes (ASOC_aux.py:1129-1183): for every (theta, phi)
+    [rad] the unit vector towards the observer ODIR and the map axes RA (increases to the
+    right) and DE, as rows of a rotation of (x, y, z).  Components of ODIR with magnitude
+    below 1e-5 are set to 1e-5, as in the reference.  Returns NDIR and three [NDIR,4]
+    float32 arrays (OpenCL float3 = 16 bytes)."""
+    th = list(OBS_THETA) if len(OBS_THETA) else [0.5 * math.pi]
+    ph = list(OBS_PHI) if len(OBS_PHI) else [0.0]
+    NDIR = len(th)
+    ODIR = np.zeros((NDIR, 4), np.float32)
+    RA = np.zeros((NDIR, 4), np.float32)
+    DE = np.zeros((NDIR, 4), np.float32)
+    for i in range(NDIR):
+        b, a = 0.5 * math.pi - th[i], ph[i]
+        R = np.zeros((3, 3), np.float32)
+        R[0, :] = [math.cos(a) * math.cos(b), -math.sin(a), -math.cos(a) * math.sin(b)]
+        R[1, :] = [math.sin(a) * math.cos(b), math.cos(a), -math.sin(a) * math.sin(b)]
+        R[2, :] = [math.sin(b), 0.0, math.cos(b)]
+        ODIR[i, :3] = np.matmul(R, [1, 0, 0])
+        RA[i, :3] = np.matmul(R, [0, 1, 0])
+        DE[i, :3] = np.matmul(R, [0, 0, 1])
+        for k in range(3):
+            if abs(ODIR[i, k]) < 1.0e-5:
+                ODIR[i, k] = 1.0e-5
+    return NDIR, ODIR, RA, DE

@@ -38,6 +38,16 @@ API = {
                              _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
     "soc_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int]),
+    "soc_sca_set_view": (C.c_int, [C.c_void_p, C.c_int, _F, _F, _F, C.c_int, C.c_int, C.c_float, _F, C.c_int]),
+    "soc_sca_zero": (C.c_int, [C.c_void_p]),
+    "soc_sca_sim_ps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, _F, _F, C.c_int, _I, _I, _F,
+                                 C.c_int, C.c_int, C.c_int]),
+    "soc_sca_sim_pb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _F, _F, C.c_int,
+                                 _I, _I, _F, C.c_int, C.c_int, C.c_int]),
+    "soc_sca_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
+    "soc_sca_read_out": (C.c_int, [C.c_void_p, _F, C.c_int64]),
+    "soc_sca_out_ptr": (C.c_void_p, [C.c_void_p]),
+    "soc_sca_bind_out": (C.c_int, [C.c_void_p, C.c_void_p]),
     "soc_sync": (C.c_int, [C.c_void_p]),
     "soc_read_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
     "soc_write_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
@@ -207,6 +217,67 @@ class Engine:
         self._chk(self.lib.soc_sim_cl(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED),
                                       np.float32(TW), int(GLOBAL), int(gid_first), int(gid_count)))
 
+    # ---- scattered-light images (ASOCS) ----
+    @staticmethod
+    def _sources(PSPOS, PS, XPS):
+        p = np.asarray(PSPOS, np.float32)
+        if p.ndim == 1:
+            p = p.reshape(-1, p.size // max(1, np.asarray(PS).size))
+        pspos = np.zeros((p.shape[0], 4), np.float32)
+        pspos[:, :3] = p[:, :3]
+        ps = np.ascontiguousarray(PS, np.float32)
+        nside = side = area = None
+        if XPS is not None:
+            nside = np.ascontiguousarray(XPS[0], np.int32)
+            side = np.ascontiguousarray(XPS[1], np.int32)
+            area = np.ascontiguousarray(XPS[2], np.float32)
+        return pspos, ps, nside, side, area
+
+    def sca_set_view(self, ODIR, RA, DE, NPIX, MAP_DX, CENTRE, FFS=1):
+        """ODIR, RA, DE: [NDIR,4] float32 (launch.set_observer_directions); NPIX = (x, y)."""
+        ODIR, RA, DE = (np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (ODIR, RA, DE))
+        cen = np.asarray(CENTRE, np.float32).ravel()[:3].copy()
+        self.sca_shape = (len(ODIR), int(NPIX[1]), int(NPIX[0]))
+        self._chk(self.lib.soc_sca_set_view(self.h, len(ODIR), _f(ODIR), _f(RA), _f(DE), int(NPIX[0]), int(NPIX[1]),
+                                            np.float32(MAP_DX), _f(cen), int(FFS)))
+
+    def sca_zero(self):
+        self._chk(self.lib.soc_sca_zero(self.h))
+
+    def sca_sim_ps(self, PACKETS, BATCH, SEED, BG, PSPOS, PS, XPS=None, GLOBAL=None, gid_first=0, gid_count=None):
+        pspos, ps, nside, side, area = self._sources(PSPOS, PS, XPS)
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sca_sim_ps(self.h, int(PACKETS), int(BATCH), np.float32(SEED), np.float32(BG), _f(pspos), _f(ps),
+                                          len(ps), _i(nside), _i(side), _f(area), int(GLOBAL), int(gid_first), int(gid_count)))
+
+    def sca_sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, PSPOS=None, PS=None, XPS=None, GLOBAL=None, gid_first=0,
+                   gid_count=None):
+        pspos = ps = nside = side = area = None
+        NO_PS = 0
+        if SOURCE == 0:
+            pspos, ps, nside, side, area = self._sources(PSPOS, PS, XPS)
+            NO_PS = len(ps)
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sca_sim_pb(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED), np.float32(BG),
+                                          _f(pspos), _f(ps), NO_PS, _i(nside), _i(side), _f(area), int(GLOBAL),
+                                          int(gid_first), int(gid_count)))
+
+    def sca_sim_cl(self, SOURCE, PACKETS, BATCH, SEED, GLOBAL, gid_first=0, gid_count=None):
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sca_sim_cl(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED), int(GLOBAL),
+                                          int(gid_first), int(gid_count)))
+
+    def sca_read_out(self):
+        out = np.zeros(self.sca_shape, np.float32)
+        self._chk(self.lib.soc_sca_read_out(self.h, _f(out), out.size))
+        return out
+
+    def sca_out_ptr(self):
+        return self.lib.soc_sca_out_ptr(self.h)
+
+    def sca_bind_out(self, device_ptr):
+        self._chk(self.lib.soc_sca_bind_out(self.h, C.c_void_p(device_ptr)))
+
     def sync(self):
         self._chk(self.lib.soc_sync(self.h))
 
@@ -295,7 +366,7 @@ class Engine:
         return st, dr[:, :ndraw]
 
     def probe_math(self, fn, x):
-        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, rcp=7)[fn]
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, rcp=7, expm1=8, pow15=9, logd=10)[fn]
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
         self._chk(self.lib.soc_probe_math(self.h, code, _f(x), _f(y), x.size))

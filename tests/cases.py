@@ -78,6 +78,56 @@ CASES = {
                                      EMIT=_emit(_c8()))),
 }
 
+# ---- scattered-light images (kernel_ASOC_sca.c) --------------------------------------------
+# name: (ref build of oracle/build.py: sca_ref_models, kernel kind, job factory, view kwargs)
+# kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS
+_PS_EXT2 = np.array([[14.3, 4.2, 4.1], [4.0, -3.0, 20.0]], np.float32)
+
+
+def sca_view(NPIX=(12, 10), MAP_DX=1.1, FFS=1, angles=((30.0, 40.0), (90.0, 0.0), (0.0, 0.0))):
+    import math
+    from oracle.pyoracle import ScaView
+    from soc_amd import launch
+    th = [math.radians(a[0]) for a in angles]
+    ph = [math.radians(a[1]) for a in angles]
+    _, OD, RA, DE = launch.set_observer_directions(th, ph)
+    return ScaView(OD, RA, DE, NPIX=NPIX, MAP_DX=MAP_DX, CENTRE=(4.0, 4.0, 4.0), FFS=FFS)
+
+
+def _xps(ps, meth):
+    from soc_amd import files
+    return files.analyse_external_point_sources(8, 8, 8, ps, len(ps), meth)
+
+
+def _psjob(meth, ps=_PS_EXT2, lum=(1.0, 2.0), **kw):
+    return Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256, PSPOS=ps, PS=list(lum), DSC=_DSC,
+               PS_METHOD=meth, XPS=_xps(ps, meth), **kw)
+
+
+SCA_CASES = {
+    "sca_bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=10, SEED=0.6004384, DSC=_DSC), {}),
+    "sca_bg_c8_noffs": ("c8noffs", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=10, SEED=0.25, DSC=_DSC),
+                        dict(FFS=0)),
+    "sca_bg_c8_abu": ("c8abu", 0, lambda: Job(_c8(), _CSC, SOURCE=1, BATCH=8, SEED=0.3, OPT=_opt(512), DSC=_DSC), {}),
+    "sca_bg_c8_thick": ("c8", 0, lambda: Job(_c8(), _CSC0, ABS=2e-2, SCA=2e-1, SOURCE=1, BATCH=2, SEED=0.77, DSC=_DSC0),
+                        dict(angles=((60.0, 200.0),))),
+    "sca_bg_oct8": ("oct8", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=8, SEED=0.41, DSC=_DSC), {}),
+    "sca_ps_in_c8": ("c8ps", 2, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256,
+                                            PSPOS=_PS_IN, PS=[1.0, 2.0], DSC=_DSC), {}),
+    "sca_ps_ext0_c8": ("c8ps", 2, lambda: _psjob(0), {}),
+    "sca_ps_ext1_c8": ("c8ps1", 2, lambda: _psjob(1), {}),
+    "sca_ps_ext2_c8": ("c8ps2", 2, lambda: _psjob(2), {}),
+    "sca_ps_ext4_c8": ("c8ps4", 2, lambda: _psjob(4, ps=np.array([[4.0, 4.0, 15.0]], np.float32), lum=(1.0,)), {}),
+    "sca_ps_ext5_c8": ("c8ps5", 2, lambda: _psjob(5), {}),
+    "sca_pbps_ext2_c8": ("c8ps2", 0, lambda: _psjob(2), {}),
+    "sca_cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                        EMIT=_emit(_c8()), DSC=_DSC), {}),
+    "sca_cl_oct8": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                            EMIT=_emit(_oct8()), DSC=_DSC), {}),
+    "sca_cl_oct8_emw": ("oct8emw", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                   EMIT=_emit(_oct8()), EMWEI=_emwei(_oct8()), USE_EMWEIGHT=1, DSC=_DSC), {}),
+}
+
 # fixed rays for step-by-step traces: (ref build, cloud factory, pos, dir)
 RAYS = {
     "ray_c32": ("c32", lambda: synth.cartesian_cloud(32, uniform=1.0), [1e-4, 10.3, 20.7], [0.8, 0.36, 0.48]),

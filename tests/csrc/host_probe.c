@@ -40,6 +40,9 @@ void hp_math(int fn, const float *x, float *y, long n)
         case 4: y[i] = soc_acosf(x[i]); break;
         case 5: y[i] = soc_sqrtf(x[i]); break;
         case 6: y[i] = soc_fmod1f(x[i]); break;
+        case 8: y[i] = soc_expm1f(x[i]); break;
+        case 9: y[i] = soc_pow15f(x[i]); break;
+        case 10: y[i] = (float)soc_logd((double)x[i]); break;
         default: y[i] = 0.0f;
         }
     }

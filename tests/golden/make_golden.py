@@ -124,7 +124,22 @@ def a2e_main():
     print("a2e golden: T range", T.min(), T.max())
 
 
+def sca_main():
+    """Scattered-light images of tests/cases.py:SCA_CASES from the x86 builds of kernel_ASOC_sca.c."""
+    from oracle.pyoracle import RefSca
+    out = {}
+    for name, (ref, kind, mk, vkw) in cases.SCA_CASES.items():
+        job, view = mk(), cases.sca_view(**vkw)
+        OUT = RefSca(ref).sim(job, view, kind)
+        out[name] = OUT.reshape(view.NDIR, view.NPIX[1], view.NPIX[0])
+        print("%-18s sum(OUT) = %.9e   nonzero pixels %d / %d" % (name, OUT.sum(dtype=np.float64), (OUT != 0).sum(), OUT.size))
+    np.savez_compressed(os.path.join(HERE, "sca.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--sca" in sys.argv:
+        sca_main()
+        sys.exit(0)
     if "--a2e" in sys.argv:
         a2e_main()
         sys.exit(0)

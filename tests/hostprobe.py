@@ -54,7 +54,7 @@ class HostProbe:
         return u, r
 
     def math(self, fn, x):
-        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6)[fn]
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, expm1=8, pow15=9, logd=10)[fn]
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
         self.lib.hp_math(code, x.ctypes.data_as(_F), y.ctypes.data_as(_F), x.size)

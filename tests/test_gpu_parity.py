@@ -42,14 +42,17 @@ def test_rng_streams_contiguous_block_vs_oracle(engine, oracle_soc):
         assert np.array_equal(dr[k], oracle_soc.draws(*s, 4)[0])
 
 
-@pytest.mark.parametrize("fn", ["exp", "log", "sin", "cos", "acos", "sqrt", "fmod1"])
+@pytest.mark.parametrize("fn", ["exp", "log", "sin", "cos", "acos", "sqrt", "fmod1", "expm1", "pow15", "logd"])
 def test_device_math_bit_identical_to_host_build(fn, engine, oracle_soc):
     rng = np.random.default_rng(11)
     x = {"exp": np.concatenate([rng.uniform(-90, 5, 200000), -np.logspace(-9, 1, 20000)]),
          "log": np.concatenate([rng.uniform(0, 1, 200000), np.logspace(-38, 30, 20000), [0.0, 1.0]]),
          "sin": rng.uniform(-7, 7, 200000), "cos": rng.uniform(-7, 7, 200000),
          "acos": np.concatenate([rng.uniform(-1, 1, 200000), [1.0, -1.0, 0.5, -0.5]]),
-         "sqrt": rng.uniform(0, 1e4, 200000), "fmod1": rng.uniform(-300, 300, 200000)}[fn].astype(np.float32)
+         "sqrt": rng.uniform(0, 1e4, 200000), "fmod1": rng.uniform(-300, 300, 200000),
+         "expm1": -np.concatenate([rng.uniform(0, 40, 100000), np.logspace(-30, 0, 100000)]),
+         "pow15": rng.uniform(0.1, 3.0, 200000),
+         "logd": np.concatenate([rng.uniform(0, 1, 200000), np.logspace(-38, 30, 20000)])}[fn].astype(np.float32)
     assert np.array_equal(engine.probe_math(fn, x).view(np.uint32), oracle_soc.math(fn, x).view(np.uint32))
 
 

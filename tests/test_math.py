@@ -60,7 +60,18 @@ def test_sqrt_correctly_rounded(hp):
     assert np.array_equal(hp.math("sqrt", x), np.sqrt(x))
 
 
+def test_expm1_pow15_logd(hp):
+    x = -np.concatenate([np.logspace(-30, 1.9, 200001), np.linspace(0.3, 0.4, 20001), [0.0]]).astype(np.float32)
+    assert ulp_err(hp.math("expm1", x), np.expm1(x.astype(np.float64))).max() < 2.0
+    x = np.linspace(0.15, 2.8, 200001).astype(np.float32)          # 1+g^2-2g*cos, g=0.65
+    assert ulp_err(hp.math("pow15", x), x.astype(np.float64) ** 1.5).max() < 1.5
+    x = np.concatenate([np.logspace(-37, 38, 200001), 1.0 - np.logspace(-7, -0.01, 100001)]).astype(np.float32)
+    want = np.log(x.astype(np.float64))
+    assert np.array_equal(hp.math("logd", x), want.astype(np.float32))   # fp64 log rounded to fp32
+
+
 def test_oracle_soc_mode_uses_this_header(hp, oracle_soc):
     x = np.random.default_rng(5).uniform(-20, 5, 20000).astype(np.float32)
-    for fn, xx in (("exp", x), ("log", np.abs(x) + 1e-9), ("sin", x), ("cos", x), ("acos", np.clip(x / 20, -1, 1))):
+    for fn, xx in (("exp", x), ("log", np.abs(x) + 1e-9), ("sin", x), ("cos", x), ("acos", np.clip(x / 20, -1, 1)),
+                   ("expm1", -np.abs(x)), ("pow15", np.abs(x) + 0.1), ("logd", np.abs(x) + 1e-9)):
         assert np.array_equal(hp.math(fn, xx).view(np.uint32), oracle_soc.math(fn, xx).view(np.uint32))
