@@ -183,6 +183,7 @@ def sca_ref_models():
         "c8ps2": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2, PS_METHOD=2),
         "c8ps4": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=1, PS_METHOD=4),
         "c8ps5": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NO_PS=2, PS_METHOD=5),
+        "c128": dict(NX=128, NY=128, NZ=128, LEVELS=1, CELLS=128 ** 3),
         "oct8": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
         "oct8emw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=1),
     }

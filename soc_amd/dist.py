@@ -65,6 +65,26 @@ class Comm:
             self.dist.all_reduce(arr)
             engine.write_tally(which, arr.numpy())
 
+    def attach_image(self, engine, npix):
+        """Same for the scattered-light image OUT[NDIR*NPIX_Y*NPIX_X]."""
+        if self.world > 1 and self.backend == "nccl":
+            t = self.torch
+            buf = t.zeros(npix, dtype=t.float32, device="cuda")
+            engine.sca_bind_out(buf.data_ptr())
+            self._tensors["out"] = buf
+            engine.set_stream(t.cuda.current_stream().cuda_stream)
+
+    def all_reduce_image(self, engine):
+        """Sum the image over all ranks; returns it as a host array [NDIR, NPIX_Y, NPIX_X]."""
+        if self.world == 1:
+            return engine.sca_read_out()
+        if self.backend == "nccl":
+            self.dist.all_reduce(self._tensors["out"])
+            return engine.sca_read_out()
+        arr = self.torch.from_numpy(np.ascontiguousarray(engine.sca_read_out()))
+        self.dist.all_reduce(arr)
+        return arr.numpy()
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()

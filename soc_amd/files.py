@@ -225,3 +225,31 @@ def read_solver(filename):
 def write_emitted(filename, EMITTED):
     """emitted file: int32 CELLS,NFREQ; float32 [CELLS,NFREQ] (A2E.py:151-156)"""
     write_absorbed(filename, EMITTED)
+
+
+def mmap_emitted(filename, CELLS, REMIT_NFREQ):
+    """Read-only view of an existing emitted file as EMITTED[CELLS, REMIT_NFREQ]
+    (ASOC_aux.py:869-935); the scattering run only reads it."""
+    dims = np.fromfile(filename, np.int32, 2)
+    if dims[0] != CELLS or dims[1] != REMIT_NFREQ:
+        raise FileError("%s holds %d cells x %d frequencies, the run needs %d x %d" % (
+            filename, dims[0], dims[1], CELLS, REMIT_NFREQ))
+    return np.memmap(filename, dtype='float32', mode='r', offset=8, shape=(int(CELLS), int(REMIT_NFREQ)))
+
+
+def write_outcoming(filename, FFREQ, OUTCOMING):
+    """outcoming.socs (ASOCS.py:409-416): int32 NPIX.y, NPIX.x, NFREQ; float32 FFREQ[NFREQ];
+    float32 OUTCOMING[NFREQ, NDIR, NPIX.y, NPIX.x]"""
+    OUTCOMING = np.asarray(OUTCOMING, np.float32)
+    with open(filename, 'wb') as fp:
+        np.asarray([OUTCOMING.shape[2], OUTCOMING.shape[3], OUTCOMING.shape[0]], np.int32).tofile(fp)
+        np.asarray(FFREQ, np.float32).tofile(fp)
+        OUTCOMING.tofile(fp)
+
+
+def read_outcoming(filename, NDIR):
+    """-> FFREQ, OUTCOMING[NFREQ, NDIR, NPIX.y, NPIX.x]"""
+    ny, nx, nfreq = np.fromfile(filename, np.int32, 3)
+    FFREQ = np.fromfile(filename, np.float32, nfreq, offset=12)
+    data = np.fromfile(filename, np.float32, offset=12 + 4 * int(nfreq))
+    return FFREQ, data.reshape(int(nfreq), NDIR, int(ny), int(nx))

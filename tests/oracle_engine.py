@@ -3,7 +3,7 @@ Lives in tests/: it lets the host driver (soc_amd.asoc.AbsorptionRun) and the mu
 sharding logic be exercised without a GPU.  Never imported by the product."""
 import numpy as np
 
-from oracle.pyoracle import Job, Oracle
+from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca
 
 
 class OracleEngine:
@@ -66,6 +66,36 @@ class OracleEngine:
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
         _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n
+
+    # ---- scattered-light images ----
+    def sca_set_view(self, ODIR, RA, DE, NPIX, MAP_DX, CENTRE, FFS=1):
+        self.view = ScaView(ODIR, RA, DE, NPIX=NPIX, MAP_DX=MAP_DX, CENTRE=CENTRE, FFS=FFS)
+        self.OUT = np.zeros(self.view.out_size(), np.float32)
+        self.sca_shape = (self.view.NDIR, int(NPIX[1]), int(NPIX[0]))
+
+    def sca_zero(self):
+        self.OUT[:] = 0
+
+    def _sca(self, kind, job, GLOBAL, gid_first, gid_count):
+        gid_count = GLOBAL - gid_first if gid_count is None else gid_count
+        _, n = oracle_sim_sca(self.orc, job, self.view, kind, gid_first, gid_first + gid_count, OUT=self.OUT)
+        self.events += n
+
+    def sca_sim_ps(self, PACKETS, BATCH, SEED, BG, PSPOS, PS, XPS=None, GLOBAL=None, gid_first=0, gid_count=None):
+        self._sca(2, self._job(0, PACKETS, BATCH, SEED, BG, 0.0, GLOBAL, PSPOS, PS, XPS), GLOBAL, gid_first, gid_count)
+
+    def sca_sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, PSPOS=None, PS=None, XPS=None, GLOBAL=None, gid_first=0,
+                   gid_count=None):
+        self._sca(0, self._job(SOURCE, PACKETS, BATCH, SEED, BG, 0.0, GLOBAL, PSPOS, PS, XPS), GLOBAL, gid_first, gid_count)
+
+    def sca_sim_cl(self, SOURCE, PACKETS, BATCH, SEED, GLOBAL, gid_first=0, gid_count=None):
+        self._sca(1, self._job(2, PACKETS, BATCH, SEED, 0.0, 0.0, GLOBAL), GLOBAL, gid_first, gid_count)
+
+    def sca_read_out(self):
+        return self.OUT.reshape(self.sca_shape).copy()
+
+    def sca_bind_out(self, ptr):
+        raise NotImplementedError
 
     def sync(self):
         pass

@@ -55,3 +55,51 @@ def test_two_rank_sharded_run_equals_single(tmp_path):
     A = files.read_absorbed(os.path.join(d, "abs.data"))
     want = files.scale_absorbed(F1.copy(), cloud, 0.5) if (F1 >= 0).all() else F1
     assert np.allclose(A, want, rtol=1e-5, atol=1e-7 * np.abs(want).max())
+
+
+SCA_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np
+from soc_amd.ini import User
+from soc_amd.asocs import ScatteringRun
+from soc_amd.dist import Comm
+from oracle_engine import OracleEngine
+comm = Comm(backend="gloo")
+os.chdir(sys.argv[2] + "/s%d" % comm.rank)
+OUT = ScatteringRun(User(sys.argv[1]), OracleEngine("soc"), comm, verbose=0).run()
+np.save("out_rank%d.npy" % comm.rank, OUT)
+comm.close()
+"""
+
+
+def test_two_rank_scattering_run_equals_single(tmp_path):
+    """Scattered-light images: two ranks split every launch by work-item range and all-reduce
+    the image; same streams, so the sum equals the single-process image."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_host_sca import _ini
+    from oracle_engine import OracleEngine
+    from soc_amd import synth, files
+    from soc_amd.ini import User
+    from soc_amd.asocs import ScatteringRun
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _ini(d, cloud, with_ps=True)
+    for r in (0, 1):
+        os.makedirs(os.path.join(d, "s%d" % r))
+    os.makedirs(os.path.join(d, "single"))
+    os.chdir(os.path.join(d, "single"))
+    O1 = ScatteringRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    script = os.path.join(d, "sca_worker.py")
+    with open(script, "w") as fp:
+        fp.write(SCA_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29537", script, ini, d],
+                          env=env, timeout=600)
+    for r in (0, 1):
+        O = np.load(os.path.join(d, "s%d" % r, "out_rank%d.npy" % r))
+        assert np.allclose(O, O1, rtol=1e-5, atol=1e-7 * np.abs(O1).max())
+    _, data = files.read_outcoming(os.path.join(d, "s0", "outcoming.socs"), 2)
+    assert np.allclose(data, O1, rtol=1e-5, atol=1e-7 * np.abs(O1).max())
+    assert not os.path.exists(os.path.join(d, "s1", "outcoming.socs"))       # only rank 0 writes

@@ -88,3 +88,23 @@ def test_sca_full_size_properties(engine):
     tot = a.reshape(3, -1).sum(axis=1, dtype=np.float64)
     assert np.abs(tot / tot.mean() - 1).max() < 0.01
     np.testing.assert_allclose(b, 2.0 * a, rtol=1e-5, atol=1e-6 * a.max())
+
+
+def test_scattering_run_end_to_end(engine, tmp_path):
+    """python -m soc_amd.asocs on the GPU equals the same host loop on the oracle engine."""
+    import os
+    from oracle_engine import OracleEngine
+    from soc_amd import synth, files
+    from soc_amd.asocs import ScatteringRun
+    from soc_amd.ini import User
+    from test_host_sca import _ini
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _ini(d, cloud, with_ps=True)
+    os.chdir(d)
+    want = ScatteringRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    got = ScatteringRun(User(ini), engine, verbose=0).run()
+    for i in range(want.shape[0]):
+        assert_image_close(got[i], want[i], rtol=2e-5)
+    _, data = files.read_outcoming("outcoming.socs", 2)
+    assert np.array_equal(data, got)
