@@ -97,6 +97,14 @@ int soc_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
 int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
                int GLOBAL, int gid_first, int gid_count);
 
+/* replaces the HPBG_buf / HPBGP_buf uploads (ASOC.py:1196-1214): the Healpix sky of the current
+ * frequency in photons per package, 49152 floats (NSIDE 64, RING order); HPBGP = cumulative
+ * pixel probability for `hpbg ... weighted` runs (-D HPBG_WEIGHTED=1) or NULL */
+int soc_set_hpbg(soc_ctx *ctx, const float *BG, const float *HPBGP);
+
+/* replaces the kernel_ram_hp launch (ASOC.py:1349-1354 -> SimRAM_HP, kernel_ASOC.c:826-850) */
+int soc_sim_hp(soc_ctx *ctx, int PACKETS, int BATCH, float SEED, float TW, int GLOBAL, int gid_first, int gid_count);
+
 /* replaces queue.finish() (ASOC.py:1461) */
 int soc_sync(soc_ctx *ctx);
 

@@ -52,7 +52,7 @@ def build_oracle(force=False):
 
 def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
              USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
-             GL=0.01):
+             GL=0.01, HPBG_WEIGHTED=0):
     """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
     d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=0, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
@@ -63,7 +63,7 @@ def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_AB
              SW_A="0.000e+00f", SW_B="0.000e+00f", STEP_WEIGHT=-1, DIR_WEIGHT=-1, DW_A="0.000e+00f",
              LEVEL_THRESHOLD=0, POLRED=0, p00="0.2000f", MINLOS="-1.000e+00f", MAXLOS="1.000e+10f",
              FFS=1, NODIR=1, USE_EMWEIGHT=USE_EMWEIGHT, SAVE_INTENSITY=SAVE_INTENSITY,
-             NOABSORBED=NOABSORBED, INTERPOLATE=0, ADHOC="1.00000e+00f", HPBG_WEIGHTED=0,
+             NOABSORBED=NOABSORBED, INTERPOLATE=0, ADHOC="1.00000e+00f", HPBG_WEIGHTED=HPBG_WEIGHTED,
              WITH_MSF=WITH_MSF, NDUST=NDUST, OPT_IS_HALF=0, POL_RHO_WEIGHT=0, MAP_INTERPOLATION=0,
              MIRROR=MIRROR, CR_HEATING=0, CR_HEATING_RATE="0.000e+00f", NVIDIA=0, NSIDE=128)
     return ["-D%s=%s" % (k, v) for k, v in d.items()]
@@ -215,6 +215,8 @@ def ref_models():
         "oct8emw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=1),
         "oct104":  dict(NX=104, NY=104, NZ=104, LEVELS=oct104.LEVELS, CELLS=oct104.CELLS),
         "c128":    dict(NX=128, NY=128, NZ=128, LEVELS=1, CELLS=128 ** 3),
+        "c8hpw":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, HPBG_WEIGHTED=1),
+        "oct8hpw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, HPBG_WEIGHTED=1, NOABSORBED=0),
     }
     for k in (1, 2, 4, 5):
         m["c8ps%d" % k] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=k, NO_PS=2)

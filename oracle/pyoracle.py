@@ -37,6 +37,7 @@ class OrcModel(C.Structure):
         ("NDIR", C.c_int), ("NPIX_X", C.c_int), ("NPIX_Y", C.c_int), ("FFS", C.c_int),
         ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
         ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("DSC", _F), ("OUT", _F), ("XPS_AS_FLOAT", C.c_int),
+        ("HPBG_WEIGHTED", C.c_int), ("HPBG", _F), ("HPBGP", _F),
     ]
 
 
@@ -48,7 +49,7 @@ class RefArgs(C.Structure):
         ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
         ("DENS", _F), ("EMIT", _F), ("TABS", _F), ("DSC", _F), ("CSC", _F), ("XAB", _F), ("EMWEI", _F),
         ("INT", _F), ("INTX", _F), ("INTY", _F), ("INTZ", _F), ("OPT", _F), ("ABU", _F),
-        ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("EMINDEX", _I),
+        ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("EMINDEX", _I), ("HPBG", _F), ("HPBGP", _F),
     ]
 
 
@@ -62,8 +63,11 @@ class Job:
 
     def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
                  GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
-                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None):
+                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None):
         self.cloud = cloud
+        # Healpix sky (NSIDE 64, RING) in photons per package; HPBGP given = weighted pixel selection
+        self.HPBG = None if HPBG is None else np.ascontiguousarray(HPBG, np.float32)
+        self.HPBGP = None if HPBGP is None else np.ascontiguousarray(HPBGP, np.float32)
         self.CSC = np.ascontiguousarray(CSC, np.float32)
         self.DSC = np.ascontiguousarray(DSC if DSC is not None else np.ones_like(self.CSC), np.float32)
         self.BINS = len(self.CSC)
@@ -158,6 +162,8 @@ class Oracle:
         m.PSPOS, m.PS = _fp(job.PSPOS), _fp(job.PS)
         m.XPS_NSIDE, m.XPS_SIDE, m.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         m.EMIT, m.EMWEI = _fp(job.EMIT), _fp(job.EMWEI)
+        m.HPBG_WEIGHTED = int(job.HPBGP is not None)
+        m.HPBG, m.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
         return m
 
     def parents(self, job):
@@ -254,6 +260,7 @@ class Ref:
         assert job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
         assert job.WITH_INT == int(m.get("NOABSORBED", 1) == 0 or m.get("SAVE_INTENSITY", 0) in (1, 2))
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1))
+        assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
 
     def seed(self, SEED, gid):
         x, c = C.c_uint32(), C.c_uint32()
@@ -327,6 +334,7 @@ class Ref:
         a.ABU = _fp(dummy)
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         a.EMINDEX = _ip(idummy)
+        a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP if job.HPBGP is not None else dummy)
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sim(C.byref(a), kind, gid0, gid1, stride, nthreads)
         return TABS, INT

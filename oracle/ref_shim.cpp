@@ -32,6 +32,9 @@ void SimRAM_PB(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float
                float *EMIT, float *TABS, float *DSC, float *CSC, float *XAB, float *EMWEI,
                float *INT, float *INTX, float *INTY, float *INTZ, float *OPT, float *ABU,
                int *XPS_NSIDE, int *XPS_SIDE, float *XPS_AREA);
+void SimRAM_HP(int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float TW, int *LCELLS, int *OFF, int *PAR,
+               float *DENS, float *EMIT, float *TABS, float *DSC, float *CSC, float *XAB, float *INT, float *INTX,
+               float *INTY, float *INTZ, float *OPT, float *BG, float *HPBGP, float *ABU);
 void SimRAM_CL(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float TW,
                int *LCELLS, int *OFF, int *PAR, float *DENS, float *EMIT, float *TABS, float *DSC,
                float *CSC, float *XAB, float *EMWEI, float *INT, float *INTX, float *INTY,
@@ -49,6 +52,7 @@ struct ref_args {
     int   *XPS_NSIDE, *XPS_SIDE;
     float *XPS_AREA;
     int   *EMINDEX;
+    float *HPBG, *HPBGP;     // Healpix sky of the current frequency, cumulative pixel probability
 };
 
 static void run_range(const ref_args *a, int kind, int gid0, int gid1, int stride = 1)
@@ -61,6 +65,9 @@ static void run_range(const ref_args *a, int kind, int gid0, int gid1, int strid
                       (float3 *)a->PSPOS, a->PS, a->TW, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
                       a->TABS, a->DSC, a->CSC, a->XAB, a->EMWEI, a->INT, a->INTX, a->INTY, a->INTZ,
                       a->OPT, a->ABU, a->XPS_NSIDE, a->XPS_SIDE, a->XPS_AREA);
+        else if (kind == 2)
+            SimRAM_HP(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->TW, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
+                      a->TABS, a->DSC, a->CSC, a->XAB, a->INT, a->INTX, a->INTY, a->INTZ, a->OPT, a->HPBG, a->HPBGP, a->ABU);
         else
             SimRAM_CL(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->TW, a->LCELLS,
                       a->OFF, a->PAR, a->DENS, a->EMIT, a->TABS, a->DSC, a->CSC, a->XAB, a->EMWEI,
@@ -70,7 +77,7 @@ static void run_range(const ref_args *a, int kind, int gid0, int gid1, int strid
 
 extern "C" {
 
-// Execute work items gid0, gid0+stride, ... < gid1 of SimRAM_PB (kind 0) / SimRAM_CL (kind 1).
+// Execute work items gid0, gid0+stride, ... < gid1 of SimRAM_PB (kind 0) / SimRAM_CL (kind 1) / SimRAM_HP (kind 2).
 // stride > 1 samples a launch evenly (bench.py's bounded CPU baseline).
 void ref_sim(const ref_args *a, int kind, int gid0, int gid1, int stride, int nthreads)
 {

@@ -103,6 +103,10 @@ typedef struct {
     const float *DSC;                 /* [BINS] discrete scattering function              */
     float *OUT;                       /* [NDIR*NPIX_Y*NPIX_X]                             */
     int   XPS_AS_FLOAT;               /* sca kernels declare XPS_NSIDE/XPS_SIDE as float* */
+    /* Healpix background (SimRAM_HP): sky map of the current frequency, NSIDE=64 RING */
+    int   HPBG_WEIGHTED;
+    const float *HPBG;                /* [49152] photons per package                      */
+    const float *HPBGP;               /* [49152] cumulative pixel probability (weighted)  */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -351,10 +355,13 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
     f3    POS0 = POS;
     long  nt = 0;
 
-    if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
-    if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
-    if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
-    normalize3(&DIR);
+    if (!(cl_order & 2)) {              /* bit 1: direction conditioned by the caller (SimRAM_HP) */
+        if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+        if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+        if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+        normalize3(&DIR);
+    }
+    cl_order &= 1;
     scatterings = 0;
     tau = 0.0f;
     free_path = -M_LOG(Rand(rng));
@@ -634,6 +641,117 @@ static long sim_pb_workitem(const orc_model *M, int id)
     for (int III = 0; III < BATCH; III++) {
         pb_create(M, &E, III, &rng, &POS, &DIR, &PHOTONS, &level, &ind);
         nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0);
+        ind = -1;
+    }
+    return nt;
+}
+
+/* ================================ SimRAM_HP ============================================ */
+
+/* Pixel2AnglesRing (kernel_ASOC_aux.c:987-1026): Healpix RING pixel -> (phi, theta) */
+static void pixel2angles_ring(const int nside, const int ipix, float *phi, float *theta)
+{
+    int   nl2, nl4, npix, ncap, iring, iphi, ip, ipix1;
+    float fact1, fact2, fodd, hip, fihip;
+    npix  = 12 * nside * nside;
+    ipix1 = ipix + 1;
+    nl2   = 2 * nside;
+    nl4   = 4 * nside;
+    ncap  = 2 * nside * (nside - 1);
+    fact1 = 1.5f * nside;
+    fact2 = 3.0f * nside * nside;
+    if (ipix1 <= ncap) {
+        hip    = ipix1 / 2.0f;
+        fihip  = (int)(hip);
+        iring  = (int)(M_SQRT(hip - M_SQRT(fihip))) + 1;
+        iphi   = ipix1 - 2 * iring * (iring - 1);
+        *theta = M_ACOS(1.0f - iring * iring / fact2);
+        *phi   = (iphi - 0.5f) * PI_F / (2.0f * iring);
+    } else {
+        if (ipix1 <= nl2 * (5 * nside + 1)) {
+            ip     = ipix1 - ncap - 1;
+            iring  = (int)(ip / nl4) + nside;
+            iphi   = (ip % nl4) + 1;
+            fodd   = 0.5f * (1 + (iring + nside) % 2);
+            *theta = M_ACOS((nl2 - iring) / fact1);
+            *phi   = (iphi - fodd) * PI_F / (2.0f * nside);
+        } else {
+            ip     = npix - ipix1 + 1;
+            hip    = ip / 2.0f;
+            fihip  = (int)(hip);
+            iring  = (int)(M_SQRT(hip - M_SQRT(fihip))) + 1;
+            iphi   = 4 * iring + 1 - (ip - 2 * iring * (iring - 1));
+            *theta = M_ACOS(-1.0f + iring * iring / fact2);
+            *phi   = (iphi - 0.5f) * PI_F / (2.0f * iring);
+        }
+    }
+}
+
+/* Healpix pixel of the next background packet: uniform (kernel_ASOC.c:881-884) or by
+ * bisection on the cumulative probability, n_bisect steps + linear scan (:885-902;
+ * the sca kernel bisects 12 times, kernel_ASOC_sca.c:118-131) */
+static int hp_select_pixel(const orc_model *M, rng_t *rng, int n_bisect)
+{
+    int ind, ind0, level0;
+    if (M->HPBG_WEIGHTED < 1) {
+        ind = clampi((int)(M_FLOOR(Rand(rng) * 49152)), 0, 49151);
+    } else {
+        const float x = Rand(rng);
+        ind0 = 0;
+        level0 = 49151;
+        for (int i = 0; i < n_bisect; i++) {
+            ind = (ind0 + level0) / 2;
+            if (M->HPBGP[ind] > x) level0 = ind;
+            else                   ind0 = ind;
+        }
+        for (ind = ind0; ind <= level0; ind++) {
+            if (M->HPBGP[ind] >= x) break;
+        }
+    }
+    return ind;
+}
+
+/* One work item of SimRAM_HP (kernel_ASOC.c:826-1207): Healpix background, entry face chosen
+ * with probability proportional to |DIR_i| (:929-945); the walk is SimRAM_PB's. */
+static long sim_hp_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
+    int   level = 0, ind = -1;
+    float phi, theta, x, y, z, ds, v1, v2, PHOTONS;
+    f3    DIR, POS = {0.0f, 0.0f, 0.0f};
+    rng_t rng;
+    long  nt = 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    if (id >= (8 * AREA)) return 0;
+    for (int III = 0; III < M->BATCH; III++) {
+        ind     = hp_select_pixel(M, &rng, 10);
+        PHOTONS = M->HPBG[ind];
+        pixel2angles_ring(64, ind, &phi, &theta);
+        DIR.x = +M_SIN(theta) * M_COS(phi);
+        DIR.y = +M_SIN(theta) * M_SIN(phi);
+        DIR.z = -M_COS(theta);
+        if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+        if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+        if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+        normalize3(&DIR);
+        x = fabsf(DIR.x);  y = fabsf(DIR.y);  z = fabsf(DIR.z);
+        ds = x + y + z;  x /= ds;  y /= ds;  z /= ds;
+        ds = Rand(&rng);  v1 = Rand(&rng);  v2 = Rand(&rng);
+        if (ds < x) {
+            POS.y = v1 * NY;  POS.z = v2 * NZ;
+            POS.x = (DIR.x > 0.0f) ? (PEPS) : (NX - PEPS);
+        } else {
+            if (ds < (x + y)) {
+                POS.x = v1 * NX;  POS.z = v2 * NZ;
+                POS.y = (DIR.y > 0.0f) ? (PEPS) : (NY - PEPS);
+            } else {
+                POS.x = v1 * NX;  POS.y = v2 * NY;
+                POS.z = (DIR.z > 0.0f) ? (PEPS) : (NZ - PEPS);
+            }
+        }
+        IndexG(M, &POS, &level, &ind);
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 2);
         ind = -1;
     }
     return nt;
@@ -1022,14 +1140,14 @@ EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int stride, int 
     if (nthreads <= 1) {
         M->threaded = 0;
         for (int id = gid0; id < gid1; id += stride)
-            total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
+            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id));
     } else {
         M->threaded = 1;
         const long n = ((long)gid1 - gid0 + stride - 1) / stride;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
         for (long k = 0; k < n; k++) {
             int id = (int)(gid0 + k * stride);
-            total += kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id);
+            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id));
         }
     }
     return total;

@@ -46,8 +46,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("mirror")
     if USER.WITH_ROI_SAVE or USER.WITH_ROI_LOAD:
         bad.append("roisave/roiload")
-    if len(USER.file_hpbg) > 2:
-        bad.append("hpbg (HEALPix background)")
     if USER.SAVE_INTENSITY == 2:
         bad.append("saveint 2 (intensity vectors)")
     if USER.PS_METHOD == 3:
@@ -99,6 +97,9 @@ class AbsorptionRun:
             if U.BGPAC > 0 else []
         self.LPS = files.read_source_luminosities(U.file_pointsource[:U.NO_PS], self.NFREQ, U.PS_SCALING) \
             if U.NO_PS > 0 else []
+        self.HPBG = []
+        if len(U.file_hpbg) > 2:                                   # ASOC.py:291-297, NSIDE 64 fixed
+            self.HPBG = np.fromfile(U.file_hpbg, np.float32).reshape(self.NFREQ, 49152) * np.float32(U.scale_background)
         self.cloud = files.read_cloud(U.file_cloud, U.KDENSITY, U.LEVELS)
         c = self.cloud
         U.AREA, U.CELLS = float(c.AREA), c.CELLS
@@ -189,7 +190,8 @@ class AbsorptionRun:
             elif II == 1:
                 if self.BGPAC < 1:
                     continue
-                L = launch.bg_launch(self.BGPAC, int(U.AREA))
+                L = launch.hpbg_launch(self.BGPAC, c.NX, c.NY, c.NZ) if len(self.HPBG) > 0 else \
+                    launch.bg_launch(self.BGPAC, int(U.AREA))
                 WBG = L["WBG"]
                 self.log("=== BG: BGPAC %d, BATCH %d, GLOBAL %d" % (L["PACKETS"], L["BATCH"], L["GLOBAL"]))
             else:
@@ -227,10 +229,18 @@ class AbsorptionRun:
                         a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
                         EMIT[a:b] = self.DIFFUSERAD[a:b, dr_ind] * coeff
                     e.set_emission(EMIT, None)
+                hp = (II == 1) and len(self.HPBG) > 0
+                if hp:
+                    sky = files.hpbg_for_frequency(self.HPBG[IFREQ], WBG / FREQ, U.HPBG_WEIGHTED)
+                    if sky is None:
+                        continue                                   # empty sky (ASOC.py:1200)
+                    e.set_hpbg(*sky)
                 self.timers["Tpush"] += time.time() - t0
                 t0 = time.time()
                 if II == 2:
                     e.sim_cl(II, L["PACKETS"], L["BATCH"], seed, FF, L["GLOBAL"], gid_first=first, gid_count=count)
+                elif hp:
+                    e.sim_hp(L["PACKETS"], L["BATCH"], seed, FF, L["GLOBAL"], gid_first=first, gid_count=count)
                 else:
                     e.sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, FF,
                              PSPOS=U.PSPOS[:max(U.NO_PS, 1), :3], PS=PS, XPS=self.XPS,

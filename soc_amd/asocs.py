@@ -26,6 +26,8 @@ from .launch import PLANCK, PARSEC, Fix
 
 class ScatteringRun(AbsorptionRun):
     def _load_inputs(self):
+        if len(self.U.file_hpbg) > 2:
+            raise UnsupportedOption("hpbg (HEALPix background) in the scattering run")
         super()._load_inputs()
         U, c = self.U, self.cloud
         if U.INTOBS[0] > -10000.0:

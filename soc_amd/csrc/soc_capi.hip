@@ -37,6 +37,8 @@ struct soc_ctx {
     float2 *dOPT = nullptr;
     float *dEMIT = nullptr, *dEMWEI = nullptr;
     bool   have_emit = false;
+    float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
+    bool   have_hpbg = false, hpbg_weighted = false;
     // tallies
     float *dTABS = nullptr, *dINT = nullptr;
     bool   own_TABS = false, own_INT = false;
@@ -134,7 +136,7 @@ void soc_destroy(soc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dPSPOS, c->dPS,
-                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE,
+                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -343,6 +345,7 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     S.ABS = c->ABS; S.SCA = c->SCA; S.BG = BG; S.TW = TW;
     S.CSC = c->dCSC; S.OPT = c->dOPT;
     S.EMIT = c->dEMIT; S.EMWEI = c->dEMWEI;
+    S.HPBG = c->dHPBG; S.HPBGP = c->dHPBGP; S.HPBG_WEIGHTED = c->hpbg_weighted ? 1 : 0;
     S.TABS = c->dTABS; S.INT = c->dINT;
     S.stats = c->dStats;
     V.octree = c->G.LEVELS > 1;
@@ -433,6 +436,49 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     HIPCHK(c, soc_launch_sim_pb(c->G, S, V, c->stream));
+    return SOC_OK;
+}
+
+int soc_set_hpbg(soc_ctx *c, const float *BG, const float *HPBGP)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!BG) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: BG is NULL");
+    const int NPIX = 49152;                                 // NSIDE = 64, fixed in the reference (ASOC.py:297)
+    for (int i = 0; i < NPIX; i++)
+        if (!std::isfinite(BG[i])) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: BG[%d] is not finite", i);
+    if (HPBGP) {
+        // the pixel search relies on a non-decreasing table that ends above every random number (ASOC.py:1208)
+        for (int i = 1; i < NPIX; i++)
+            if (!(HPBGP[i] >= HPBGP[i - 1])) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: HPBGP decreases at pixel %d", i);
+        if (!(HPBGP[NPIX - 1] >= 1.0f)) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: HPBGP[last]=%g must be >= 1", (double)HPBGP[NPIX - 1]);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->dHPBG) {
+        HIPCHK(c, dev_alloc(&c->dHPBG, (size_t)NPIX));
+        HIPCHK(c, dev_alloc(&c->dHPBGP, (size_t)NPIX));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dHPBG, BG, (size_t)NPIX * 4, hipMemcpyHostToDevice, c->stream));
+    if (HPBGP) HIPCHK(c, hipMemcpyAsync(c->dHPBGP, HPBGP, (size_t)NPIX * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_hpbg = true;
+    c->hpbg_weighted = (HPBGP != nullptr);
+    return SOC_OK;
+}
+
+int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    int r = check_launch(c, "soc_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (!c->have_hpbg) return fail(c, SOC_ERR_STATE, "soc_sim_hp: call soc_set_hpbg first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, 1, BATCH, SEED, 0.0f, TW, GLOBAL, gid_first, gid_count);
+    S.NO_PS = 1;
+    c->last_passes = 0;
+    HIPCHK(c, soc_launch_sim_hp(c->G, S, V, c->stream));
     return SOC_OK;
 }
 

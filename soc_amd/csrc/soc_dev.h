@@ -31,6 +31,8 @@ struct SocSim {
     const int    *XPS_NSIDE, *XPS_SIDE;
     const float  *XPS_AREA;
     const float  *EMIT, *EMWEI;
+    int    HPBG_WEIGHTED;      /* SimRAM_HP: pixel chosen by cumulative probability       */
+    const float  *HPBG, *HPBGP; /* [49152] sky (photons per package), cumulative probability */
     float *TABS, *INT;
     unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
 };
@@ -45,6 +47,7 @@ struct SocVariant {
 
 hipError_t soc_launch_sim_pb(const SocGrid &G, const SocSim &S, const SocVariant &V, hipStream_t st);
 hipError_t soc_launch_sim_cl(const SocGrid &G, const SocSim &S, const SocVariant &V, hipStream_t st);
+hipError_t soc_launch_sim_hp(const SocGrid &G, const SocSim &S, const SocVariant &V, hipStream_t st);
 hipError_t soc_launch_parents(const SocGrid &G, int *PAR, hipStream_t st);
 hipError_t soc_launch_seed_probe(uint64_t seed_mul, const uint64_t *tab, uint32_t gid0, uint32_t n,
                                  int ndraw, uint32_t *out_state, uint32_t *out_draws, hipStream_t st);

@@ -82,6 +82,63 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
 }
 
 // ------------------------------------------------------------------------------------
+// SimRAM_HP: background from a Healpix sky map (kernel_ASOC.c:826-1207); the walk is SimRAM_PB's
+// ------------------------------------------------------------------------------------
+
+template <bool OCT, bool DBL, bool ABU, bool WINT>
+__global__ __launch_bounds__(256) void soc_sim_hp_kernel(const SocGrid G, const SocSim S)
+{
+    extern __shared__ float lds[];
+    float *sCSC = lds;
+    int   *sOFF = (int *)(lds + S.BINS);
+    int   *sLC  = sOFF + SOC_MAXL;
+    soc_stage_lds(G, S, sCSC, sOFF, sLC);
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S.gid_count) return;
+    const int id = (int)(S.gid0 + t);                      // logical get_global_id(0)
+    const int AREA = 2 * (G.NX * G.NY + G.NY * G.NZ + G.NZ * G.NX);
+    if (id >= 8 * AREA) return;                            // kernel_ASOC.c:874
+
+    SocWalker<OCT, DBL, ABU, WINT> w;
+    w.rng = soc_seed_stream(S.seed_mul, S.seed_tab, (uint32_t)id);
+    w.ind = -1;  w.level = 0;  w.n_tally = 0;  w.n_scat = 0;
+    w.ux = w.uy = w.uz = 0.0f;  w.px = w.py = w.pz = 0.0f;
+    w.dens = 0.0f;  w.photons = 0.0f;  w.tau = 0.0f;  w.free_path = 0.0f;  w.scat = 0;
+
+
+    int III = 0;
+    int mode = SOC_M_CREATE;
+    while (true) {
+        const bool nobody_steps = (__ballot(mode == SOC_M_STEP) == 0ull);
+        if (soc_service_now(mode == SOC_M_CREATE, nobody_steps)) {
+            if (mode == SOC_M_CREATE) {
+                if (III >= S.BATCH) {
+                    mode = SOC_M_DONE;
+                } else {
+                    soc_hp_create<OCT>(G, S, sOFF, w);
+                    III++;
+                    w.begin_conditioned();
+                    mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+                }
+            }
+        }
+        if (soc_service_now(mode == SOC_M_SCATTER, nobody_steps)) {
+            if (mode == SOC_M_SCATTER) {
+                w.template scatter<false>(S, sCSC, sOFF);
+                mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+            }
+        }
+        if (__ballot(mode != SOC_M_DONE) == 0ull) break;
+        if (mode == SOC_M_STEP) {
+            if (w.template step<false>(G, S, sOFF)) mode = SOC_M_SCATTER;
+            else if (w.ind < 0) mode = SOC_M_CREATE;
+        }
+    }
+    soc_flush_stats(S, w.n_tally, (unsigned int)III, w.n_scat);
+}
+
+// ------------------------------------------------------------------------------------
 // SimRAM_CL: emission from the cells themselves (diffuse field / dust re-emission)
 // ------------------------------------------------------------------------------------
 
@@ -319,6 +376,18 @@ hipError_t soc_launch_sim_pb(const SocGrid &G, const SocSim &S, const SocVariant
     soc_launch_shape(S.gid_count, grid, block);
     const size_t lds = soc_lds_bytes(S);
     SOC_DISPATCH(soc_sim_pb_kernel);
+    return hipGetLastError();
+}
+
+hipError_t soc_launch_sim_hp(const SocGrid &G, const SocSim &S, const SocVariant &Vin, hipStream_t st)
+{
+    if (S.gid_count == 0) return hipSuccess;
+    SocVariant V = Vin;
+    if (!V.octree) V.dbl = 0;
+    dim3 grid, block;
+    soc_launch_shape(S.gid_count, grid, block);
+    const size_t lds = soc_lds_bytes(S);
+    SOC_DISPATCH(soc_sim_hp_kernel);
     return hipGetLastError();
 }
 

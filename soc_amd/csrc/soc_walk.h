@@ -241,6 +241,15 @@ struct SocWalker {
         free_path = -soc_logf(soc_rand(&rng));
     }
 
+    // SimRAM_HP conditions the direction itself, before it picks the entry point
+    // (kernel_ASOC.c:919-922); only the counters and the first free path remain (:950-955)
+    __device__ __forceinline__ void begin_conditioned()
+    {
+        scat = 0;
+        tau  = 0.0f;
+        free_path = -soc_logf(soc_rand(&rng));
+    }
+
     // One pass of the inner loop body (kernel_ASOC.c:565-683).  Returns true when the free
     // path ends inside the cell: the lane is then put back to the state it had at the
     // beginning of the step (what the reference does with ind0/level0/POS0) and the
@@ -521,6 +530,96 @@ __device__ __forceinline__ void soc_pb_create(const SocGrid &G, const SocSim &S,
             }
         }
     }
+}
+
+// Pixel2AnglesRing (kernel_ASOC_aux.c:987-1026): Healpix RING pixel -> (phi, theta)
+__device__ __forceinline__ void soc_pixel2angles_ring(const int nside, const int ipix, float &phi, float &theta)
+{
+    const int   npix = 12 * nside * nside, ipix1 = ipix + 1, nl2 = 2 * nside, nl4 = 4 * nside;
+    const int   ncap = 2 * nside * (nside - 1);
+    const float fact1 = 1.5f * nside, fact2 = 3.0f * nside * nside;
+    if (ipix1 <= ncap) {
+        const float hip = ipix1 / 2.0f, fihip = (float)(int)hip;
+        const int   iring = (int)soc_sqrtf(hip - soc_sqrtf(fihip)) + 1;
+        const int   iphi = ipix1 - 2 * iring * (iring - 1);
+        theta = soc_acosf(1.0f - (float)(iring * iring) / fact2);
+        phi   = ((float)iphi - 0.5f) * SOC_PI / (2.0f * (float)iring);
+    } else if (ipix1 <= nl2 * (5 * nside + 1)) {
+        const int   ip = ipix1 - ncap - 1;
+        const int   iring = (ip / nl4) + nside, iphi = (ip % nl4) + 1;
+        const float fodd = 0.5f * (float)(1 + (iring + nside) % 2);
+        theta = soc_acosf((float)(nl2 - iring) / fact1);
+        phi   = ((float)iphi - fodd) * SOC_PI / (2.0f * (float)nside);
+    } else {
+        const int   ip = npix - ipix1 + 1;
+        const float hip = ip / 2.0f, fihip = (float)(int)hip;
+        const int   iring = (int)soc_sqrtf(hip - soc_sqrtf(fihip)) + 1;
+        const int   iphi = 4 * iring + 1 - (ip - 2 * iring * (iring - 1));
+        theta = soc_acosf(-1.0f + (float)(iring * iring) / fact2);
+        phi   = ((float)iphi - 0.5f) * SOC_PI / (2.0f * (float)iring);
+    }
+}
+
+// Healpix pixel of the next background packet (kernel_ASOC.c:881-902): uniform, or bisection
+// (n_bisect halvings + linear scan) on the cumulative probability HPBGP
+__device__ __forceinline__ int soc_hp_select_pixel(const SocSim &S, soc_rng_t *rng, int n_bisect)
+{
+    int ind;
+    if (S.HPBG_WEIGHTED < 1) {
+        ind = (int)soc_floorf(soc_rand(rng) * 49152);
+        ind = ind < 0 ? 0 : (ind > 49151 ? 49151 : ind);
+    } else {
+        const float x = soc_rand(rng);
+        int ind0 = 0, level0 = 49151;
+        for (int i = 0; i < n_bisect; i++) {
+            ind = (ind0 + level0) / 2;
+            if (S.HPBGP[ind] > x) level0 = ind;
+            else                  ind0 = ind;
+        }
+        for (ind = ind0; ind <= level0; ind++) {
+            if (S.HPBGP[ind] >= x) break;
+        }
+        ind = ind > 49151 ? 49151 : ind;          // the host guarantees HPBGP[49151] > 1; never read past the map
+    }
+    return ind;
+}
+
+// Creation of a SimRAM_HP packet (kernel_ASOC.c:878-947): direction from the sky pixel, entry
+// face chosen with probability proportional to |DIR_i|, uniform position on that face.
+template <bool OCT, typename W>
+__device__ __forceinline__ void soc_hp_create(const SocGrid &G, const SocSim &S, const int *sOFF, W &w)
+{
+    const int NX = G.NX, NY = G.NY, NZ = G.NZ;
+    const int pix = soc_hp_select_pixel(S, &w.rng, 10);
+    w.photons = S.HPBG[pix];
+    float phi, theta, st, ct, sp, cp;
+    soc_pixel2angles_ring(64, pix, phi, theta);
+    soc_sincosf(theta, &st, &ct);
+    soc_sincosf(phi, &sp, &cp);
+    w.ux = +st * cp;
+    w.uy = +st * sp;
+    w.uz = -ct;
+    if (soc_fabsf(w.ux) < SOC_DEPS) w.ux = SOC_DEPS;
+    if (soc_fabsf(w.uy) < SOC_DEPS) w.uy = SOC_DEPS;
+    if (soc_fabsf(w.uz) < SOC_DEPS) w.uz = SOC_DEPS;
+    soc_normalize(w.ux, w.uy, w.uz);
+    float x = soc_fabsf(w.ux), y = soc_fabsf(w.uy), z = soc_fabsf(w.uz);
+    float ds = x + y + z;
+    x /= ds;  y /= ds;  z /= ds;
+    ds = soc_rand(&w.rng);
+    const float v1 = soc_rand(&w.rng), v2 = soc_rand(&w.rng);
+    if (ds < x) {
+        w.py = v1 * NY;  w.pz = v2 * NZ;
+        w.px = (w.ux > 0.0f) ? SOC_PEPS : (NX - SOC_PEPS);
+    } else if (ds < (x + y)) {
+        w.px = v1 * NX;  w.pz = v2 * NZ;
+        w.py = (w.uy > 0.0f) ? SOC_PEPS : (NY - SOC_PEPS);
+    } else {
+        w.px = v1 * NX;  w.py = v2 * NY;
+        w.pz = (w.uz > 0.0f) ? SOC_PEPS : (NZ - SOC_PEPS);
+    }
+    (void)z;
+    soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
 }
 
 #endif  // SOC_WALK_H

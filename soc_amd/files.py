@@ -253,3 +253,24 @@ def read_outcoming(filename, NDIR):
     FFREQ = np.fromfile(filename, np.float32, nfreq, offset=12)
     data = np.fromfile(filename, np.float32, offset=12 + 4 * int(nfreq))
     return FFREQ, data.reshape(int(nfreq), NDIR, int(ny), int(nx))
+
+
+def hpbg_for_frequency(sky, scale, weighted):
+    """Device arrays of the Healpix background for one frequency (ASOC.py:1196-1214): sky[49152]
+    (file units x user scaling) -> photons per package BG = scale*sky, and with `weighted`
+    the cumulative pixel probability HPBGP (pixels chosen in proportion to their clipped
+    intensity, the packet weight corrected by HPBGW).  Returns (BG, HPBGP or None), or None
+    for an empty sky in weighted mode."""
+    sky = np.asarray(sky, np.float32)
+    if not weighted:
+        return np.asarray(np.float32(scale) * sky, np.float32), None
+    tmp = np.asarray(sky, np.float64)
+    if np.max(tmp) < 1.0e-40:
+        return None
+    tmp = tmp / np.mean(tmp)
+    tmp = np.clip(tmp, 1.0e-3, 1.0e4)
+    tmp /= np.sum(tmp)
+    HPBGW = (1.0 / 49152.0) / tmp
+    HPBGP = np.cumsum(tmp)
+    HPBGP[-1] = 1.00001
+    return np.asarray(scale * sky * HPBGW, np.float32), np.asarray(HPBGP, np.float32)

@@ -65,6 +65,19 @@ def bg_launch(BGPAC, AREA):
     return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
 
 
+def hpbg_launch(BGPAC, NX, NY, NZ):
+    """Healpix background (ASOC.py:1050-1059): 100 packets per work item, no systematic
+    traversal of surface elements.  Work items with id >= 8*AREA return at once in the kernel
+    (kernel_ASOC.c:874) while the weight counts them -- kept as in the reference.
+    Returns dict(GLOBAL, BATCH, PACKETS, WBG)."""
+    BATCH = 100
+    GLOBAL = Fix(BGPAC / BATCH, 64)
+    PACKETS = GLOBAL * BATCH
+    WBG = np.pi / PLANCK
+    WBG /= (GLOBAL * BATCH) / (2 * (NX * NY + NX * NZ + NY * NZ))
+    return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
+
+
 def cl_launch(PAC, CELLS, GLOBAL=GLOBAL_0):
     """Cell emission: diffuse (ASOC.py:1086-1090) or dust re-emission (ASOC.py:1640).
     Returns dict(GLOBAL, BATCH, PACKETS)."""

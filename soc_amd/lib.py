@@ -38,6 +38,8 @@ API = {
                              _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
     "soc_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int]),
+    "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
+    "soc_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_set_view": (C.c_int, [C.c_void_p, C.c_int, _F, _F, _F, C.c_int, C.c_int, C.c_float, _F, C.c_int]),
     "soc_sca_zero": (C.c_int, [C.c_void_p]),
     "soc_sca_sim_ps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, _F, _F, C.c_int, _I, _I, _F,
@@ -216,6 +218,20 @@ class Engine:
         gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
         self._chk(self.lib.soc_sim_cl(self.h, int(SOURCE), int(PACKETS), int(BATCH), np.float32(SEED),
                                       np.float32(TW), int(GLOBAL), int(gid_first), int(gid_count)))
+
+    def set_hpbg(self, BG, HPBGP=None):
+        """Healpix sky of the current frequency (49152 pixels, photons per package); HPBGP = cumulative
+        pixel probability for weighted sampling."""
+        BG = np.ascontiguousarray(BG, np.float32)
+        HPBGP = None if HPBGP is None else np.ascontiguousarray(HPBGP, np.float32)
+        if BG.size != 49152 or (HPBGP is not None and HPBGP.size != 49152):
+            raise SocError("set_hpbg: the sky map must hold 49152 pixels (NSIDE 64)")
+        self._chk(self.lib.soc_set_hpbg(self.h, _f(BG), _f(HPBGP)))
+
+    def sim_hp(self, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sim_hp(self.h, int(PACKETS), int(BATCH), np.float32(SEED), np.float32(TW), int(GLOBAL),
+                                      int(gid_first), int(gid_count)))
 
     # ---- scattered-light images (ASOCS) ----
     @staticmethod

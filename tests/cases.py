@@ -46,8 +46,29 @@ def _emwei(cloud, seed=5):
     return rr.uniform(0, 3, cloud.CELLS).astype(np.float32)
 
 
+def hp_sky(seed=8, weighted=False):
+    """Synthetic Healpix sky (NSIDE 64) in photons per package; with weighted=True the pair
+    (BG*weight, cumulative probability) the host prepares at ASOC.py:1198-1211."""
+    sky = np.random.default_rng(seed).lognormal(0, 1, 49152).astype(np.float32)
+    if not weighted:
+        return sky, None
+    tmp = np.asarray(sky, np.float64)
+    tmp = tmp / tmp.mean()
+    tmp = np.clip(tmp, 1.0e-3, 1.0e4)
+    tmp /= tmp.sum()
+    W = (1.0 / 49152.0) / tmp
+    P = np.cumsum(tmp)
+    P[-1] = 1.00001
+    return np.asarray(sky * W, np.float32), np.asarray(P, np.float32)
+
+
+def _hpjob(cloud, ref_weighted, **kw):
+    bg, P = hp_sky(weighted=ref_weighted)
+    return Job(cloud, _CSC, ABS=1e-4, SCA=3e-4, HPBG=bg, HPBGP=P, **kw)
+
+
 CASES = {
-    # name: (ref build, kind, job factory)
+    # name: (ref build, kind, job factory); kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_HP
     "bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=50, SEED=0.6004384)),
     "bg_c8_thin": ("c8", 0, lambda: Job(_c8(), _CSC0, ABS=1e-7, SCA=2e-7, SOURCE=1, BATCH=20, SEED=0.25, BG=3.0)),
     "bg_c8_int": ("c8int", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=20, SEED=0.123,
@@ -74,6 +95,10 @@ CASES = {
     "cl_oct8_emw": ("oct8emw", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9,
                                                 GLOBAL=128, EMIT=_emit(_oct8()), EMWEI=_emwei(_oct8()),
                                                 USE_EMWEIGHT=1)),
+    "hp_c8": ("c8", 2, lambda: _hpjob(_c8(), False, BATCH=10, SEED=0.37, TW=1.5, GLOBAL=3072 + 64)),
+    "hp_c8_weighted": ("c8hpw", 2, lambda: _hpjob(_c8(), True, BATCH=10, SEED=0.37, TW=1.5, GLOBAL=3072)),
+    "hp_oct8_weighted_int": ("oct8hpw", 2, lambda: _hpjob(_oct8(), True, BATCH=6, SEED=0.11, TW=1.5, GLOBAL=3072, WITH_INT=1)),
+    "hp_oct8": ("oct8", 2, lambda: _hpjob(_oct8(), False, BATCH=6, SEED=0.11, GLOBAL=3072)),
     "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
                                      EMIT=_emit(_c8()))),
 }

@@ -61,6 +61,16 @@ class OracleEngine:
         _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n
 
+    def set_hpbg(self, BG, HPBGP=None):
+        self.HPBG, self.HPBGP = np.asarray(BG, np.float32).copy(), None if HPBGP is None else np.asarray(HPBGP, np.float32).copy()
+
+    def sim_hp(self, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
+        job = self._job(1, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
+        job.HPBG, job.HPBGP = self.HPBG, self.HPBGP
+        gid_count = GLOBAL - gid_first if gid_count is None else gid_count
+        _, _, n = self.orc.sim(job, 2, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        self.events += n
+
     def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
         job = self._job(SOURCE, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count

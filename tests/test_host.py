@@ -187,6 +187,43 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("mirror xX\n", "split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n", "hpbg sky.bin\n"):
+    for extra in ("mirror xX\n", "split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
+
+
+def test_healpix_background_block(tmp_path):
+    """hpbg runs: launch size and weight of ASOC.py:1050-1059, per-frequency sky arrays of
+    ASOC.py:1196-1214, SimRAM_HP launch -- re-derived here for one frequency."""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(6, seed=4)
+    sky = np.random.default_rng(3).lognormal(0, 1, (3, 49152)).astype(np.float32) * 1e-13
+    sky.tofile(os.path.join(d, "sky.bin"))
+    for weighted in (0, 1):
+        ini = _write_model(d, cloud, extra="hpbg %s/sky.bin 2.0 %d\nbgpackets 60000\n" % (d, weighted))
+        run = AbsorptionRun(User(ini), OracleEngine("soc"))
+        os.chdir(d)
+        CTABS, FABS = run.run()
+        L = launch.hpbg_launch(run.BGPAC, 6, 6, 6)
+        assert L["BATCH"] == 100 and L["GLOBAL"] == launch.Fix(run.BGPAC / 100, 64)
+        assert np.isclose(L["WBG"], np.pi / launch.PLANCK / (L["GLOBAL"] * 100 / 216.0))
+        FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+        FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 3, 500)
+        T = np.zeros(cloud.CELLS, np.float32)
+        for i in range(3):
+            s = np.float32(2.0) * sky[i]
+            if weighted:
+                p = np.clip(s.astype(np.float64) / s.astype(np.float64).mean(), 1e-3, 1e4)
+                p /= p.sum()
+                bg = (L["WBG"] / float(FFREQ[i]) * s * ((1.0 / 49152.0) / p)).astype(np.float32)
+                P = np.cumsum(p)
+                P[-1] = 1.00001
+                P = P.astype(np.float32)
+            else:
+                bg, P = (np.float32(L["WBG"] / float(FFREQ[i])) * s).astype(np.float32), None
+            job = Job(cloud, FCSC[0, i], ABS=AFABS[0][i], SCA=AFSCA[0][i], BATCH=100, SEED=launch.launch_seed(math.pi / 4, i),
+                      TW=launch.trapezoid_weight(FFREQ, i), GLOBAL=L["GLOBAL"], HPBG=bg, HPBGP=P, WITH_INT=1)
+            Oracle("soc").sim(job, 2, TABS=T, INT=np.zeros(cloud.CELLS, np.float32))
+        assert np.array_equal(CTABS, T) and T.sum() > 0

@@ -21,6 +21,9 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
         eng.sim_pb(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.BG, job.TW,
                    PSPOS=job.PSPOS[:, :3], PS=job.PS, XPS=xps, GLOBAL=job.GLOBAL,
                    gid_first=gid_first, gid_count=gid_count)
+    elif kind == 2:
+        eng.set_hpbg(job.HPBG, job.HPBGP)
+        eng.sim_hp(job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
     else:
         eng.set_emission(job.EMIT, job.EMWEI)
         eng.sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL,
