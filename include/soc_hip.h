@@ -56,6 +56,10 @@ int soc_set_grid(soc_ctx *ctx, int NX, int NY, int NZ, int LEVELS, const int32_t
  *   use_emweight : USE_EMWEIGHT 0 or 1 (SimRAM_CL)                                         */
 int soc_set_features(soc_ctx *ctx, int with_int, int ps_method, int use_emweight);
 
+/* replaces -D MIRROR=%d (ASOC.py:319-321,352; ASOCS.py:119-122): reflecting model faces, bits
+ * x,X,y,Y,z,Z = 1,2,4,8,16,32 (lower/upper face per axis); 0 = none (default) */
+int soc_set_mirror(soc_ctx *ctx, int mask);
+
 /* how launches are executed (no counterpart in the reference; results are the same packets):
  *   mode 0  direct: one lane per work item, one global float atomic per tally event
  *   mode 1  brick sweep: packets sorted by brick of 2^brick_log2 root cells per edge, tallies

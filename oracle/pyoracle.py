@@ -37,7 +37,7 @@ class OrcModel(C.Structure):
         ("NDIR", C.c_int), ("NPIX_X", C.c_int), ("NPIX_Y", C.c_int), ("FFS", C.c_int),
         ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
         ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("DSC", _F), ("OUT", _F), ("XPS_AS_FLOAT", C.c_int),
-        ("HPBG_WEIGHTED", C.c_int), ("HPBG", _F), ("HPBGP", _F),
+        ("HPBG_WEIGHTED", C.c_int), ("HPBG", _F), ("HPBGP", _F), ("MIRROR", C.c_int),
     ]
 
 
@@ -63,8 +63,9 @@ class Job:
 
     def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
                  GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
-                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None):
+                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None, MIRROR=0):
         self.cloud = cloud
+        self.MIRROR = int(MIRROR)
         # Healpix sky (NSIDE 64, RING) in photons per package; HPBGP given = weighted pixel selection
         self.HPBG = None if HPBG is None else np.ascontiguousarray(HPBG, np.float32)
         self.HPBGP = None if HPBGP is None else np.ascontiguousarray(HPBGP, np.float32)
@@ -162,6 +163,7 @@ class Oracle:
         m.PSPOS, m.PS = _fp(job.PSPOS), _fp(job.PS)
         m.XPS_NSIDE, m.XPS_SIDE, m.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         m.EMIT, m.EMWEI = _fp(job.EMIT), _fp(job.EMWEI)
+        m.MIRROR = job.MIRROR
         m.HPBG_WEIGHTED = int(job.HPBGP is not None)
         m.HPBG, m.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
         return m
@@ -261,6 +263,7 @@ class Ref:
         assert job.WITH_INT == int(m.get("NOABSORBED", 1) == 0 or m.get("SAVE_INTENSITY", 0) in (1, 2))
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1))
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
+        assert job.MIRROR == m.get("MIRROR", 0)
 
     def seed(self, SEED, gid):
         x, c = C.c_uint32(), C.c_uint32()
@@ -496,6 +499,7 @@ class RefSca:
         assert job.BINS == m.get("BINS", 2500) and view.FFS == m.get("FFS", 1)
         assert int(job.OPT is not None) == m.get("WITH_ABU", 0) and job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1)) and job.PS_METHOD == m.get("PS_METHOD", 0)
+        assert job.MIRROR == m.get("MIRROR", 0)
         PAR = np.zeros(max(1, cl.CELLS - cl.NX * cl.NY * cl.NZ), np.int32)
         self.lib.ref_sca_parents(_fp(job.DENS), _ip(job.LCELLS), _ip(job.OFF), _ip(PAR))
         OUT = np.zeros(view.out_size(), np.float32) if OUT is None else OUT

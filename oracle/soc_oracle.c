@@ -107,6 +107,7 @@ typedef struct {
     int   HPBG_WEIGHTED;
     const float *HPBG;                /* [49152] photons per package                      */
     const float *HPBGP;               /* [49152] cumulative pixel probability (weighted)  */
+    int   MIRROR;                     /* bit mask x,X,y,Y,z,Z = 1,2,4,8,16,32 (ASOC.py:319-321) */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -345,6 +346,22 @@ static inline void tally(const orc_model *M, float *buf, int oind, float v)
  * (PB) and :1409-1676 (CL).  cl_order selects the CL kernel's placement of the
  * scatterings>20 test (before the scatter tally, kernel_ASOC.c:1545-1551) instead of the
  * PB placement (after Scatter(), :802-804).  Returns the number of tally events. */
+#define EPS_MIRROR 5.0e-4f      /* EPS, kernel_ASOC_aux.c:111 */
+
+/* Mirror (kernel_ASOC_aux.c:1050-1083), called with ind<0.  As written in the reference the
+ * direction flip is outside the if-statement (no braces): every enabled face flips its
+ * component whenever the function runs, whichever face the packet left through. */
+static void Mirror(const orc_model *M, f3 *pos, f3 *dir, int *level, int *ind)
+{
+    const int MIRROR = M->MIRROR;
+    if (MIRROR & 1)  { if (pos->x < 0.0f)  pos->x = EPS_MIRROR;          dir->x = -dir->x;  IndexG(M, pos, level, ind); }
+    if (MIRROR & 2)  { if (pos->x > M->NX) pos->x = M->NX - EPS_MIRROR;  dir->x = -dir->x;  IndexG(M, pos, level, ind); }
+    if (MIRROR & 4)  { if (pos->y < 0.0f)  pos->y = EPS_MIRROR;          dir->y = -dir->y;  IndexG(M, pos, level, ind); }
+    if (MIRROR & 8)  { if (pos->y > M->NY) pos->y = M->NY - EPS_MIRROR;  dir->y = -dir->y;  IndexG(M, pos, level, ind); }
+    if (MIRROR & 16) { if (pos->z < 0.0f)  pos->z = EPS_MIRROR;          dir->z = -dir->z;  IndexG(M, pos, level, ind); }
+    if (MIRROR & 32) { if (pos->z > M->NZ) pos->z = M->NZ - EPS_MIRROR;  dir->z = -dir->z;  IndexG(M, pos, level, ind); }
+}
+
 static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS,
                         int level, int ind, int cl_order)
 {
@@ -401,6 +418,7 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
                     steps += 1;
                 }
             }
+            if ((M->MIRROR > 0) && (ind < 0)) Mirror(M, &POS, &DIR, &level, &ind);   /* :686-688, :1064, :1540 */
         }
         if (ind < 0) break;
         /* scatter */
@@ -906,6 +924,7 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
                 break;
             }
             tau += dtau;
+            if ((M->MIRROR > 0) && (ind < 0)) Mirror(M, &POS, &DIR, &level, &ind);   /* kernel_ASOC_sca.c:983, :1283, :1781 */
         }
         if (ind < 0) break;
         scatterings++;

@@ -42,8 +42,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("stepweight")
     if USER.DIR_WEIGHT[0] > 0:
         bad.append("direweight")
-    if USER.MIRROR:
-        bad.append("mirror")
     if USER.WITH_ROI_SAVE or USER.WITH_ROI_LOAD:
         bad.append("roisave/roiload")
     if USER.SAVE_INTENSITY == 2:
@@ -138,6 +136,7 @@ class AbsorptionRun:
         e, c, U = self.eng, self.cloud, self.U
         e.set_cloud(c)
         e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(U.USE_EMWEIGHT, 1))
+        e.set_mirror(launch.mirror_mask(U.MIRROR))
         if self.comm:
             self.comm.attach(e, c.CELLS)
 

@@ -70,6 +70,7 @@ class ScatteringRun(AbsorptionRun):
         e, c, U = self.eng, self.cloud, self.U
         e.set_cloud(c)
         e.set_features(with_int=0, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 1))
+        e.set_mirror(launch.mirror_mask(U.MIRROR))
         e.sca_set_view(self.ODIR, self.RA, self.DE, U.NPIX, U.MAP_DX, U.MAPCENTRE, U.FFS)
         if self.comm:
             self.comm.attach_image(e, self.NDIR * U.NPIX[0] * U.NPIX[1])

@@ -51,7 +51,7 @@ struct soc_ctx {
     uint64_t *dSeedTab = nullptr;
     unsigned long long *dStats = nullptr;
     // features
-    int with_int = 0, ps_method = 0, use_emweight = 0;
+    int with_int = 0, ps_method = 0, use_emweight = 0, mirror = 0;
     // execution
     int exec_mode = -1, brick_log2 = 4, last_passes = 0;
     // A2E
@@ -229,6 +229,14 @@ int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
     return SOC_OK;
 }
 
+int soc_set_mirror(soc_ctx *c, int mask)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (mask < 0 || mask > 63) return fail(c, SOC_ERR_ARG, "soc_set_mirror: mask %d (bits x,X,y,Y,z,Z = 1,2,4,8,16,32)", mask);
+    c->mirror = mask;
+    return SOC_OK;
+}
+
 int soc_set_exec(soc_ctx *c, int mode, int brick_log2)
 {
     if (!c) return SOC_ERR_ARG;
@@ -339,7 +347,7 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
 {
     memset(&S, 0, sizeof S);
     S.SOURCE = SOURCE; S.BATCH = BATCH; S.GLOBAL = GLOBAL;
-    S.PS_METHOD = c->ps_method; S.BINS = c->BINS; S.USE_EMWEIGHT = c->use_emweight;
+    S.PS_METHOD = c->ps_method; S.BINS = c->BINS; S.USE_EMWEIGHT = c->use_emweight; S.MIRROR = c->mirror;
     S.gid0 = (uint32_t)gid_first; S.gid_count = (uint32_t)gid_count;
     S.seed_mul = soc_seed_mul(SEED); S.seed_tab = c->dSeedTab;
     S.ABS = c->ABS; S.SCA = c->SCA; S.BG = BG; S.TW = TW;
@@ -426,10 +434,10 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     // brick sweep: Cartesian grids with enough work items to fill the chip
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && !V.octree && nb <= 8192 && c->device < 16;
+    bool bricks = (c->exec_mode != 0) && !V.octree && nb <= 8192 && c->device < 16 && c->mirror == 0;
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8;
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (octree or > 8192 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (octree, mirror or > 8192 bricks)");
     if (bricks) {
         hipError_t e = soc_brick_run_pb(c->device, c->G, S, V, c->brick_log2, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));

@@ -20,6 +20,7 @@ struct SocGrid {
 // One launch of SimRAM_PB / SimRAM_CL (argument lists: kernel_ASOC.c:15-52, 1223-1256).
 struct SocSim {
     int   SOURCE, BATCH, GLOBAL, PS_METHOD, NO_PS, BINS, USE_EMWEIGHT;
+    int   MIRROR;              /* reflecting faces x,X,y,Y,z,Z = 1,2,4,8,16,32 (ASOC.py:319-321) */
     uint32_t gid0, gid_count;  /* this device runs logical work items [gid0, gid0+gid_count) */
     uint64_t seed_mul;         /* BASEID * A^base mod M for this SEED                     */
     const uint64_t *seed_tab;  /* 4 x 256 table of G^(b*256^k), see soc_rng.h             */

@@ -22,7 +22,7 @@
 //    (as 0): analytic Henyey-Greenstein g=0.65 and the factor (1-exp(-tau)), DSC unused (:1387-1392);
 //  * SimRAM_PS: W=-expm1(-tau) and an fp32 logarithm for the forced free path (:1737-1742); PB/CL
 //    evaluate log(1.0-W*u) in fp64 (:906, :1256);
-//  * the XPS_* type mismatch is resolved on the host (soc_capi.hip, soc_sca_effective_xps).
+//  * the XPS_* type mismatch is resolved on the host (soc_capi.hip: upload_sources).
 #include "soc_walk.h"
 
 enum { SCA_M_FFS = 0, SCA_M_MAIN = 1, SCA_M_PEEL = 2,                 // stepping modes
@@ -283,6 +283,8 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                     mode = SCA_M_SCAT;
                 } else {
                     tau += dtau;
+                    if ((S.MIRROR > 0) && (w.ind < 0))       // kernel_ASOC_sca.c:983, :1283, :1781
+                        soc_mirror<OCT>(G, sOFF, S.MIRROR, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
                     if (w.ind < 0) mode = SCA_M_CREATE;
                 }
             }

@@ -221,6 +221,22 @@ __device__ __forceinline__ void soc_surface(const SocGrid &G, float &px, float &
 // per-lane packet state and the cell step
 // ------------------------------------------------------------------------------------
 
+// Mirror (kernel_ASOC_aux.c:1050-1083), for a packet that has just left the grid (ind < 0).
+// As written in the reference the direction flip sits outside the if-statement: every enabled
+// face flips its component each time the function runs.  Kept.
+#define SOC_EPS_MIRROR 5.0e-4f
+template <bool OCT>
+__device__ __forceinline__ void soc_mirror(const SocGrid &G, const int *sOFF, int MIRROR, float &px, float &py, float &pz,
+                                           float &ux, float &uy, float &uz, int &level, int &ind, float &dens)
+{
+    if (MIRROR & 1)  { if (px < 0.0f) px = SOC_EPS_MIRROR;         ux = -ux;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+    if (MIRROR & 2)  { if (px > G.NX) px = G.NX - SOC_EPS_MIRROR;  ux = -ux;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+    if (MIRROR & 4)  { if (py < 0.0f) py = SOC_EPS_MIRROR;         uy = -uy;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+    if (MIRROR & 8)  { if (py > G.NY) py = G.NY - SOC_EPS_MIRROR;  uy = -uy;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+    if (MIRROR & 16) { if (pz < 0.0f) pz = SOC_EPS_MIRROR;         uz = -uz;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+    if (MIRROR & 32) { if (pz > G.NZ) pz = G.NZ - SOC_EPS_MIRROR;  uz = -uz;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
+}
+
 template <bool OCT, bool DBL, bool ABU, bool WINT>
 struct SocWalker {
     float px, py, pz, ux, uy, uz;
@@ -292,6 +308,8 @@ struct SocWalker {
                 pz += SOC_PEPS * uz;
             }
         }
+        if ((S.MIRROR > 0) && (ind < 0))                     // kernel_ASOC.c:686-688, :1064, :1540
+            soc_mirror<OCT>(G, sOFF, S.MIRROR, px, py, pz, ux, uy, uz, level, ind, dens);
         return false;
     }
 

@@ -112,6 +112,13 @@ def shard_range(GLOBAL, rank, world):
     return first, last - first
 
 
+def mirror_mask(MIRROR):
+    """`mirror xXyYzZ` -> bit mask of reflecting faces (ASOC.py:319-321)"""
+    MIRROR = MIRROR or ""
+    return (1 * ('x' in MIRROR) + 2 * ('X' in MIRROR) + 4 * ('y' in MIRROR) + 8 * ('Y' in MIRROR)
+            + 16 * ('z' in MIRROR) + 32 * ('Z' in MIRROR))
+
+
 def set_observer_directions(OBS_THETA, OBS_PHI):
     """Observer directions and image axes (ASOC_aux.py:1129-1183): for every (theta, phi)
     [rad] the unit vector towards the observer ODIR and the map axes RA (increases to the

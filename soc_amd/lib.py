@@ -38,6 +38,7 @@ API = {
                              _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
     "soc_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int]),
+    "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
     "soc_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_set_view": (C.c_int, [C.c_void_p, C.c_int, _F, _F, _F, C.c_int, C.c_int, C.c_float, _F, C.c_int]),
@@ -155,6 +156,10 @@ class Engine:
 
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self._chk(self.lib.soc_set_features(self.h, int(with_int), int(ps_method), int(use_emweight)))
+
+    def set_mirror(self, mask=0):
+        """reflecting faces, bits x,X,y,Y,z,Z = 1,2,4,8,16,32"""
+        self._chk(self.lib.soc_set_mirror(self.h, int(mask)))
 
     def set_exec(self, mode=-1, brick_log2=4):
         """0 direct kernel, 1 brick sweep (LDS tallies), -1 automatic."""

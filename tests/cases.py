@@ -99,6 +99,12 @@ CASES = {
     "hp_c8_weighted": ("c8hpw", 2, lambda: _hpjob(_c8(), True, BATCH=10, SEED=0.37, TW=1.5, GLOBAL=3072)),
     "hp_oct8_weighted_int": ("oct8hpw", 2, lambda: _hpjob(_oct8(), True, BATCH=6, SEED=0.11, TW=1.5, GLOBAL=3072, WITH_INT=1)),
     "hp_oct8": ("oct8", 2, lambda: _hpjob(_oct8(), False, BATCH=6, SEED=0.11, GLOBAL=3072)),
+    # reflecting faces (`mirror` key): mask bits x,X,y,Y,z,Z = 1,2,4,8,16,32
+    "bg_c8_mirror": ("c8mir", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=10, SEED=0.6, MIRROR=25)),
+    "bg_oct8_mirror": ("oct8mir", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=6, SEED=0.61, MIRROR=6)),
+    "cl_oct8_mirror": ("oct8mir", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                  EMIT=_emit(_oct8()), MIRROR=6)),
+    "hp_c8_mirror": ("c8mir", 2, lambda: _hpjob(_c8(), False, BATCH=6, SEED=0.3, GLOBAL=3072, MIRROR=25)),
     "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
                                      EMIT=_emit(_c8()))),
 }
@@ -145,6 +151,11 @@ SCA_CASES = {
     "sca_ps_ext4_c8": ("c8ps4", 2, lambda: _psjob(4, ps=np.array([[4.0, 4.0, 15.0]], np.float32), lum=(1.0,)), {}),
     "sca_ps_ext5_c8": ("c8ps5", 2, lambda: _psjob(5), {}),
     "sca_pbps_ext2_c8": ("c8ps2", 0, lambda: _psjob(2), {}),
+    "sca_bg_c8_mirror": ("c8mir", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=6, SEED=0.6, DSC=_DSC, MIRROR=5), {}),
+    "sca_cl_c8_mirror": ("c8mir", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                  EMIT=_emit(_c8()), DSC=_DSC, MIRROR=5), {}),
+    "sca_ps_c8_mirror": ("c8mir", 2, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256,
+                                                  PSPOS=[[4.3, 4.2, 4.1]], PS=[1.0], DSC=_DSC, MIRROR=5), {}),
     "sca_cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
                                         EMIT=_emit(_c8()), DSC=_DSC), {}),
     "sca_cl_oct8": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,

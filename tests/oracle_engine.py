@@ -26,6 +26,9 @@ class OracleEngine:
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self.feat = dict(with_int=with_int, ps_method=ps_method, use_emweight=use_emweight)
 
+    def set_mirror(self, mask=0):
+        self.mirror = int(mask)
+
     def set_optical(self, ABS, SCA):
         self.ABS, self.SCA = ABS, SCA
 
@@ -52,7 +55,7 @@ class OracleEngine:
                    TW=TW, GLOBAL=GLOBAL, PACKETS=PACKETS, PSPOS=PSPOS if SOURCE == 0 else None,
                    PS=PS if SOURCE == 0 else None, PS_METHOD=self.feat["ps_method"], XPS=XPS if SOURCE == 0 else None,
                    OPT=self.OPT, EMIT=self.EMIT, EMWEI=self.EMWEI, USE_EMWEIGHT=self.feat["use_emweight"],
-                   WITH_INT=self.feat["with_int"], DSC=self.DSC)
+                   WITH_INT=self.feat["with_int"], DSC=self.DSC, MIRROR=getattr(self, "mirror", 0))
 
     def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None, GLOBAL=None,
                gid_first=0, gid_count=None):

@@ -10,7 +10,7 @@ from util import run_engine, assert_tally_close
 
 pytestmark = pytest.mark.gpu
 
-CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n]
+CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n and "mirror" not in n]
 
 
 @pytest.mark.parametrize("name", CART)
@@ -50,3 +50,14 @@ def test_brick_sweep_rejects_octree(engine):
     with pytest.raises(SocError, match="not applicable"):
         run_engine(engine, mk(), kind, exec_mode=1, brick_log2=2)
     engine.set_exec(-1, 4)
+
+
+def test_brick_sweep_refuses_mirror(engine):
+    """reflecting faces are handled by the direct kernel only: forcing the brick sweep is an error,
+    automatic mode falls back"""
+    from soc_amd.lib import SocError
+    ref, kind, mk = cases.CASES["bg_c8_mirror"]
+    with pytest.raises(SocError):
+        run_engine(engine, mk(), kind, exec_mode=1)
+    run_engine(engine, mk(), kind, exec_mode=-1)
+    assert engine.last_passes() == 0

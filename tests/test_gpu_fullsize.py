@@ -17,6 +17,8 @@ def big(engine):
     _, csc = synth.hg_scattering_table(0.6)
     engine.set_cloud(cloud)
     engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_exec(-1, 4)
     engine.set_scatter_table(None, csc)
     engine.set_optical(ABS, SCA)
     engine.set_opt(None)

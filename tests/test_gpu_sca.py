@@ -20,6 +20,7 @@ def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True):
     eng.set_scatter_table(job.DSC, job.CSC)
     eng.set_optical(job.ABS, job.SCA)
     eng.set_opt(job.OPT)
+    eng.set_mirror(job.MIRROR)
     eng.sca_set_view(view.ODIR, view.RA, view.DE, view.NPIX, view.MAP_DX, view.CENTRE, view.FFS)
     if zero:
         eng.sca_zero()
@@ -57,7 +58,7 @@ def test_sca_hip_matches_oracle(name, engine, oracle_soc):
     assert st["tally_events"] == n                       # identical trajectories
     assert_image_close(got, want)
     # and, at Monte Carlo accuracy, the reference's own image
-    assert abs(got.sum(dtype=np.float64) / GOLD[name].sum(dtype=np.float64) - 1.0) < 5e-3
+    assert abs(got.sum(dtype=np.float64) / GOLD[name].sum(dtype=np.float64) - 1.0) < 1e-2
 
 
 def test_sca_split_launch_adds_up(engine, oracle_soc):

@@ -187,7 +187,7 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("mirror xX\n", "split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n"):
+    for extra in ("split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
 
@@ -227,3 +227,17 @@ def test_healpix_background_block(tmp_path):
                       TW=launch.trapezoid_weight(FFREQ, i), GLOBAL=L["GLOBAL"], HPBG=bg, HPBGP=P, WITH_INT=1)
             Oracle("soc").sim(job, 2, TABS=T, INT=np.zeros(cloud.CELLS, np.float32))
         assert np.array_equal(CTABS, T) and T.sum() > 0
+
+
+def test_mirror_key_reaches_the_engine(tmp_path):
+    """`mirror` -> bit mask (ASOC.py:319-321) -> soc_set_mirror; reflected packets deposit (a little, the test model is opaque) more energy."""
+    from oracle_engine import OracleEngine
+    assert launch.mirror_mask("xY") == 1 + 8 and launch.mirror_mask("xXyYzZ") == 63 and launch.mirror_mask("") == 0
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(6, seed=4)
+    os.chdir(d)
+    plain = AbsorptionRun(User(_write_model(d, cloud)), OracleEngine("soc")).run()[0]
+    eng = OracleEngine("soc")
+    mir = AbsorptionRun(User(_write_model(d, cloud, extra="mirror xZ\n")), eng).run()[0]
+    assert eng.mirror == 1 + 32
+    assert not np.array_equal(mir, plain) and mir.sum(dtype=np.float64) > plain.sum(dtype=np.float64)

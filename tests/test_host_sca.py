@@ -121,6 +121,6 @@ def test_scattering_run_refuses_what_it_cannot_do(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("perspective 2 2 2\n", "hpbg sky.bin\n", "mirror xX\n"):
+    for extra in ("perspective 2 2 2\n", "hpbg sky.bin\n", "split 1\n"):
         with pytest.raises(UnsupportedOption):
             ScatteringRun(User(_ini(d, cloud, extra=extra)), OracleEngine("soc"))

@@ -10,6 +10,7 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
     eng.set_scatter_table(job.DSC, job.CSC)
     eng.set_optical(job.ABS, job.SCA)
     eng.set_opt(job.OPT)
+    eng.set_mirror(getattr(job, "MIRROR", 0))
     eng.set_exec(exec_mode, brick_log2)
     if zero:
         eng.zero(0)
