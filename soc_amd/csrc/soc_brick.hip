@@ -9,16 +9,22 @@
 //
 // How: the grid is cut into bricks of B^3 root cells.  In-flight packets (one per logical
 // work item -- a work item's packets are sequential in its RNG stream, so one is in
-// flight at a time) are kept sorted by the brick they are in.  One pass =
-//   soc_brick_step    a workgroup takes a chunk of one brick's queue, keeps the brick's
-//                     tally in LDS (ds_add_f32), walks each packet until it leaves the brick
-//                     (or ends: the work item's next packet is created on the spot), writes
-//                     the packet back with its destination brick, then flushes the brick
-//                     tally with row-contiguous atomics (>= 16x fewer fabric requests);
+// flight at a time) are kept sorted by the queue they wait in: one queue per brick, plus
+// one for work items whose packet has left the cloud and one for packets whose free path
+// has ended.  One pass =
+//   soc_brick_walk    a workgroup takes a chunk of one brick's queue, keeps the brick's
+//                     tally in LDS (ds_add_f32), walks each packet until it leaves the brick,
+//                     leaves the cloud or must scatter, writes it back with its destination
+//                     queue, then flushes the brick tally with row-contiguous atomics;
+//   soc_brick_events  one lane per packet of the two event queues: scattering block, or
+//                     creation of the work item's next packet (all RNG use is here);
 //   soc_brick_scan    exclusive scan of the arrival histogram -> next queue offsets and
 //                     workgroup descriptors (one workgroup, exact sizes, no capacity guess);
 //   soc_brick_scatter counting-sort placement of the packet ids into the next queues.
 // A kernel boundary separates the phases, so no in-launch inter-workgroup hand-off exists.
+// The work items of a launch are split into independent populations, each with its own queues
+// on its own stream: while one population's walk fills the chip, the short latency-bound
+// kernels (events, scan, scatter) of the others run beside it.
 //
 // What does not change: the logical work items, their MWC64X streams, every fp32 operation
 // of a packet's life (same code as soc_walk.h, same operand order).  Trajectories are
@@ -33,24 +39,16 @@
 #define SOC_BRICK_T 256          // threads per workgroup (scatter kernel; step kernel uses A.T)
 #define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk
 
-enum { SOC_BM_STEP = 0, SOC_BM_CREATE = 1, SOC_BM_SCATTER = 2, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
+enum { SOC_BM_STEP = 0, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
 
-struct __align__(16) SocPacket {
-    float px, py, pz, ux;
-    float uy, uz, photons, free_path;
-    float tau, dens;
-    uint32_t rx, rc;
-    int   ind, III;
-    uint32_t misc;               // scat | mode << 8
-    int   lid;                   // tally slot of the current cell inside its brick
-};
+struct __align__(16) SocPk2 { float4 A, B, C; uint4 D; };   // 64-B packet record, see soc_brick_walk
 
 struct SocDesc { int brick, start, count, pad; };
 
 struct SocBrickArgs {
     int LB, NBX, NBY, NBZ, NB;   // brick edge = 1 << LB root cells; NB bricks
     int T, P, KCAP, FTH;         // step-kernel threads, packets per chunk, max steps per packet per pass, fetch threshold
-    SocPacket *pk;
+    SocPk2 *pk;
     const uint32_t *idq;         // current queue (ids sorted by brick)
     uint32_t *idq_next;
     uint32_t *keyq;              // destination brick of every entry of the current queue
@@ -62,7 +60,7 @@ struct SocBrickArgs {
     SocDesc *desc_next;
     int *ndesc_next;
     int *total;                  // packets still in flight after this pass
-    long long *dbg;              // diagnostic build only: 8 timestamps per workgroup (NULL otherwise)
+    int ev_brick;                // scan: first event queue (descriptors from here on belong to soc_brick_events)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -94,98 +92,94 @@ struct SocBrickLane {
     }
 };
 
-__global__ void soc_brick_init(const SocGrid G, const SocSim S, SocBrickArgs A, uint32_t count, uint32_t *idq0,
-                               SocDesc *desc0, int *ndesc0, int *hist)
+
+// ---------------------------------------------------------------------------------------
+// Stepping and events in separate kernels.
+//
+// Measured on the first form of this file (one kernel with creation and scattering as arms of
+// the stepping loop; rocprofv3 SQ counters, C2): 43 % of the lanes of an average VALU
+// instruction active, waves 44 % of their cycles in s_waitcnt, 88 VGPRs.  The lanes idled
+// because creation and scattering -- a few hundred instructions each, needed by ~1 lane in 130
+// per iteration -- were arms of the same loop, and the kernel carried their registers.
+// Here the two rare events are simply two more destinations of the sort the sweep does anyway:
+//   queue NB   : work items whose packet has left the cloud  -> soc_brick_events creates the next
+//   queue NB+1 : packets whose free path ends in their cell  -> soc_brick_events scatters them
+//   queue NB+2 : finished work items (never scheduled)
+// soc_brick_events runs one lane per queued packet at full utilisation and sends every packet
+// to the queue of the brick it is in.  soc_brick_walk is left with one arm (the cell step) plus
+// the swap, no RNG, no tables, and half the registers.
+// Packet record (64 B): A = position, photons | B = direction, free_path | C = tau, density of
+// the current cell, tally slot, cell index | D = RNG state, III | scat << 24, brick.
+// ---------------------------------------------------------------------------------------
+__global__ void soc_brick2_init(const SocSim S, SocBrickArgs A, uint32_t count, uint32_t *idq0, SocDesc *desc0, int *ndesc0, int *hist)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    SocPk2 *pk = A.pk;
     if (t < count) {
-        SocPacket p;
-        soc_rng_t r = soc_seed_stream(S.seed_mul, S.seed_tab, S.gid0 + t);
-        p.px = p.py = p.pz = p.ux = p.uy = p.uz = 0.0f;
-        p.photons = p.free_path = p.tau = p.dens = 0.0f;
-        p.rx = r.x;  p.rc = r.c;
-        p.ind = -1;  p.III = 0;  p.lid = 0;
-        p.misc = (uint32_t)SOC_BM_CREATE << 8;
-        A.pk[t] = p;
+        const soc_rng_t r = soc_seed_stream(S.seed_mul, S.seed_tab, S.gid0 + t);
+        SocPk2 p;
+        p.A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        p.B = p.A;
+        p.C = make_float4(0.0f, 0.0f, __int_as_float(0), __int_as_float(-1));
+        p.D = make_uint4(r.x, r.c, 0u, 0u);
+        pk[t] = p;
         idq0[t] = t;
     }
     const uint32_t nd = (count + A.P - 1) / A.P;
     if (t < nd) {
         SocDesc d;
-        d.brick = -1;
+        d.brick = A.NB;                                    // everybody starts in the creation queue
         d.start = (int)(t * A.P);
         d.count = (int)min((uint32_t)A.P, count - t * A.P);
         d.pad = 0;
         desc0[t] = d;
     }
-    if (t == 0) *ndesc0 = (int)nd;
-    if (t <= (uint32_t)A.NB) hist[t] = 0;
+    if (t == 0) { ndesc0[0] = (int)nd;  ndesc0[2] = 0; }
+    if (t <= (uint32_t)A.NB + 2) hist[t] = 0;
 }
 
-template <bool ABU, bool WINT, bool SD>
-__global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const SocSim S, const SocBrickArgs A)
+template <bool ABU, bool WINT>
+__device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S, const SocBrickArgs &A, const int bid)
 {
-    if ((int)blockIdx.x >= *A.ndesc) return;
-    const SocDesc D = A.desc[blockIdx.x];
+    if (bid >= *A.ndesc) return;
+    const SocDesc D = A.desc[bid];
+    if (D.brick >= A.NB) return;                           // an event queue: soc_brick_events
     const int BV = 1 << (3 * A.LB);
     const int nthr = (int)blockDim.x;
-    long long t0 = 0, t1 = 0, t2 = 0;
-    if (A.dbg) t0 = wall_clock64();
+    SocPk2 *pk = A.pk;
 
     extern __shared__ float lds[];
-    float *sT   = lds;                                   // [BV] TABS of this brick
-    float *sD   = sT + BV;                               // [BV] densities of this brick (SD)
-    float *sI   = sD + (SD ? BV : 0);                    // [BV] INT (WINT)
-    int   *sH   = (int *)(sI + (WINT ? BV : 0));         // [NB+1] arrivals per brick, next pass
-    int   *sCtl = sH + A.NB + 1;                         // [0] next packet, [1..3] stats, [4] = 0 (OFF[0])
+    float *sT   = lds;                                     // [BV] TABS of this brick
+    float *sI   = sT + BV;                                 // [BV] INT (WINT)
+    int   *sH   = (int *)(sI + (WINT ? BV : 0));           // [NB+3] arrivals per queue, next pass
+    int   *sCtl = sH + A.NB + 3;                           // [0] next packet, [1] tally events
     for (int i = threadIdx.x; i < BV; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
-    if (SD) {
-        // stage the brick's densities: no global access is left inside the step loop
-        const int Bq = 1 << A.LB, Mq = Bq - 1;
-        const int bx = D.brick % A.NBX, by = (D.brick / A.NBX) % A.NBY, bz = D.brick / (A.NBX * A.NBY);
-        for (int i = threadIdx.x; i < BV; i += nthr) {
-            float d = 0.0f;
-            if (D.brick >= 0) {
-                const int ix = bx * Bq + (i & Mq), iy = by * Bq + ((i >> A.LB) & Mq), iz = bz * Bq + (i >> (2 * A.LB));
-                if (ix < G.NX && iy < G.NY && iz < G.NZ) d = G.DENS[(iz * G.NY + iy) * G.NX + ix];
-            }
-            sD[i] = d;
-        }
-    }
-    for (int i = threadIdx.x; i <= A.NB; i += nthr) sH[i] = 0;
-    if (threadIdx.x < 5) sCtl[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < A.NB + 3; i += nthr) sH[i] = 0;
+    if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
     __syncthreads();
-    if (A.dbg) t1 = wall_clock64();
 
-    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
-    const float fNX = (float)NX, fNY = (float)NY, fNZ = (float)NZ;
+    const int   NX = G.NX, NY = G.NY;
+    const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
     const int   mybrick = D.brick, LB = A.LB, M = (1 << A.LB) - 1;
-    SocBrickLane w;
-    w.level = 0;  w.ind = -1;  w.scat = 0;
-    w.px = w.py = w.pz = w.ux = w.uy = w.uz = 0.0f;
-    w.photons = w.free_path = w.tau = w.dens = 0.0f;
-    w.rng.x = w.rng.c = 0u;
-    int   mode = SOC_BM_SWAP, next_mode = 0, slot = 0, III = 0, lid = 0, nvisit = 0, key = 0;
+    float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+    float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
+    int   ind = -1, lid = 0, nvisit = 0, key = 0, slot = 0;
+    int   mode = SOC_BM_SWAP;
     bool  have = false;
     uint32_t wid = 0;
-    unsigned int n_tally = 0, n_scat = 0, n_pkt = 0;
-    const int *sOFF0 = sCtl + 4;                          // OFF[0] == 0: Cartesian grids only
+    unsigned int n_tally = 0;
 
     while (true) {
-        bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
-        // ---- swap: write back packets that are through with this brick, take the next ones ----
         {
             const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
+            const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
             if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
                 if (mode == SOC_BM_SWAP) {
                     if (have) {
-                        SocPacket p;
-                        p.px = w.px;  p.py = w.py;  p.pz = w.pz;  p.ux = w.ux;  p.uy = w.uy;  p.uz = w.uz;
-                        p.photons = w.photons;  p.free_path = w.free_path;  p.tau = w.tau;  p.dens = w.dens;
-                        p.rx = w.rng.x;  p.rc = w.rng.c;
-                        p.ind = w.ind;  p.III = III;  p.lid = lid;
-                        p.misc = (uint32_t)(w.scat & 0xff) | ((uint32_t)next_mode << 8);
-                        A.pk[wid] = p;
+                        SocPk2 *q = pk + wid;
+                        q->A = make_float4(px, py, pz, photons);
+                        q->C = make_float4(tau, dens, __int_as_float(lid), __int_as_float(ind));
+                        if (key == A.NB + 1) q->D.w = (uint32_t)mybrick;             // scattering: the brick to come back to
                         A.keyq[D.start + slot] = (uint32_t)key;
                         atomicAdd(&sH[key], 1);
                     }
@@ -195,136 +189,72 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
                         mode = SOC_BM_IDLE;
                     } else {
                         wid = A.idq[D.start + slot];
-                        const SocPacket p = A.pk[wid];
-                        w.px = p.px;  w.py = p.py;  w.pz = p.pz;  w.ux = p.ux;  w.uy = p.uy;  w.uz = p.uz;
-                        w.photons = p.photons;  w.free_path = p.free_path;  w.tau = p.tau;
-                        w.rng.x = p.rx;  w.rng.c = p.rc;
-                        w.ind = p.ind;  III = p.III;  lid = p.lid;
-                        w.scat = (int)(p.misc & 0xffu);
-                        mode = (int)((p.misc >> 8) & 0xffu);
-                        w.dens = SD ? ((mybrick >= 0) ? sD[lid] : 0.0f) : p.dens;
+                        const SocPk2 *q = pk + wid;
+                        const float4 a = q->A, b = q->B, c = q->C;
+                        px = a.x;  py = a.y;  pz = a.z;  photons = a.w;
+                        ux = b.x;  uy = b.y;  uz = b.z;  free_path = b.w;
+                        tau = c.x;  dens = c.y;  lid = __float_as_int(c.z);  ind = __float_as_int(c.w);
                         nvisit = 0;
+                        mode = SOC_BM_STEP;
                     }
                 }
-                nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
-            }
-        }
-        // ---- create the work item's next packet ----
-        if (soc_service_now(mode == SOC_BM_CREATE, nobody_steps)) {
-            if (mode == SOC_BM_CREATE) {
-                if (III >= S.BATCH) {
-                    mode = SOC_BM_SWAP;  key = A.NB;  next_mode = SOC_BM_CREATE;     // work item finished
-                } else {
-                    const int id = (int)(S.gid0 + wid);
-                    const SocSurfElem E = soc_surface_element(G, S, id);
-                    soc_pb_create<false>(G, S, sOFF0, E, III, w);
-                    III++;
-                    n_pkt++;
-                    w.begin();
-                    if (w.ind >= 0) {
-                        int b;
-                        soc_cell_brick(A, w.px, w.py, w.pz, b, lid);
-                        mode = SOC_BM_STEP;
-                        if (b != mybrick) { mode = SOC_BM_SWAP;  key = b;  next_mode = SOC_BM_STEP; }
-                    }                                                        // else: missed the cloud, create again
-                }
-            }
-        }
-        // ---- scattering block ----
-        if (soc_service_now(mode == SOC_BM_SCATTER, nobody_steps)) {
-            if (mode == SOC_BM_SCATTER) {
-                const int oind = w.ind;
-                float kabs, ksca;
-                if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
-                else     { kabs = S.ABS;  ksca = S.SCA; }
-                w.scat++;
-                float dt = w.free_path - w.tau;
-                float dx = dt / (ksca * w.dens);
-                float tauA = dx * w.dens * kabs;
-                float e = soc_expf(-tauA);
-                float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[lid], delta * S.TW);
-                if (WINT) atomicAdd(&sI[lid], delta);
-                n_tally++;
-                n_scat++;
-                dx = soc_scale_up(dx, 0);
-                dx = __builtin_fmaxf(0.0f, dx - 2.0f * SOC_PEPS);
-                w.px = w.px + dx * w.ux;
-                w.py = w.py + dx * w.uy;
-                w.pz = w.pz + dx * w.uz;
-                w.photons *= e;
-                w.free_path = -soc_logf(soc_rand(&w.rng));
-                soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);
-                w.tau = 0.0f;
-                mode = (w.scat > 20) ? SOC_BM_CREATE : SOC_BM_STEP;          // dropped after 20 scatterings
-                if (w.scat > 20) w.ind = -1;
             }
         }
         if (__ballot(mode != SOC_BM_IDLE) == 0ull) break;
         // ---- one cell step (kernel_ASOC.c:565-683, LEVELS == 1) ----
         if (mode == SOC_BM_STEP) {
-            const int   oind = w.ind, lid0 = lid;
-            const float p0x = w.px, p0y = w.py, p0z = w.pz, d0 = w.dens;
+            const int   oind = ind, lid0 = lid;
+            const float p0x = px, p0y = py, p0z = pz, d0 = dens;
             float kabs, ksca;
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
             else     { kabs = S.ABS;  ksca = S.SCA; }
-            float ax = (w.ux > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(w.px)) / w.ux) : ((-SOC_PEPS - soc_fmod1f(w.px)) / w.ux);
-            float ay = (w.uy > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(w.py)) / w.uy) : ((-SOC_PEPS - soc_fmod1f(w.py)) / w.uy);
-            float az = (w.uz > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(w.pz)) / w.uz) : ((-SOC_PEPS - soc_fmod1f(w.pz)) / w.uz);
+            float ax = (ux > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(px)) / ux) : ((-SOC_PEPS - soc_fmod1f(px)) / ux);
+            float ay = (uy > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(py)) / uy) : ((-SOC_PEPS - soc_fmod1f(py)) / uy);
+            float az = (uz > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(pz)) / uz) : ((-SOC_PEPS - soc_fmod1f(pz)) / uz);
             float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
-            w.px += ds * w.ux;
-            w.py += ds * w.uy;
-            w.pz += ds * w.uz;
+            px += ds * ux;
+            py += ds * uy;
+            pz += ds * uz;
             ds = soc_scale_down(ds, 0);
-            // new cell, without branches: inside <=> 0 < p < N on every axis (same outcome as the
-            // reference's "<= 0 || >= N" exit test for every finite position)
-            const bool inside = (w.px > 0.0f) & (w.px < fNX) & (w.py > 0.0f) & (w.py < fNY) & (w.pz > 0.0f) & (w.pz < fNZ);
-            const int ix = inside ? (int)soc_floorf(w.px) : 0;
-            const int iy = inside ? (int)soc_floorf(w.py) : 0;
-            const int iz = inside ? (int)soc_floorf(w.pz) : 0;
+            const bool inside = (px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ);
+            const int ix = inside ? (int)soc_floorf(px) : 0;
+            const int iy = inside ? (int)soc_floorf(py) : 0;
+            const int iz = inside ? (int)soc_floorf(pz) : 0;
             const int nind = iz * NX * NY + iy * NX + ix;
             const int nb   = ((iz >> LB) * A.NBY + (iy >> LB)) * A.NBX + (ix >> LB);
             const int nlid = ((iz & M) << (2 * LB)) | ((iy & M) << LB) | (ix & M);
             const bool stay = inside & (nb == mybrick);
-            float ndens;
-            if (SD) ndens = sD[stay ? nlid : 0];
-            else    ndens = G.DENS[nind];
+            const float ndens = G.DENS[nind];
             const float tauA = ds * d0 * kabs;
             const float dtau = ds * d0 * ksca;
-            if (w.free_path < (w.tau + dtau)) {
-                w.px = p0x;  w.py = p0y;  w.pz = p0z;                        // back to the start of the step
-                mode = SOC_BM_SCATTER;
+            if (free_path < (tau + dtau)) {
+                px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
+                mode = SOC_BM_SWAP;  key = A.NB + 1;                          // -> scattering queue
             } else {
                 const float e = soc_expf(-tauA);
-                const float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
+                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
                 atomicAdd(&sT[lid0], delta * S.TW);
                 if (WINT) atomicAdd(&sI[lid0], delta);
                 n_tally++;
-                w.photons *= e;
-                w.tau += dtau;
-                w.ind = inside ? nind : -1;
-                w.dens = ndens;
+                photons *= e;
+                tau += dtau;
+                ind = inside ? nind : -1;
+                dens = ndens;
                 lid = nlid;
-                const bool failed = (w.ind == oind);                         // failed step: nudge
-                w.px += failed ? (SOC_PEPS * w.ux) : 0.0f;
-                w.py += failed ? (SOC_PEPS * w.uy) : 0.0f;
-                w.pz += failed ? (SOC_PEPS * w.uz) : 0.0f;
+                const bool failed = (ind == oind);                            // failed step: nudge
+                px += failed ? (SOC_PEPS * ux) : 0.0f;
+                py += failed ? (SOC_PEPS * uy) : 0.0f;
+                pz += failed ? (SOC_PEPS * uz) : 0.0f;
                 nvisit++;
-                // out of the cloud -> next packet; out of the brick, or this pass's step budget used
-                // up -> back to the queue of the brick it is in (bounds the pass length)
-                if (!inside)                              mode = SOC_BM_CREATE;
-                else if (!stay || nvisit >= A.KCAP)     { mode = SOC_BM_SWAP;  key = nb;  next_mode = SOC_BM_STEP; }
+                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB; }       // -> creation queue
+                else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = nb; }
             }
         }
     }
 
-    if (A.dbg) t2 = wall_clock64();
-    // ---- flush: brick tally -> global (rows of 1<<LB contiguous cells), histogram, stats ----
     atomicAdd(&sCtl[1], (int)n_tally);
-    atomicAdd(&sCtl[2], (int)n_pkt);
-    atomicAdd(&sCtl[3], (int)n_scat);
     __syncthreads();
-    if (mybrick >= 0) {
+    {
         const int B = 1 << A.LB;
         const int bx = mybrick % A.NBX, by = (mybrick / A.NBX) % A.NBY, bz = mybrick / (A.NBX * A.NBY);
         for (int i = threadIdx.x; i < BV; i += nthr) {
@@ -338,22 +268,128 @@ __global__ __launch_bounds__(1024) void soc_brick_step(const SocGrid G, const So
             }
         }
     }
-    for (int i = threadIdx.x; i <= A.NB; i += nthr) {
+    for (int i = threadIdx.x; i < A.NB + 3; i += nthr) {
         const int c = sH[i];
         if (c) atomicAdd(&A.hist[i], c);
     }
-    if (A.dbg && (threadIdx.x & 63) == 0) {
-        // per wave: loop end; per WG (wave 0): start, init end, end, brick, count, n_tally
-        long long *d = A.dbg + (size_t)blockIdx.x * 24;
-        const int wv = threadIdx.x >> 6;
-        d[8 + wv] = t2;
-        if (wv == 0) { d[0] = t0; d[1] = t1; d[2] = wall_clock64(); d[3] = D.brick; d[4] = D.count; d[5] = sCtl[1]; d[6] = blockDim.x >> 6;
-                       unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); d[7] = xcc; }
+    if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
+}
+
+// creation and scattering, one lane per queued packet
+template <bool ABU, bool WINT>
+__device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim &S, const SocBrickArgs &A, const int ebid, const int slice)
+{
+    // ebid counts from the first event descriptor (event queues sort last);
+    // slice: blockDim.x packets of the chunk -- one packet per lane
+    const int di = A.ndesc[2] + ebid;
+    if (di >= *A.ndesc) return;
+    SocDesc D = A.desc[di];
+    if (D.brick < A.NB) return;
+    {
+        const int first = (int)(slice * blockDim.x);
+        if (first >= D.count) return;
+        D.start += first;
+        D.count = min((int)blockDim.x, D.count - first);
+    }
+    SocPk2 *pk = A.pk;
+    extern __shared__ float lds[];
+    int   *sH   = (int *)lds;                              // [NB+3]
+    int   *sCtl = sH + A.NB + 3;                           // [0..2] stats, [4] = 0 (OFF[0])
+    for (int i = threadIdx.x; i < A.NB + 3; i += blockDim.x) sH[i] = 0;
+    if (threadIdx.x < 8) sCtl[threadIdx.x] = 0;
+    __syncthreads();
+    const int *sOFF0 = sCtl + 4;
+    unsigned int n_tally = 0, n_pkt = 0, n_scat = 0;
+
+    for (int j = threadIdx.x; j < D.count; j += blockDim.x) {
+        const uint32_t wid = A.idq[D.start + j];
+        SocPk2 p = pk[wid];
+        SocBrickLane w;
+        w.level = 0;
+        w.px = p.A.x;  w.py = p.A.y;  w.pz = p.A.z;  w.photons = p.A.w;
+        w.ux = p.B.x;  w.uy = p.B.y;  w.uz = p.B.z;  w.free_path = p.B.w;
+        w.tau = p.C.x;  w.dens = p.C.y;
+        int lid = __float_as_int(p.C.z);
+        w.ind = __float_as_int(p.C.w);
+        w.rng.x = p.D.x;  w.rng.c = p.D.y;
+        int III = (int)(p.D.z & 0xffffffu);
+        w.scat = (int)(p.D.z >> 24);
+        int key = (int)p.D.w;
+        bool create = (D.brick == A.NB);
+        if (!create) {
+            // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
+            const int oind = w.ind;
+            float kabs, ksca;
+            if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
+            else     { kabs = S.ABS;  ksca = S.SCA; }
+            w.scat++;
+            float dt = w.free_path - w.tau;
+            float dx = dt / (ksca * w.dens);
+            float tauA = dx * w.dens * kabs;
+            float e = soc_expf(-tauA);
+            float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
+            soc_tally(S.TABS, oind, delta * S.TW);
+            if (WINT) soc_tally(S.INT, oind, delta);
+            n_tally++;
+            n_scat++;
+            dx = soc_scale_up(dx, 0);
+            dx = __builtin_fmaxf(0.0f, dx - 2.0f * SOC_PEPS);
+            w.px = w.px + dx * w.ux;
+            w.py = w.py + dx * w.uy;
+            w.pz = w.pz + dx * w.uz;
+            w.photons *= e;
+            w.free_path = -soc_logf(soc_rand(&w.rng));
+            soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);           // one table read per event: no staging
+            w.tau = 0.0f;
+            if (w.scat > 20) { w.ind = -1;  create = true; }                  // dropped after 20 scatterings
+        }
+        if (create) {
+            const int id = (int)(S.gid0 + wid);
+            const SocSurfElem E = soc_surface_element(G, S, id);
+            while (true) {
+                if (III >= S.BATCH) { key = A.NB + 2;  break; }                // work item finished
+                soc_pb_create<false>(G, S, sOFF0, E, III, w);
+                III++;
+                n_pkt++;
+                w.begin();
+                if (w.ind >= 0) { soc_cell_brick(A, w.px, w.py, w.pz, key, lid);  break; }
+            }
+        }
+        p.A = make_float4(w.px, w.py, w.pz, w.photons);
+        p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
+        p.C = make_float4(w.tau, w.dens, __int_as_float(lid), __int_as_float(w.ind));
+        p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), (uint32_t)key);
+        pk[wid] = p;
+        A.keyq[D.start + j] = (uint32_t)key;
+        atomicAdd(&sH[key], 1);
+    }
+    atomicAdd(&sCtl[0], (int)n_tally);
+    atomicAdd(&sCtl[1], (int)n_pkt);
+    atomicAdd(&sCtl[2], (int)n_scat);
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.NB + 3; i += blockDim.x) {
+        const int c = sH[i];
+        if (c) atomicAdd(&A.hist[i], c);
     }
     if (threadIdx.x == 0 && S.stats) {
-        atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
-        atomicAdd(S.stats + 1, (unsigned long long)(unsigned int)sCtl[2]);
-        atomicAdd(S.stats + 2, (unsigned long long)(unsigned int)sCtl[3]);
+        atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[0]);
+        atomicAdd(S.stats + 1, (unsigned long long)(unsigned int)sCtl[1]);
+        atomicAdd(S.stats + 2, (unsigned long long)(unsigned int)sCtl[2]);
+    }
+}
+
+// One launch per pass for both: blocks [0, nwalk) walk the descriptor of their index (and leave at
+// once if it belongs to an event queue), the blocks after them are the event workgroups.  The short,
+// latency-bound event work runs beside the walk instead of after it.
+template <bool ABU, bool WINT>
+__global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSim S, const SocBrickArgs A, const int nwalk, const int slices)
+{
+    const int b = (int)blockIdx.x;
+    if (b < nwalk) {
+        soc_brick_walk<ABU, WINT>(G, S, A, b);
+    } else {
+        const int e = b - nwalk;
+        soc_brick_events<ABU, WINT>(G, S, A, e / slices, e % slices);
     }
 }
 
@@ -386,6 +422,7 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         const int c = A.hist[b];
         A.off[b] = off;
         A.cursor[b] = 0;
+        if (b == A.ev_brick) A.ndesc_next[2] = offd;
         for (int k = 0; k * A.P < c; k++) {
             SocDesc d;
             d.brick = b;
@@ -442,16 +479,21 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A)
 // host orchestration
 // ---------------------------------------------------------------------------------------
 
+#define SOC_BRICK_MAXPOP 8
+
 struct SocBrickBuffers {
     size_t cap_items = 0;
     int    cap_nb = 0, cap_desc = 0;
-    SocPacket *pk = nullptr;
+    SocPk2 *pk = nullptr;
     uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr;
     int *hist = nullptr, *off = nullptr, *cursor = nullptr, *ndesc = nullptr, *total = nullptr;
     SocDesc *desc[2] = { nullptr, nullptr };
+    hipStream_t side = nullptr;                           // populations 1.. run on their own streams
+    hipEvent_t  join = nullptr;
 };
 
-static SocBrickBuffers g_bb[16];                          // one set per device ordinal
+static SocBrickBuffers g_bb[16][SOC_BRICK_MAXPOP];        // per device ordinal, per population
+static hipEvent_t g_fork[16];
 
 #define BCHK(call)                          \
     do {                                    \
@@ -469,10 +511,81 @@ static hipError_t brick_alloc(T **p, size_t n)
 void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
-    SocBrickBuffers &b = g_bb[device];
-    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    b = SocBrickBuffers();
+    for (int q = 0; q < SOC_BRICK_MAXPOP; q++) {
+        SocBrickBuffers &b = g_bb[device][q];
+        void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        if (b.side) (void)hipStreamDestroy(b.side);
+        if (b.join) (void)hipEventDestroy(b.join);
+        b = SocBrickBuffers();
+    }
+    if (g_fork[device]) { (void)hipEventDestroy(g_fork[device]);  g_fork[device] = nullptr; }
+}
+
+// one population: a contiguous range of the launch's work items with its own queues
+struct SocBrickPop {
+    SocBrickBuffers *bb;
+    SocSim S;
+    SocBrickArgs A;
+    uint32_t count;
+    int maxdesc;
+    hipStream_t st;
+    int total;
+};
+
+static hipError_t pop_prepare(SocBrickPop &P, hipStream_t sync_st)
+{
+    SocBrickBuffers &bb = *P.bb;
+    const uint32_t count = P.count;
+    if (bb.cap_items < count) {
+        BCHK(hipStreamSynchronize(sync_st));
+        BCHK(brick_alloc(&bb.pk, count));
+        BCHK(brick_alloc(&bb.idq[0], count));
+        BCHK(brick_alloc(&bb.idq[1], count));
+        BCHK(brick_alloc(&bb.keyq, count));
+        bb.cap_items = count;
+    }
+    if (bb.cap_nb < P.A.NB + 3) {
+        BCHK(hipStreamSynchronize(sync_st));
+        BCHK(brick_alloc(&bb.hist, P.A.NB + 3));
+        BCHK(brick_alloc(&bb.off, P.A.NB + 3));
+        BCHK(brick_alloc(&bb.cursor, P.A.NB + 3));
+        bb.cap_nb = P.A.NB + 3;
+    }
+    if (bb.cap_desc < P.maxdesc) {
+        BCHK(hipStreamSynchronize(sync_st));
+        BCHK(brick_alloc(&bb.desc[0], P.maxdesc));
+        BCHK(brick_alloc(&bb.desc[1], P.maxdesc));
+        bb.cap_desc = P.maxdesc;
+    }
+    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1)); }
+    P.A.pk = bb.pk;  P.A.keyq = bb.keyq;  P.A.hist = bb.hist;  P.A.off = bb.off;  P.A.cursor = bb.cursor;  P.A.total = bb.total;
+    return hipSuccess;
+}
+
+// one pass of one population: walk, events, scan, scatter on the population's stream
+static hipError_t pop_pass(const SocGrid &G, SocBrickPop &P, int vkey, int c, size_t lds_walk, size_t lds_ev, size_t lds_scat)
+{
+    SocBrickBuffers &bb = *P.bb;
+    SocBrickArgs &A = P.A;
+    A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
+    A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
+    A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
+    const int slices = (A.P + A.T - 1) / A.T;
+    const int nev = ((int)((P.count + A.P - 1) / A.P) + 2) * slices;
+    const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
+    switch (vkey) {
+    case 0:  soc_brick_pass<false, false><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
+    case 1:  soc_brick_pass<false, true><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
+    case 2:  soc_brick_pass<true, false><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
+    default: soc_brick_pass<true, true><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
+    }
+    SocBrickArgs Q = A;                                   // the sort sees NB + 2 live queues; [NB+2] = finished
+    Q.NB = A.NB + 2;
+    Q.ev_brick = A.NB;
+    soc_brick_scan<<<1, 1024, 0, P.st>>>(Q);
+    soc_brick_scatter<<<P.maxdesc, SOC_BRICK_T, lds_scat, P.st>>>(Q);
+    return hipGetLastError();
 }
 
 // LB: log2 of the brick edge.  Returns hipErrorNotSupported when the launch cannot use bricks.
@@ -480,105 +593,91 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &Sin, con
                             int *passes_out)
 {
     if (V.octree || device < 0 || device >= 16) return hipErrorNotSupported;
-    SocSim S = Sin;
+    if (Sin.BATCH >= (1 << 24)) return hipErrorNotSupported;          // III shares a word with the scattering count
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
+    A.ev_brick = -1;
     A.NBX = (G.NX + B - 1) / B;  A.NBY = (G.NY + B - 1) / B;  A.NBZ = (G.NZ + B - 1) / B;
     A.NB = A.NBX * A.NBY * A.NBZ;
     if (A.NB > 8192) return hipErrorNotSupported;
-    // workgroup shape; overridable for experiments
-    // measured on C2 (128^3, 786k packets in flight): T=512, P=2048, KCAP=32 is the best of the sweep
+    // workgroup shape and population count; overridable for experiments (measured on C2)
     A.T = 512;
     A.P = 4 * A.T;
     A.KCAP = 32;
+    A.FTH = 16;
+    int npop = 1;
     if (const char *e = getenv("SOC_BRICK_T")) A.T = atoi(e);
     if (const char *e = getenv("SOC_BRICK_P")) A.P = atoi(e);
     if (const char *e = getenv("SOC_BRICK_KCAP")) A.KCAP = atoi(e);
-    A.FTH = 8;
     if (const char *e = getenv("SOC_BRICK_FTH")) A.FTH = atoi(e);
-    if (A.T < 64 || A.T > 1024 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
-    uint32_t count = S.gid_count;
-    if (S.SOURCE == 1) {
+    if (const char *e = getenv("SOC_BRICK_NPOP")) npop = atoi(e);
+    if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
+    if (npop < 1) npop = 1;
+    if (npop > SOC_BRICK_MAXPOP) npop = SOC_BRICK_MAXPOP;
+    uint32_t count = Sin.gid_count;
+    if (Sin.SOURCE == 1) {
         const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
-        if ((long long)S.gid0 >= lim) return hipSuccess;
-        if ((long long)S.gid0 + count > lim) count = (uint32_t)(lim - S.gid0);
+        if ((long long)Sin.gid0 >= lim) return hipSuccess;
+        if ((long long)Sin.gid0 + count > lim) count = (uint32_t)(lim - Sin.gid0);
     }
-    if (count == 0 || S.BATCH <= 0) return hipSuccess;
-    const int maxdesc = (int)((count + A.P - 1) / A.P) + A.NB + 1;
+    if (count == 0 || Sin.BATCH <= 0) return hipSuccess;
+    while (npop > 1 && count / npop < 65536) npop--;                  // small launches: one population
 
-    SocBrickBuffers &bb = g_bb[device];
-    if (bb.cap_items < count) {
-        BCHK(hipStreamSynchronize(st));
-        BCHK(brick_alloc(&bb.pk, count));
-        BCHK(brick_alloc(&bb.idq[0], count));
-        BCHK(brick_alloc(&bb.idq[1], count));
-        BCHK(brick_alloc(&bb.keyq, count));
-        bb.cap_items = count;
-    }
-    if (bb.cap_nb < A.NB + 1) {
-        BCHK(hipStreamSynchronize(st));
-        BCHK(brick_alloc(&bb.hist, A.NB + 1));
-        BCHK(brick_alloc(&bb.off, A.NB + 1));
-        BCHK(brick_alloc(&bb.cursor, A.NB + 1));
-        bb.cap_nb = A.NB + 1;
-    }
-    if (bb.cap_desc < maxdesc) {
-        BCHK(hipStreamSynchronize(st));
-        BCHK(brick_alloc(&bb.desc[0], maxdesc));
-        BCHK(brick_alloc(&bb.desc[1], maxdesc));
-        bb.cap_desc = maxdesc;
-    }
-    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 2));  BCHK(brick_alloc(&bb.total, 1)); }
-
-    A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
     const int BV = 1 << (3 * LB);
-    bool use_sd = false;      // LDS copy of the brick densities: measured no gain (268 vs 274 ms at C2), costs LDS
-    if (const char *e = getenv("SOC_BRICK_SD")) use_sd = atoi(e) != 0;
-    const size_t lds_step = (size_t)(BV * (1 + (use_sd ? 1 : 0) + (V.wint ? 1 : 0)) + A.NB + 1 + 8) * 4;
-    const size_t lds_scat = (size_t)A.NB * 4;
+    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + A.NB + 3 + 2) * 4;
+    const size_t lds_ev = (size_t)(A.NB + 3 + 8) * 4;
+    const size_t lds_scat = (size_t)(A.NB + 2) * 4;
+    const int vkey = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
 
-    soc_brick_init<<<(max(count, (uint32_t)A.NB + 1) + 255) / 256, 256, 0, st>>>(G, S, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
-    BCHK(hipGetLastError());
-    int cur = 0, passes = 0, total = 1;
-    int dbg_pass = -1;
-    long long *dbg_buf = nullptr;
-    if (const char *e = getenv("SOC_BRICK_DBG")) {
-        dbg_pass = atoi(e);
-        BCHK(hipMalloc((void **)&dbg_buf, (size_t)maxdesc * 24 * sizeof(long long)));
-        BCHK(hipMemset(dbg_buf, 0, (size_t)maxdesc * 24 * sizeof(long long)));
-    }
-    while (total > 0) {
-        for (int k = 0; k < 64; k++, passes++) {
-            A.dbg = (passes == dbg_pass) ? dbg_buf : nullptr;
-            A.idq = bb.idq[cur];  A.idq_next = bb.idq[1 - cur];
-            A.desc = bb.desc[cur];  A.ndesc = bb.ndesc + cur;
-            A.desc_next = bb.desc[1 - cur];  A.ndesc_next = bb.ndesc + (1 - cur);
-            const int key = (V.abu ? 4 : 0) | (V.wint ? 2 : 0) | (use_sd ? 1 : 0);
-            switch (key) {
-            case 0: soc_brick_step<false, false, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 1: soc_brick_step<false, false, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 2: soc_brick_step<false, true, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 3: soc_brick_step<false, true, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 4: soc_brick_step<true, false, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 5: soc_brick_step<true, false, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            case 6: soc_brick_step<true, true, false><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            default: soc_brick_step<true, true, true><<<maxdesc, A.T, lds_step, st>>>(G, S, A); break;
-            }
-            soc_brick_scan<<<1, 1024, 0, st>>>(A);
-            soc_brick_scatter<<<maxdesc, SOC_BRICK_T, lds_scat, st>>>(A);
-            cur = 1 - cur;
+    SocBrickPop pops[SOC_BRICK_MAXPOP];
+    const uint32_t per = ((count + npop - 1) / npop + 63) / 64 * 64;
+    if (!g_fork[device]) BCHK(hipEventCreateWithFlags(&g_fork[device], hipEventDisableTiming));
+    for (int q = 0; q < npop; q++) {
+        SocBrickPop &P = pops[q];
+        P.bb = &g_bb[device][q];
+        const uint32_t first = min(count, (uint32_t)q * per);
+        P.count = min(per, count - first);
+        P.S = Sin;
+        P.S.gid0 = Sin.gid0 + first;
+        P.S.gid_count = P.count;
+        P.A = A;
+        P.maxdesc = (int)((P.count + A.P - 1) / A.P) + A.NB + 3;
+        P.total = P.count ? 1 : 0;
+        if (q > 0 && !P.bb->side) {
+            BCHK(hipStreamCreateWithFlags(&P.bb->side, hipStreamNonBlocking));
+            BCHK(hipEventCreateWithFlags(&P.bb->join, hipEventDisableTiming));
         }
-        BCHK(hipGetLastError());
-        BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));
-        BCHK(hipStreamSynchronize(st));
-        if (passes > 4000000) return hipErrorUnknown;     // cannot happen: every pass retires work
+        P.st = (q == 0) ? st : P.bb->side;
+        if (P.count) BCHK(pop_prepare(P, st));
     }
-    if (dbg_buf) {
-        std::vector<long long> h((size_t)maxdesc * 24);
-        BCHK(hipMemcpy(h.data(), dbg_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        if (FILE *fp = fopen("gpurun_out/brick_dbg.bin", "wb")) { fwrite(h.data(), sizeof(long long), h.size(), fp); fclose(fp); }
-        (void)hipFree(dbg_buf);
+    // the side streams start after everything already queued on st ...
+    BCHK(hipEventRecord(g_fork[device], st));
+    for (int q = 1; q < npop; q++) BCHK(hipStreamWaitEvent(pops[q].st, g_fork[device], 0));
+    for (int q = 0; q < npop; q++) {
+        SocBrickPop &P = pops[q];
+        if (!P.count) continue;
+        soc_brick2_init<<<(max(P.count, (uint32_t)A.NB + 3) + 255) / 256, 256, 0, P.st>>>(P.S, P.A, P.count, P.bb->idq[0], P.bb->desc[0],
+                                                                                          P.bb->ndesc, P.bb->hist);
+    }
+    BCHK(hipGetLastError());
+    int passes = 0;
+    bool busy = true;
+    while (busy) {
+        for (int k = 0; k < 64; k++, passes++)
+            for (int q = 0; q < npop; q++)
+                if (pops[q].total > 0) BCHK(pop_pass(G, pops[q], vkey, k & 1, lds_walk, lds_ev, lds_scat));
+        for (int q = 0; q < npop; q++)
+            if (pops[q].total > 0) BCHK(hipMemcpyAsync(&pops[q].total, pops[q].bb->total, sizeof(int), hipMemcpyDeviceToHost, pops[q].st));
+        for (int q = 0; q < npop; q++) BCHK(hipStreamSynchronize(pops[q].st));
+        busy = false;
+        for (int q = 0; q < npop; q++) busy = busy || (pops[q].total > 0);
+        if (passes > 4000000) return hipErrorUnknown;                 // cannot happen: every pass retires work
+    }
+    // ... and st continues after them (all streams are idle here; kept for callers that do not sync)
+    for (int q = 1; q < npop; q++) {
+        BCHK(hipEventRecord(pops[q].bb->join, pops[q].st));
+        BCHK(hipStreamWaitEvent(st, pops[q].bb->join, 0));
     }
     if (passes_out) *passes_out = passes;
     return hipSuccess;
