@@ -212,7 +212,7 @@ def main():
         packets_total = packets_rank
 
     passes = eng.last_passes()
-    kernel_name = ("soc_brick_step<scalar-opacity,TABS-only> x %d passes (+ soc_brick_scan, soc_brick_scatter): "
+    kernel_name = ("soc_brick_pass<scalar-opacity,TABS-only> x %d passes (+ soc_brick_scan, soc_brick_scatter): "
                    "time is the HIP-event span of all kernels of one step" % passes) if passes else \
         "soc_sim_pb_kernel<Cartesian,float,scalar-opacity,TABS-only>"
     if rank == 0:

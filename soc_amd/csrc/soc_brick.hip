@@ -163,6 +163,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
     const int   mybrick = D.brick, LB = A.LB, M = (1 << A.LB) - 1;
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
+    float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
     int   ind = -1, lid = 0, nvisit = 0, key = 0, slot = 0;
     int   mode = SOC_BM_SWAP;
     bool  have = false;
@@ -193,6 +194,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
                         const float4 a = q->A, b = q->B, c = q->C;
                         px = a.x;  py = a.y;  pz = a.z;  photons = a.w;
                         ux = b.x;  uy = b.y;  uz = b.z;  free_path = b.w;
+                        rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
                         tau = c.x;  dens = c.y;  lid = __float_as_int(c.z);  ind = __float_as_int(c.w);
                         nvisit = 0;
                         mode = SOC_BM_STEP;
@@ -208,18 +210,29 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
             float kabs, ksca;
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
             else     { kabs = S.ABS;  ksca = S.SCA; }
-            float ax = (ux > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(px)) / ux) : ((-SOC_PEPS - soc_fmod1f(px)) / ux);
-            float ay = (uy > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(py)) / uy) : ((-SOC_PEPS - soc_fmod1f(py)) / uy);
-            float az = (uz > 0.0f) ? (((1.0f + SOC_PEPS) - soc_fmod1f(pz)) / uz) : ((-SOC_PEPS - soc_fmod1f(pz)) / uz);
+            // GetStep (kernel_ASOC_aux.c:282-315) with the same results from fewer instructions:
+            //  * fmod(p,1) of a positive p is v_fract (exact); a lane with a negative coordinate (possible
+            //    only right after a failed-step nudge) sends the wave through the general form;
+            //  * n/u from the cached correctly rounded 1/u (soc_div_by_rcp: bit-identical to the division);
+            //  * floor of a positive coordinate is the float->int conversion.
+            float fx, fy, fz;
+            if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
+                fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
+            } else {
+                fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
+            }
+            const float ax = soc_div_by_rcp(((ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fx, ux, rux);
+            const float ay = soc_div_by_rcp(((uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fy, uy, ruy);
+            const float az = soc_div_by_rcp(((uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fz, uz, ruz);
             float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
             px += ds * ux;
             py += ds * uy;
             pz += ds * uz;
             ds = soc_scale_down(ds, 0);
             const bool inside = (px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ);
-            const int ix = inside ? (int)soc_floorf(px) : 0;
-            const int iy = inside ? (int)soc_floorf(py) : 0;
-            const int iz = inside ? (int)soc_floorf(pz) : 0;
+            const int ix = inside ? (int)px : 0;
+            const int iy = inside ? (int)py : 0;
+            const int iz = inside ? (int)pz : 0;
             const int nind = iz * NX * NY + iy * NX + ix;
             const int nb   = ((iz >> LB) * A.NBY + (iy >> LB)) * A.NBX + (ix >> LB);
             const int nlid = ((iz & M) << (2 * LB)) | ((iy & M) << LB) | (ix & M);
@@ -231,7 +244,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
                 px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
                 mode = SOC_BM_SWAP;  key = A.NB + 1;                          // -> scattering queue
             } else {
-                const float e = soc_expf(-tauA);
+                // every lane of the wave in the interval where soc_expf_small == soc_expf (the common case)
+                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                 const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
                 atomicAdd(&sT[lid0], delta * S.TW);
                 if (WINT) atomicAdd(&sI[lid0], delta);
@@ -423,12 +437,14 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         A.off[b] = off;
         A.cursor[b] = 0;
         if (b == A.ev_brick) A.ndesc_next[2] = offd;
-        for (int k = 0; k * A.P < c; k++) {
+        const int nk = (c + A.P - 1) / A.P;               // chunks of equal size (a queue of P+1 is not 2048 + 1)
+        for (int k = 0, o = off; k < nk; k++) {
             SocDesc d;
             d.brick = b;
-            d.start = off + k * A.P;
-            d.count = min(A.P, c - k * A.P);
+            d.start = o;
+            d.count = c / nk + (k < c % nk ? 1 : 0);
             d.pad = 0;
+            o += d.count;
             A.desc_next[offd++] = d;
         }
         off += c;

@@ -41,9 +41,15 @@ void hp_math(int fn, const float *x, float *y, long n)
         case 5: y[i] = soc_sqrtf(x[i]); break;
         case 6: y[i] = soc_fmod1f(x[i]); break;
         case 8: y[i] = soc_expm1f(x[i]); break;
+        case 11: y[i] = soc_expf_small(x[i]); break;
         case 9: y[i] = soc_pow15f(x[i]); break;
         case 10: y[i] = (float)soc_logd((double)x[i]); break;
         default: y[i] = 0.0f;
         }
     }
+}
+
+void hp_div_by_rcp(const float *n, const float *u, float *q, long cnt)
+{
+    for (long i = 0; i < cnt; i++) q[i] = soc_div_by_rcp(n[i], u[i], 1.0f / u[i]);
 }

@@ -54,8 +54,15 @@ class HostProbe:
         return u, r
 
     def math(self, fn, x):
-        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, expm1=8, pow15=9, logd=10)[fn]
+        code = dict(exp=0, log=1, sin=2, cos=3, acos=4, sqrt=5, fmod1=6, expm1=8, pow15=9, logd=10, exp_small=11)[fn]
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
         self.lib.hp_math(code, x.ctypes.data_as(_F), y.ctypes.data_as(_F), x.size)
         return y
+
+    def div_by_rcp(self, n, u):
+        n = np.ascontiguousarray(n, np.float32)
+        u = np.ascontiguousarray(u, np.float32)
+        q = np.zeros_like(n)
+        self.lib.hp_div_by_rcp(n.ctypes.data_as(_F), u.ctypes.data_as(_F), q.ctypes.data_as(_F), n.size)
+        return q

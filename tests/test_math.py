@@ -70,6 +70,29 @@ def test_expm1_pow15_logd(hp):
     assert np.array_equal(hp.math("logd", x), want.astype(np.float32))   # fp64 log rounded to fp32
 
 
+def test_exp_small_is_exp_on_its_interval(hp):
+    """soc_expf_small (used by the brick walk when every lane's argument is small) must give the
+    bits of soc_expf on (-0.34, 0]."""
+    x = -np.concatenate([np.linspace(0, 0.34, 2000001)[:-1], np.logspace(-30, -0.5, 200001), [0.0]]).astype(np.float32)
+    x = x[x > -0.34]
+    assert np.array_equal(hp.math("exp_small", x).view(np.uint32), hp.math("exp", x).view(np.uint32))
+
+
+def test_division_by_cached_reciprocal_is_the_division(hp):
+    """soc_div_by_rcp(n, u, 1/u) == n / u bit for bit over the ranges of GetStep
+    (numerators (1+PEPS)-frac or -PEPS-frac, |u| in [5e-5, 1])."""
+    rng = np.random.default_rng(7)
+    m = 4000000
+    u = np.exp(rng.uniform(np.log(4.9e-5), 0.0, m)).astype(np.float32) * rng.choice([-1.0, 1.0], m).astype(np.float32)
+    frac = rng.uniform(0, 1, m).astype(np.float32)
+    frac[: m // 8] = np.exp(rng.uniform(-60, 0, m // 8)).astype(np.float32)
+    n = np.where(u > 0, np.float32(1.0 + 1.0e-4) - frac, np.float32(-1.0e-4) - frac).astype(np.float32)
+    ones = (np.arange(100, 127, dtype=np.uint32)[:, None] << 23 | np.uint32(0x7fffff)).view(np.float32).ravel()   # all-ones significands
+    u = np.concatenate([u, np.repeat(ones, 1000)])
+    n = np.concatenate([n, rng.uniform(0.5, 1.0001, ones.size * 1000).astype(np.float32)])
+    assert np.array_equal(hp.div_by_rcp(n, u).view(np.uint32), (n / u).view(np.uint32))
+
+
 def test_oracle_soc_mode_uses_this_header(hp, oracle_soc):
     x = np.random.default_rng(5).uniform(-20, 5, 20000).astype(np.float32)
     for fn, xx in (("exp", x), ("log", np.abs(x) + 1e-9), ("sin", x), ("cos", x), ("acos", np.clip(x / 20, -1, 1)),
