@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,13 +170,18 @@ def main():
     else:
         first, count = launch.shard_range(L["GLOBAL"], rank, world)
 
-    def step(i):
-        # per-frequency body: seed for this (frequency, device), launch, reduce
+    def steps(i0, n):
+        """n steps = n launches of the workload with the seeds of (frequency i, device): the per-frequency
+        body of the reference's loop.  They are handed to the engine together (deferred launches), which
+        runs up to --in-flight of them per brick sweep; then one all-reduce of TABS."""
         dev_id = rank if args.scaling == "weak" else 0
         ndev = world if args.scaling == "weak" else 1
-        seed = launch.launch_seed(work["SEED"], i, DEVICES=ndev, ID=dev_id)
         eng.timer_start()
-        eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, BG, TW, GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+        eng.batch_begin(args.in_flight)
+        for i in range(i0, i0 + n):
+            seed = launch.launch_seed(work["SEED"], i, DEVICES=ndev, ID=dev_id)
+            eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, BG, TW, GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+        eng.batch_end()
         ms = eng.timer_stop()
         if world > 1:
             dist.all_reduce(tabs)
@@ -187,14 +194,12 @@ def main():
         else:
             eng.sync()
 
-    for i in range(args.warmup):
-        step(i)
+    if args.warmup:
+        steps(0, args.warmup)
     eng.stats(reset=True)
     fence()
     t0 = time.perf_counter()
-    kernel_ms = []
-    for i in range(args.steps):
-        kernel_ms.append(step(args.warmup + i))
+    kernel_ms = [steps(args.warmup, args.steps) / max(args.steps, 1)]      # HIP-event span of all K steps / K
     fence()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
@@ -212,8 +217,8 @@ def main():
         packets_total = packets_rank
 
     passes = eng.last_passes()
-    kernel_name = ("soc_brick_pass<scalar-opacity,TABS-only> x %d passes (+ soc_brick_scan, soc_brick_scatter): "
-                   "time is the HIP-event span of all kernels of one step" % passes) if passes else \
+    kernel_name = ("soc_brick_pass<scalar-opacity,TABS-only> (+ soc_brick_scan, soc_brick_scatter), %d passes in the last "
+                   "sweep of up to %d steps: time is the HIP-event span of all kernels of the K steps / K" % (passes, args.in_flight)) if passes else \
         "soc_sim_pb_kernel<Cartesian,float,scalar-opacity,TABS-only>"
     if rank == 0:
         kavg_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
@@ -234,9 +239,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": work["name"], "packets_per_step_per_gpu": packets_rank // max(args.steps, 1),
                        "cells": cloud.CELLS, "tally_events_per_packet": events_rank / max(packets_rank, 1),
+                       "steps_in_flight": args.in_flight,
                        "parallelism": "1 process per GPU; %s" % (
-                           "replicas with per-rank seeds + 1 RCCL all-reduce of TABS per step" if args.scaling == "weak"
-                           else "work-item ranges of one launch + 1 RCCL all-reduce of TABS per step")},
+                           "replicas with per-rank seeds + 1 RCCL all-reduce of TABS after the K steps (TABS integrates over frequency on the device)" if args.scaling == "weak"
+                           else "work-item ranges of one launch + 1 RCCL all-reduce of TABS after the K steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": kernel_name,

@@ -101,6 +101,17 @@ int soc_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
 int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
                int GLOBAL, int gid_first, int gid_count);
 
+/* Deferred execution of consecutive soc_sim_pb launches (no counterpart in the reference, which
+ * runs one kernel per frequency and waits for it, ASOC.py:1360-1461).  Between soc_batch_begin and
+ * soc_batch_end a launch that qualifies for the brick sweep with scalar opacities and without the
+ * per-frequency INT tally is recorded with a snapshot of its inputs (ABS, SCA, scattering table,
+ * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default 4,
+ * at most 8): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
+ * flight per pass.  Any other call that reads or changes engine state executes what is pending
+ * first; launches that do not qualify run immediately as always. */
+int soc_batch_begin(soc_ctx *ctx, int max_launches);
+int soc_batch_end(soc_ctx *ctx);
+
 /* replaces the HPBG_buf / HPBGP_buf uploads (ASOC.py:1196-1214): the Healpix sky of the current
  * frequency in photons per package, 49152 floats (NSIDE 64, RING order); HPBGP = cumulative
  * pixel probability for `hpbg ... weighted` runs (-D HPBG_WEIGHTED=1) or NULL */

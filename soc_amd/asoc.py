@@ -200,6 +200,11 @@ class AbsorptionRun:
                 self.log("=== DFPAC %d, GLOBAL %d, BATCH %d" % (self.DFPAC, L["GLOBAL"], L["BATCH"]))
             first, count = self.comm.shard(L["GLOBAL"]) if self.comm else (0, L["GLOBAL"])
             e.zero(0)
+            # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
+            # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
+            deferred = (not self.with_int) and II != 2 and hasattr(e, "batch_begin")
+            if deferred:
+                e.batch_begin(0)
             for IFREQ in range(NFREQ):
                 FREQ = float(FFREQ[IFREQ])
                 if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
@@ -246,7 +251,8 @@ class AbsorptionRun:
                              GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
                 if self.with_int and self.comm:
                     self.comm.all_reduce_tally(e, 1)      # one all-reduce of the per-cell buffer per frequency
-                e.sync()
+                if not deferred:
+                    e.sync()
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
                 t0 = time.time()
@@ -256,6 +262,11 @@ class AbsorptionRun:
                 if self.verbose and self.rank == 0:
                     print("  FREQ %3d/%3d  %10.3e   BG %12.4e  PS %12.4e   TW %10.3e" % (
                         IFREQ + 1, NFREQ, FREQ, BG, PS[0], FF))
+            if deferred:
+                t0 = time.time()
+                e.batch_end()
+                e.sync()
+                self.timers["Tkernel"] += time.time() - t0
             if self.comm:
                 self.comm.all_reduce_tally(e, 0)          # TABS: integrated over frequency on the device
             t0 = time.time()

@@ -22,9 +22,8 @@
 //                     workgroup descriptors (one workgroup, exact sizes, no capacity guess);
 //   soc_brick_scatter counting-sort placement of the packet ids into the next queues.
 // A kernel boundary separates the phases, so no in-launch inter-workgroup hand-off exists.
-// The work items of a launch are split into independent populations, each with its own queues
-// on its own stream: while one population's walk fills the chip, the short latency-bound
-// kernels (events, scan, scatter) of the others run beside it.
+// Several launches (frequencies of a run, steps of the benchmark) can share one sweep: their
+// work items are one population, each launch with its own pair of event queues.
 //
 // What does not change: the logical work items, their MWC64X streams, every fp32 operation
 // of a packet's life (same code as soc_walk.h, same operand order).  Trajectories are
@@ -111,35 +110,44 @@ struct SocBrickLane {
 // Packet record (64 B): A = position, photons | B = direction, free_path | C = tau, density of
 // the current cell, tally slot, cell index | D = RNG state, III | scat << 24, brick.
 // ---------------------------------------------------------------------------------------
-__global__ void soc_brick2_init(const SocSim S, SocBrickArgs A, uint32_t count, uint32_t *idq0, SocDesc *desc0, int *ndesc0, int *hist)
+__global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t count, uint32_t *idq0, SocDesc *desc0, int *ndesc0, int *hist)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     SocPk2 *pk = A.pk;
     if (t < count) {
-        const soc_rng_t r = soc_seed_stream(S.seed_mul, S.seed_tab, S.gid0 + t);
+        int l = 0;
+        while (l + 1 < K.n && t >= K.first[l + 1]) l++;
+        const soc_rng_t r = soc_seed_stream(K.S[l].seed_mul, K.S[l].seed_tab, K.S[l].gid0 + (t - K.first[l]));
         SocPk2 p;
         p.A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         p.B = p.A;
-        p.C = make_float4(0.0f, 0.0f, __int_as_float(0), __int_as_float(-1));
+        p.C = make_float4(0.0f, 0.0f, __int_as_float(l << 16), __int_as_float(-1));
         p.D = make_uint4(r.x, r.c, 0u, 0u);
         pk[t] = p;
         idq0[t] = t;
     }
-    const uint32_t nd = (count + A.P - 1) / A.P;
-    if (t < nd) {
-        SocDesc d;
-        d.brick = A.NB;                                    // everybody starts in the creation queue
-        d.start = (int)(t * A.P);
-        d.count = (int)min((uint32_t)A.P, count - t * A.P);
-        d.pad = 0;
-        desc0[t] = d;
+    // every launch starts in its own creation queue NB + 2l
+    uint32_t dbase = 0;
+    for (int l = 0; l < K.n; l++) {
+        const uint32_t cnt = K.first[l + 1] - K.first[l];
+        const uint32_t nd = (cnt + A.P - 1) / A.P;
+        if (t >= dbase && t < dbase + nd) {
+            const uint32_t k = t - dbase;
+            SocDesc d;
+            d.brick = A.NB + 2 * l;
+            d.start = (int)(K.first[l] + k * A.P);
+            d.count = (int)min((uint32_t)A.P, cnt - k * A.P);
+            d.pad = 0;
+            desc0[t] = d;
+        }
+        dbase += nd;
     }
-    if (t == 0) { ndesc0[0] = (int)nd;  ndesc0[2] = 0; }
-    if (t <= (uint32_t)A.NB + 2) hist[t] = 0;
+    if (t == 0) { ndesc0[0] = (int)dbase;  ndesc0[2] = 0; }
+    if (t <= (uint32_t)(A.NB + 2 * K.n)) hist[t] = 0;
 }
 
 template <bool ABU, bool WINT>
-__device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S, const SocBrickArgs &A, const int bid)
+__device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
     if (bid >= *A.ndesc) return;
     const SocDesc D = A.desc[bid];
@@ -151,10 +159,16 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + BV;                                 // [BV] INT (WINT)
-    int   *sH   = (int *)(sI + (WINT ? BV : 0));           // [NB+3] arrivals per queue, next pass
-    int   *sCtl = sH + A.NB + 3;                           // [0] next packet, [1] tally events
+    const int NQ = A.NB + 2 * K.n + 1;                     // bricks, (creation, scattering) per launch, finished
+    int   *sH   = (int *)(sI + (WINT ? BV : 0));           // [NQ] arrivals per queue, next pass
+    int   *sCtl = sH + NQ;                                 // [0] next packet, [1] tally events
+    float *sL   = (float *)(sCtl + 2);                     // [3 * n] ABS, SCA, TW of every launch
+    const SocSim &S = K.S[0];                              // what the launches share: tallies, stats, OPT (n == 1)
+    if ((int)threadIdx.x < K.n) {
+        sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
+    }
     for (int i = threadIdx.x; i < BV; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
-    for (int i = threadIdx.x; i < A.NB + 3; i += nthr) sH[i] = 0;
+    for (int i = threadIdx.x; i < NQ; i += nthr) sH[i] = 0;
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
     __syncthreads();
 
@@ -164,6 +178,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
+    float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;             // of the packet's launch
+    int   lsh = 0;                                         // launch index << 16
     int   ind = -1, lid = 0, nvisit = 0, key = 0, slot = 0;
     int   mode = SOC_BM_SWAP;
     bool  have = false;
@@ -179,8 +195,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
                     if (have) {
                         SocPk2 *q = pk + wid;
                         q->A = make_float4(px, py, pz, photons);
-                        q->C = make_float4(tau, dens, __int_as_float(lid), __int_as_float(ind));
-                        if (key == A.NB + 1) q->D.w = (uint32_t)mybrick;             // scattering: the brick to come back to
+                        q->C = make_float4(tau, dens, __int_as_float(lid | lsh), __int_as_float(ind));
+                        if (key >= A.NB) q->D.w = (uint32_t)mybrick;                 // scattering: the brick to come back to
                         A.keyq[D.start + slot] = (uint32_t)key;
                         atomicAdd(&sH[key], 1);
                     }
@@ -195,7 +211,9 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
                         px = a.x;  py = a.y;  pz = a.z;  photons = a.w;
                         ux = b.x;  uy = b.y;  uz = b.z;  free_path = b.w;
                         rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
-                        tau = c.x;  dens = c.y;  lid = __float_as_int(c.z);  ind = __float_as_int(c.w);
+                        tau = c.x;  dens = c.y;  ind = __float_as_int(c.w);
+                        lid = __float_as_int(c.z) & 0xffff;  lsh = __float_as_int(c.z) & ~0xffff;
+                        { const int l3 = 3 * (lsh >> 16);  kabs = sL[l3];  ksca = sL[l3 + 1];  tw = sL[l3 + 2]; }
                         nvisit = 0;
                         mode = SOC_BM_STEP;
                     }
@@ -207,9 +225,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
         if (mode == SOC_BM_STEP) {
             const int   oind = ind, lid0 = lid;
             const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-            float kabs, ksca;
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
-            else     { kabs = S.ABS;  ksca = S.SCA; }
             // GetStep (kernel_ASOC_aux.c:282-315) with the same results from fewer instructions:
             //  * fmod(p,1) of a positive p is v_fract (exact); a lane with a negative coordinate (possible
             //    only right after a failed-step nudge) sends the wave through the general form;
@@ -242,12 +258,12 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
             const float dtau = ds * d0 * ksca;
             if (free_path < (tau + dtau)) {
                 px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                mode = SOC_BM_SWAP;  key = A.NB + 1;                          // -> scattering queue
+                mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> 16) + 1;          // -> scattering queue of its launch
             } else {
                 // every lane of the wave in the interval where soc_expf_small == soc_expf (the common case)
                 const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                 const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[lid0], delta * S.TW);
+                atomicAdd(&sT[lid0], delta * tw);
                 if (WINT) atomicAdd(&sI[lid0], delta);
                 n_tally++;
                 photons *= e;
@@ -260,7 +276,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
                 py += failed ? (SOC_PEPS * uy) : 0.0f;
                 pz += failed ? (SOC_PEPS * uz) : 0.0f;
                 nvisit++;
-                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB; }       // -> creation queue
+                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> 16); }   // -> creation queue
                 else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = nb; }
             }
         }
@@ -282,7 +298,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
             }
         }
     }
-    for (int i = threadIdx.x; i < A.NB + 3; i += nthr) {
+    for (int i = threadIdx.x; i < NQ; i += nthr) {
         const int c = sH[i];
         if (c) atomicAdd(&A.hist[i], c);
     }
@@ -291,7 +307,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSim &S
 
 // creation and scattering, one lane per queued packet
 template <bool ABU, bool WINT>
-__device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim &S, const SocBrickArgs &A, const int ebid, const int slice)
+__device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
     // ebid counts from the first event descriptor (event queues sort last);
     // slice: blockDim.x packets of the chunk -- one packet per lane
@@ -306,10 +322,13 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
         D.count = min((int)blockDim.x, D.count - first);
     }
     SocPk2 *pk = A.pk;
+    const int NQ = A.NB + 2 * K.n + 1;
+    const int lq = (D.brick - A.NB) >> 1;                  // the launch this queue belongs to (workgroup-uniform)
+    const SocSim &S = K.S[lq];
     extern __shared__ float lds[];
-    int   *sH   = (int *)lds;                              // [NB+3]
-    int   *sCtl = sH + A.NB + 3;                           // [0..2] stats, [4] = 0 (OFF[0])
-    for (int i = threadIdx.x; i < A.NB + 3; i += blockDim.x) sH[i] = 0;
+    int   *sH   = (int *)lds;                              // [NQ]
+    int   *sCtl = sH + NQ;                                 // [0..2] stats, [4] = 0 (OFF[0])
+    for (int i = threadIdx.x; i < NQ; i += blockDim.x) sH[i] = 0;
     if (threadIdx.x < 8) sCtl[threadIdx.x] = 0;
     __syncthreads();
     const int *sOFF0 = sCtl + 4;
@@ -323,13 +342,13 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
         w.px = p.A.x;  w.py = p.A.y;  w.pz = p.A.z;  w.photons = p.A.w;
         w.ux = p.B.x;  w.uy = p.B.y;  w.uz = p.B.z;  w.free_path = p.B.w;
         w.tau = p.C.x;  w.dens = p.C.y;
-        int lid = __float_as_int(p.C.z);
+        int lid = __float_as_int(p.C.z) & 0xffff;
         w.ind = __float_as_int(p.C.w);
         w.rng.x = p.D.x;  w.rng.c = p.D.y;
         int III = (int)(p.D.z & 0xffffffu);
         w.scat = (int)(p.D.z >> 24);
         int key = (int)p.D.w;
-        bool create = (D.brick == A.NB);
+        bool create = (((D.brick - A.NB) & 1) == 0);
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
             const int oind = w.ind;
@@ -358,10 +377,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
             if (w.scat > 20) { w.ind = -1;  create = true; }                  // dropped after 20 scatterings
         }
         if (create) {
-            const int id = (int)(S.gid0 + wid);
+            const int id = (int)(S.gid0 + (wid - K.first[lq]));
             const SocSurfElem E = soc_surface_element(G, S, id);
             while (true) {
-                if (III >= S.BATCH) { key = A.NB + 2;  break; }                // work item finished
+                if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
                 soc_pb_create<false>(G, S, sOFF0, E, III, w);
                 III++;
                 n_pkt++;
@@ -371,7 +390,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
         }
         p.A = make_float4(w.px, w.py, w.pz, w.photons);
         p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
-        p.C = make_float4(w.tau, w.dens, __int_as_float(lid), __int_as_float(w.ind));
+        p.C = make_float4(w.tau, w.dens, __int_as_float(lid | (lq << 16)), __int_as_float(w.ind));
         p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), (uint32_t)key);
         pk[wid] = p;
         A.keyq[D.start + j] = (uint32_t)key;
@@ -381,7 +400,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
     atomicAdd(&sCtl[1], (int)n_pkt);
     atomicAdd(&sCtl[2], (int)n_scat);
     __syncthreads();
-    for (int i = threadIdx.x; i < A.NB + 3; i += blockDim.x) {
+    for (int i = threadIdx.x; i < NQ; i += blockDim.x) {
         const int c = sH[i];
         if (c) atomicAdd(&A.hist[i], c);
     }
@@ -396,14 +415,14 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSim 
 // once if it belongs to an event queue), the blocks after them are the event workgroups.  The short,
 // latency-bound event work runs beside the walk instead of after it.
 template <bool ABU, bool WINT>
-__global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSim S, const SocBrickArgs A, const int nwalk, const int slices)
+__global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSimPack K, const SocBrickArgs A, const int nwalk, const int slices)
 {
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
-        soc_brick_walk<ABU, WINT>(G, S, A, b);
+        soc_brick_walk<ABU, WINT>(G, K, A, b);
     } else {
         const int e = b - nwalk;
-        soc_brick_events<ABU, WINT>(G, S, A, e / slices, e % slices);
+        soc_brick_events<ABU, WINT>(G, K, A, e / slices, e % slices);
     }
 }
 
@@ -495,21 +514,16 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A)
 // host orchestration
 // ---------------------------------------------------------------------------------------
 
-#define SOC_BRICK_MAXPOP 8
-
 struct SocBrickBuffers {
     size_t cap_items = 0;
-    int    cap_nb = 0, cap_desc = 0;
+    int    cap_nq = 0, cap_desc = 0;
     SocPk2 *pk = nullptr;
     uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr;
     int *hist = nullptr, *off = nullptr, *cursor = nullptr, *ndesc = nullptr, *total = nullptr;
     SocDesc *desc[2] = { nullptr, nullptr };
-    hipStream_t side = nullptr;                           // populations 1.. run on their own streams
-    hipEvent_t  join = nullptr;
 };
 
-static SocBrickBuffers g_bb[16][SOC_BRICK_MAXPOP];        // per device ordinal, per population
-static hipEvent_t g_fork[16];
+static SocBrickBuffers g_bb[16];                          // one set per device ordinal
 
 #define BCHK(call)                          \
     do {                                    \
@@ -527,89 +541,21 @@ static hipError_t brick_alloc(T **p, size_t n)
 void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
-    for (int q = 0; q < SOC_BRICK_MAXPOP; q++) {
-        SocBrickBuffers &b = g_bb[device][q];
-        void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
-        for (void *p : ptrs) if (p) (void)hipFree(p);
-        if (b.side) (void)hipStreamDestroy(b.side);
-        if (b.join) (void)hipEventDestroy(b.join);
-        b = SocBrickBuffers();
-    }
-    if (g_fork[device]) { (void)hipEventDestroy(g_fork[device]);  g_fork[device] = nullptr; }
+    SocBrickBuffers &b = g_bb[device];
+    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    b = SocBrickBuffers();
 }
 
-// one population: a contiguous range of the launch's work items with its own queues
-struct SocBrickPop {
-    SocBrickBuffers *bb;
-    SocSim S;
-    SocBrickArgs A;
-    uint32_t count;
-    int maxdesc;
-    hipStream_t st;
-    int total;
-};
-
-static hipError_t pop_prepare(SocBrickPop &P, hipStream_t sync_st)
+// LB: log2 of the brick edge.  nlaunch launches (same geometry, same tallies; scalar opacities and no
+// INT tally when nlaunch > 1) share one sweep: more packets in flight per pass, and the passes in which
+// one launch's last work items finish are filled by the others.  Returns hipErrorNotSupported when the
+// launches cannot use bricks.
+hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
+                            hipStream_t st, int *passes_out)
 {
-    SocBrickBuffers &bb = *P.bb;
-    const uint32_t count = P.count;
-    if (bb.cap_items < count) {
-        BCHK(hipStreamSynchronize(sync_st));
-        BCHK(brick_alloc(&bb.pk, count));
-        BCHK(brick_alloc(&bb.idq[0], count));
-        BCHK(brick_alloc(&bb.idq[1], count));
-        BCHK(brick_alloc(&bb.keyq, count));
-        bb.cap_items = count;
-    }
-    if (bb.cap_nb < P.A.NB + 3) {
-        BCHK(hipStreamSynchronize(sync_st));
-        BCHK(brick_alloc(&bb.hist, P.A.NB + 3));
-        BCHK(brick_alloc(&bb.off, P.A.NB + 3));
-        BCHK(brick_alloc(&bb.cursor, P.A.NB + 3));
-        bb.cap_nb = P.A.NB + 3;
-    }
-    if (bb.cap_desc < P.maxdesc) {
-        BCHK(hipStreamSynchronize(sync_st));
-        BCHK(brick_alloc(&bb.desc[0], P.maxdesc));
-        BCHK(brick_alloc(&bb.desc[1], P.maxdesc));
-        bb.cap_desc = P.maxdesc;
-    }
-    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1)); }
-    P.A.pk = bb.pk;  P.A.keyq = bb.keyq;  P.A.hist = bb.hist;  P.A.off = bb.off;  P.A.cursor = bb.cursor;  P.A.total = bb.total;
-    return hipSuccess;
-}
-
-// one pass of one population: walk, events, scan, scatter on the population's stream
-static hipError_t pop_pass(const SocGrid &G, SocBrickPop &P, int vkey, int c, size_t lds_walk, size_t lds_ev, size_t lds_scat)
-{
-    SocBrickBuffers &bb = *P.bb;
-    SocBrickArgs &A = P.A;
-    A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
-    A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
-    A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-    const int slices = (A.P + A.T - 1) / A.T;
-    const int nev = ((int)((P.count + A.P - 1) / A.P) + 2) * slices;
-    const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
-    switch (vkey) {
-    case 0:  soc_brick_pass<false, false><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
-    case 1:  soc_brick_pass<false, true><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
-    case 2:  soc_brick_pass<true, false><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
-    default: soc_brick_pass<true, true><<<P.maxdesc + nev, A.T, lds, P.st>>>(G, P.S, A, P.maxdesc, slices); break;
-    }
-    SocBrickArgs Q = A;                                   // the sort sees NB + 2 live queues; [NB+2] = finished
-    Q.NB = A.NB + 2;
-    Q.ev_brick = A.NB;
-    soc_brick_scan<<<1, 1024, 0, P.st>>>(Q);
-    soc_brick_scatter<<<P.maxdesc, SOC_BRICK_T, lds_scat, P.st>>>(Q);
-    return hipGetLastError();
-}
-
-// LB: log2 of the brick edge.  Returns hipErrorNotSupported when the launch cannot use bricks.
-hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &Sin, const SocVariant &V, int LB, hipStream_t st,
-                            int *passes_out)
-{
-    if (V.octree || device < 0 || device >= 16) return hipErrorNotSupported;
-    if (Sin.BATCH >= (1 << 24)) return hipErrorNotSupported;          // III shares a word with the scattering count
+    if (V.octree || device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
+    if (nlaunch > 1 && (V.abu || V.wint)) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
@@ -617,83 +563,101 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &Sin, con
     A.NBX = (G.NX + B - 1) / B;  A.NBY = (G.NY + B - 1) / B;  A.NBZ = (G.NZ + B - 1) / B;
     A.NB = A.NBX * A.NBY * A.NBZ;
     if (A.NB > 8192) return hipErrorNotSupported;
-    // workgroup shape and population count; overridable for experiments (measured on C2)
+    // workgroup shape; overridable for experiments (measured on C2)
     A.T = 512;
     A.P = 4 * A.T;
     A.KCAP = 32;
     A.FTH = 16;
-    int npop = 1;
     if (const char *e = getenv("SOC_BRICK_T")) A.T = atoi(e);
     if (const char *e = getenv("SOC_BRICK_P")) A.P = atoi(e);
     if (const char *e = getenv("SOC_BRICK_KCAP")) A.KCAP = atoi(e);
     if (const char *e = getenv("SOC_BRICK_FTH")) A.FTH = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_NPOP")) npop = atoi(e);
     if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
-    if (npop < 1) npop = 1;
-    if (npop > SOC_BRICK_MAXPOP) npop = SOC_BRICK_MAXPOP;
-    uint32_t count = Sin.gid_count;
-    if (Sin.SOURCE == 1) {
-        const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
-        if ((long long)Sin.gid0 >= lim) return hipSuccess;
-        if ((long long)Sin.gid0 + count > lim) count = (uint32_t)(lim - Sin.gid0);
+
+    SocSimPack K{};
+    uint32_t count = 0;
+    for (int l = 0; l < nlaunch; l++) {
+        const SocSim &S = Sin[l];
+        if (S.BATCH >= (1 << 24)) return hipErrorNotSupported;       // III shares a word with the scattering count
+        uint32_t c = S.gid_count;
+        if (S.SOURCE == 1 && !getenv("SOC_EXPERIMENT_OVERSUB")) {
+            const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
+            if ((long long)S.gid0 >= lim) c = 0;
+            else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);
+        }
+        if (S.BATCH <= 0) c = 0;
+        if (c == 0) continue;                                         // nothing to do for this launch
+        if ((unsigned long long)count + c > 0x7fffffffull) return hipErrorNotSupported;
+        K.S[K.n] = S;
+        K.S[K.n].gid_count = c;
+        K.first[K.n] = count;
+        count += c;
+        K.n++;
     }
-    if (count == 0 || Sin.BATCH <= 0) return hipSuccess;
-    while (npop > 1 && count / npop < 65536) npop--;                  // small launches: one population
+    if (K.n == 0) { if (passes_out) *passes_out = 0;  return hipSuccess; }
+    for (int l = K.n; l <= SOC_MAXLAUNCH; l++) K.first[l] = count;
+    const int NQ = A.NB + 2 * K.n + 1;
+    const int maxdesc = (int)((count + A.P - 1) / A.P) + NQ + K.n;
+
+    SocBrickBuffers &bb = g_bb[device];
+    if (bb.cap_items < count) {
+        BCHK(hipStreamSynchronize(st));
+        BCHK(brick_alloc(&bb.pk, count));
+        BCHK(brick_alloc(&bb.idq[0], count));
+        BCHK(brick_alloc(&bb.idq[1], count));
+        BCHK(brick_alloc(&bb.keyq, count));
+        bb.cap_items = count;
+    }
+    if (bb.cap_nq < NQ) {
+        BCHK(hipStreamSynchronize(st));
+        BCHK(brick_alloc(&bb.hist, NQ));
+        BCHK(brick_alloc(&bb.off, NQ));
+        BCHK(brick_alloc(&bb.cursor, NQ));
+        bb.cap_nq = NQ;
+    }
+    if (bb.cap_desc < maxdesc) {
+        BCHK(hipStreamSynchronize(st));
+        BCHK(brick_alloc(&bb.desc[0], maxdesc));
+        BCHK(brick_alloc(&bb.desc[1], maxdesc));
+        bb.cap_desc = maxdesc;
+    }
+    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1)); }
+    A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
 
     const int BV = 1 << (3 * LB);
-    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + A.NB + 3 + 2) * 4;
-    const size_t lds_ev = (size_t)(A.NB + 3 + 8) * 4;
-    const size_t lds_scat = (size_t)(A.NB + 2) * 4;
+    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + NQ + 2 + 3 * SOC_MAXLAUNCH) * 4;
+    const size_t lds_ev = (size_t)(NQ + 8) * 4;
+    const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
+    const size_t lds_scat = (size_t)(NQ - 1) * 4;
     const int vkey = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
+    const int slices = (A.P + A.T - 1) / A.T;
+    const int nev = ((int)((count + A.P - 1) / A.P) + 3 * K.n) * slices;
 
-    SocBrickPop pops[SOC_BRICK_MAXPOP];
-    const uint32_t per = ((count + npop - 1) / npop + 63) / 64 * 64;
-    if (!g_fork[device]) BCHK(hipEventCreateWithFlags(&g_fork[device], hipEventDisableTiming));
-    for (int q = 0; q < npop; q++) {
-        SocBrickPop &P = pops[q];
-        P.bb = &g_bb[device][q];
-        const uint32_t first = min(count, (uint32_t)q * per);
-        P.count = min(per, count - first);
-        P.S = Sin;
-        P.S.gid0 = Sin.gid0 + first;
-        P.S.gid_count = P.count;
-        P.A = A;
-        P.maxdesc = (int)((P.count + A.P - 1) / A.P) + A.NB + 3;
-        P.total = P.count ? 1 : 0;
-        if (q > 0 && !P.bb->side) {
-            BCHK(hipStreamCreateWithFlags(&P.bb->side, hipStreamNonBlocking));
-            BCHK(hipEventCreateWithFlags(&P.bb->join, hipEventDisableTiming));
-        }
-        P.st = (q == 0) ? st : P.bb->side;
-        if (P.count) BCHK(pop_prepare(P, st));
-    }
-    // the side streams start after everything already queued on st ...
-    BCHK(hipEventRecord(g_fork[device], st));
-    for (int q = 1; q < npop; q++) BCHK(hipStreamWaitEvent(pops[q].st, g_fork[device], 0));
-    for (int q = 0; q < npop; q++) {
-        SocBrickPop &P = pops[q];
-        if (!P.count) continue;
-        soc_brick2_init<<<(max(P.count, (uint32_t)A.NB + 3) + 255) / 256, 256, 0, P.st>>>(P.S, P.A, P.count, P.bb->idq[0], P.bb->desc[0],
-                                                                                          P.bb->ndesc, P.bb->hist);
-    }
+    soc_brick2_init<<<(max(count, (uint32_t)NQ) + 255) / 256, 256, 0, st>>>(K, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
     BCHK(hipGetLastError());
-    int passes = 0;
-    bool busy = true;
-    while (busy) {
-        for (int k = 0; k < 64; k++, passes++)
-            for (int q = 0; q < npop; q++)
-                if (pops[q].total > 0) BCHK(pop_pass(G, pops[q], vkey, k & 1, lds_walk, lds_ev, lds_scat));
-        for (int q = 0; q < npop; q++)
-            if (pops[q].total > 0) BCHK(hipMemcpyAsync(&pops[q].total, pops[q].bb->total, sizeof(int), hipMemcpyDeviceToHost, pops[q].st));
-        for (int q = 0; q < npop; q++) BCHK(hipStreamSynchronize(pops[q].st));
-        busy = false;
-        for (int q = 0; q < npop; q++) busy = busy || (pops[q].total > 0);
+    int passes = 0, total = 1;
+    while (total > 0) {
+        for (int k = 0; k < 64; k++, passes++) {
+            const int c = k & 1;
+            A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
+            A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
+            A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
+            switch (vkey) {
+            case 0:  soc_brick_pass<false, false><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
+            case 1:  soc_brick_pass<false, true><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
+            case 2:  soc_brick_pass<true, false><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
+            default: soc_brick_pass<true, true><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
+            }
+            SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
+            Q.NB = NQ - 1;
+            Q.ev_brick = A.NB;
+            soc_brick_scan<<<1, 1024, 0, st>>>(Q);
+            soc_brick_scatter<<<maxdesc, SOC_BRICK_T, lds_scat, st>>>(Q);
+        }
+        BCHK(hipGetLastError());
+        BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));
+        BCHK(hipStreamSynchronize(st));
         if (passes > 4000000) return hipErrorUnknown;                 // cannot happen: every pass retires work
-    }
-    // ... and st continues after them (all streams are idle here; kept for callers that do not sync)
-    for (int q = 1; q < npop; q++) {
-        BCHK(hipEventRecord(pops[q].bb->join, pops[q].st));
-        BCHK(hipStreamWaitEvent(st, pops[q].bb->join, 0));
     }
     if (passes_out) *passes_out = passes;
     return hipSuccess;

@@ -42,11 +42,19 @@ struct soc_ctx {
     // tallies
     float *dTABS = nullptr, *dINT = nullptr;
     bool   own_TABS = false, own_INT = false;
-    // point-source scratch
-    float4 *dPSPOS = nullptr;
-    float  *dPS = nullptr, *dXPS_AREA = nullptr;
-    int    *dXPS_NSIDE = nullptr, *dXPS_SIDE = nullptr;
-    int     ps_cap = 0;
+    // point-source scratch: slot 0 for immediate launches, one slot per deferred launch of a batch
+    struct SrcBuf {
+        float4 *PSPOS = nullptr;
+        float  *PS = nullptr, *XPS_AREA = nullptr;
+        int    *XPS_NSIDE = nullptr, *XPS_SIDE = nullptr;
+        int     cap = 0;
+    } src[SOC_MAXLAUNCH];
+    // deferred launches (soc_batch_begin .. soc_batch_end): executed together in one brick sweep
+    bool   batching = false;
+    int    batch_max = 4;
+    std::vector<SocSim> pending;
+    float *dCSCslot[SOC_MAXLAUNCH] = {};
+    int    csc_slot_bins = 0;
     // rng
     uint64_t *dSeedTab = nullptr;
     unsigned long long *dStats = nullptr;
@@ -87,6 +95,25 @@ static hipError_t dev_alloc(T **p, size_t n)
     if (*p) { (void)hipFree(*p); *p = nullptr; }
     return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
 }
+
+// Execute the launches deferred since soc_batch_begin: one brick sweep for all of them.
+static int flush_pending(soc_ctx *c)
+{
+    if (c->pending.empty()) return SOC_OK;
+    std::vector<SocSim> todo;
+    todo.swap(c->pending);
+    SocVariant V;
+    V.octree = 0;  V.dbl = 0;  V.abu = 0;  V.wint = 0;      // what makes a launch deferrable (see soc_sim_pb)
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, c->stream, &c->last_passes);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
+    return SOC_OK;
+}
+#define FLUSH(c)                                    \
+    do {                                            \
+        int f_ = flush_pending(c);                  \
+        if (f_) return f_;                          \
+    } while (0)
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -133,10 +160,15 @@ int soc_create(int device, soc_ctx **out)
 void soc_destroy(soc_ctx *c)
 {
     if (!c) return;
+    (void)flush_pending(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dPSPOS, c->dPS,
-                     c->dXPS_AREA, c->dXPS_NSIDE, c->dXPS_SIDE, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP,
+    for (auto &b : c->src) {
+        void *sb[] = { b.PSPOS, b.PS, b.XPS_AREA, b.XPS_NSIDE, b.XPS_SIDE };
+        for (void *q : sb) if (q) (void)hipFree(q);
+    }
+    for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
+    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -152,6 +184,7 @@ void soc_destroy(soc_ctx *c)
 int soc_set_stream(soc_ctx *c, void *hip_stream)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return SOC_OK;
 }
@@ -159,6 +192,7 @@ int soc_set_stream(soc_ctx *c, void *hip_stream)
 int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *LCELLS, const float *DENS)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!LCELLS || !DENS) return fail(c, SOC_ERR_ARG, "soc_set_grid: NULL array");
     if (NX < 1 || NY < 1 || NZ < 1 || NX > 9999) return fail(c, SOC_ERR_ARG, "soc_set_grid: bad dimensions %d %d %d", NX, NY, NZ);
     if (LEVELS < 1 || LEVELS > SOC_MAXL) return fail(c, SOC_ERR_ARG, "soc_set_grid: LEVELS=%d unsupported (1..%d)", LEVELS, SOC_MAXL);
@@ -219,6 +253,7 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
 int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!(ps_method == 0 || ps_method == 1 || ps_method == 2 || ps_method == 4 || ps_method == 5))
         return fail(c, SOC_ERR_ARG, "soc_set_features: PS_METHOD %d not supported (0,1,2,4,5)", ps_method);
     if (use_emweight < 0 || use_emweight > 1)
@@ -232,6 +267,7 @@ int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
 int soc_set_mirror(soc_ctx *c, int mask)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (mask < 0 || mask > 63) return fail(c, SOC_ERR_ARG, "soc_set_mirror: mask %d (bits x,X,y,Y,z,Z = 1,2,4,8,16,32)", mask);
     c->mirror = mask;
     return SOC_OK;
@@ -240,6 +276,7 @@ int soc_set_mirror(soc_ctx *c, int mask)
 int soc_set_exec(soc_ctx *c, int mode, int brick_log2)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (mode < -1 || mode > 1 || brick_log2 < 2 || brick_log2 > 4)
         return fail(c, SOC_ERR_ARG, "soc_set_exec: mode %d (-1,0,1), brick_log2 %d (2..4)", mode, brick_log2);
     c->exec_mode = mode;
@@ -262,6 +299,7 @@ int soc_set_optical(soc_ctx *c, const float *ABS, const float *SCA, int ndust)
 int soc_set_opt(soc_ctx *c, const float *OPT)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_opt: call soc_set_grid first");
     HIPCHK(c, hipSetDevice(c->device));
     if (!OPT) {
@@ -297,6 +335,7 @@ int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BI
 int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_emission: call soc_set_grid first");
     if (!EMIT) return fail(c, SOC_ERR_ARG, "soc_set_emission: EMIT is NULL");
     HIPCHK(c, hipSetDevice(c->device));
@@ -323,6 +362,7 @@ static float *tally_buf(soc_ctx *c, int which)
 int soc_zero(soc_ctx *c, int tag)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_zero: call soc_set_grid first");
     float *b = tally_buf(c, tag);
     if (!b) return fail(c, SOC_ERR_ARG, "soc_zero: tag %d", tag);
@@ -368,8 +408,9 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
 // reference reads the integer bit patterns as floats: floor(u*asfloat(nside)*0.999999f) and
 // (int)asfloat(side).  The values the reference kernel ends up with are computed here.
 static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *PSPOS, const float *PS, int NO_PS,
-                          const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA, bool xps_as_float)
+                          const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA, bool xps_as_float, int slot = 0)
 {
+    soc_ctx::SrcBuf &B = c->src[slot];
     if (NO_PS < 1 || !PSPOS || !PS) return fail(c, SOC_ERR_ARG, "%s: point sources need PSPOS, PS and NO_PS>=1", who);
     if ((c->ps_method == 2 || c->ps_method == 5) && (!XPS_NSIDE || !XPS_SIDE || !XPS_AREA))
         return fail(c, SOC_ERR_ARG, "%s: PS_METHOD %d needs XPS_NSIDE/XPS_SIDE/XPS_AREA", who, c->ps_method);
@@ -388,25 +429,25 @@ static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *P
         for (auto &v : nside) { float f;  memcpy(&f, &v, 4);  v = (f * 0.999999f < 1.0f) ? 0 : (int32_t)f; }
         for (auto &v : side)  { float f;  memcpy(&f, &v, 4);  v = (int32_t)f; }
     }
-    if (NO_PS > c->ps_cap) {
+    if (NO_PS > B.cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, dev_alloc(&c->dPSPOS, (size_t)NO_PS));
-        HIPCHK(c, dev_alloc(&c->dPS, (size_t)NO_PS));
-        HIPCHK(c, dev_alloc(&c->dXPS_NSIDE, (size_t)NO_PS));
-        HIPCHK(c, dev_alloc(&c->dXPS_SIDE, (size_t)3 * NO_PS));
-        HIPCHK(c, dev_alloc(&c->dXPS_AREA, (size_t)3 * NO_PS));
-        c->ps_cap = NO_PS;
+        HIPCHK(c, dev_alloc(&B.PSPOS, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&B.PS, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&B.XPS_NSIDE, (size_t)NO_PS));
+        HIPCHK(c, dev_alloc(&B.XPS_SIDE, (size_t)3 * NO_PS));
+        HIPCHK(c, dev_alloc(&B.XPS_AREA, (size_t)3 * NO_PS));
+        B.cap = NO_PS;
     }
-    HIPCHK(c, hipMemcpyAsync(c->dPSPOS, PSPOS, (size_t)NO_PS * 16, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dPS, PS, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dXPS_NSIDE, nside.data(), (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dXPS_SIDE, side.data(), (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
-    if (XPS_AREA)  HIPCHK(c, hipMemcpyAsync(c->dXPS_AREA, XPS_AREA, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
-    else           HIPCHK(c, hipMemsetAsync(c->dXPS_AREA, 0, (size_t)NO_PS * 12, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.PSPOS, PSPOS, (size_t)NO_PS * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.PS, PS, (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.XPS_NSIDE, nside.data(), (size_t)NO_PS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.XPS_SIDE, side.data(), (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+    if (XPS_AREA)  HIPCHK(c, hipMemcpyAsync(B.XPS_AREA, XPS_AREA, (size_t)NO_PS * 12, hipMemcpyHostToDevice, c->stream));
+    else           HIPCHK(c, hipMemsetAsync(B.XPS_AREA, 0, (size_t)NO_PS * 12, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     S.NO_PS = NO_PS;
-    S.PSPOS = c->dPSPOS; S.PS = c->dPS;
-    S.XPS_NSIDE = c->dXPS_NSIDE; S.XPS_SIDE = c->dXPS_SIDE; S.XPS_AREA = c->dXPS_AREA;
+    S.PSPOS = B.PSPOS; S.PS = B.PS;
+    S.XPS_NSIDE = B.XPS_NSIDE; S.XPS_SIDE = B.XPS_SIDE; S.XPS_AREA = B.XPS_AREA;
     return SOC_OK;
 }
 
@@ -424,13 +465,6 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     SocSim S;
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
-    if (SOURCE == 0) {
-        r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false);
-        if (r) return r;
-    } else {
-        S.NO_PS = 1;
-    }
-    c->last_passes = 0;
     // brick sweep: Cartesian grids with enough work items to fill the chip
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
@@ -438,8 +472,32 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8;
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (octree, mirror or > 8192 bricks)");
+    // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
+    // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
+    const bool defer = c->batching && bricks && !V.abu && !V.wint;
+    if (!defer) FLUSH(c);
+    const int slot = defer ? (int)c->pending.size() : 0;
+    if (SOURCE == 0) {
+        r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false, slot);
+        if (r) return r;
+    } else {
+        S.NO_PS = 1;
+    }
+    c->last_passes = 0;
+    if (defer) {
+        if (c->csc_slot_bins != c->BINS) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int k = 0; k < SOC_MAXLAUNCH; k++) HIPCHK(c, dev_alloc(&c->dCSCslot[k], (size_t)c->BINS));
+            c->csc_slot_bins = c->BINS;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dCSCslot[slot], c->dCSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
+        S.CSC = c->dCSCslot[slot];
+        c->pending.push_back(S);
+        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        return SOC_OK;
+    }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, S, V, c->brick_log2, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -447,9 +505,29 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     return SOC_OK;
 }
 
+int soc_batch_begin(soc_ctx *c, int max_launches)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (max_launches < 0 || max_launches > SOC_MAXLAUNCH)
+        return fail(c, SOC_ERR_ARG, "soc_batch_begin: max_launches %d (1..%d, 0 = default)", max_launches, SOC_MAXLAUNCH);
+    FLUSH(c);
+    c->batching = true;
+    c->batch_max = max_launches ? max_launches : 4;
+    return SOC_OK;
+}
+
+int soc_batch_end(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    c->batching = false;
+    FLUSH(c);
+    return SOC_OK;
+}
+
 int soc_set_hpbg(soc_ctx *c, const float *BG, const float *HPBGP)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!BG) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: BG is NULL");
     const int NPIX = 49152;                                 // NSIDE = 64, fixed in the reference (ASOC.py:297)
     for (int i = 0; i < NPIX; i++)
@@ -477,6 +555,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     int r = check_launch(c, "soc_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_hpbg) return fail(c, SOC_ERR_STATE, "soc_sim_hp: call soc_set_hpbg first");
@@ -495,6 +574,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     int r = check_launch(c, "soc_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sim_cl: call soc_set_emission first");
@@ -515,6 +595,7 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
                      int NPIX_X, int NPIX_Y, float MAP_DX, const float *CENTRE, int FFS)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (NDIR < 1 || NDIR > 4096 || !ODIR || !RA || !DE || !CENTRE)
         return fail(c, SOC_ERR_ARG, "soc_sca_set_view: need 1 <= NDIR <= 4096 observer directions (Healpix output, NDIR<0, is not supported)");
     if (NPIX_X < 1 || NPIX_Y < 1 || (int64_t)NDIR * NPIX_X * NPIX_Y > 2147483647LL || !(MAP_DX > 0.0f))
@@ -559,6 +640,7 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
 int soc_sca_zero(soc_ctx *c)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_zero: call soc_sca_set_view first");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->dOUT, 0, (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y * 4, c->stream));
@@ -585,6 +667,7 @@ int soc_sca_sim_ps(soc_ctx *c, int PACKETS, int BATCH, float SEED, float BG, con
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     int r = check_launch(c, "soc_sca_sim_ps", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     HIPCHK(c, hipSetDevice(c->device));
@@ -602,6 +685,7 @@ int soc_sca_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, f
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     int r = check_launch(c, "soc_sca_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (SOURCE != 0 && SOURCE != 1)
@@ -623,6 +707,7 @@ int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, i
 {
     (void)PACKETS;  (void)SOURCE;
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     int r = check_launch(c, "soc_sca_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sca_sim_cl: call soc_set_emission first");
@@ -637,6 +722,7 @@ int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, i
 int soc_sca_read_out(soc_ctx *c, float *out, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_read_out: call soc_sca_set_view first");
     const int64_t npix = (int64_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y;
     if (!out || n < 0 || n > npix) return fail(c, SOC_ERR_ARG, "soc_sca_read_out: n=%lld (image has %lld values)", (long long)n, (long long)npix);
@@ -651,6 +737,7 @@ void *soc_sca_out_ptr(soc_ctx *c) { return (c && c->have_view) ? (void *)c->dOUT
 int soc_sca_bind_out(soc_ctx *c, void *device_ptr)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_bind_out: call soc_sca_set_view first");
     if (!device_ptr) return fail(c, SOC_ERR_ARG, "soc_sca_bind_out: NULL pointer");
     HIPCHK(c, hipSetDevice(c->device));
@@ -664,6 +751,7 @@ int soc_sca_bind_out(soc_ctx *c, void *device_ptr)
 int soc_sync(soc_ctx *c)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
@@ -672,6 +760,7 @@ int soc_sync(soc_ctx *c)
 int soc_read_tally(soc_ctx *c, int which, float *out, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_read_tally: call soc_set_grid first");
     float *b = tally_buf(c, which);
     if (!b || !out || n < 0 || n > c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_read_tally: which=%d n=%lld", which, (long long)n);
@@ -684,6 +773,7 @@ int soc_read_tally(soc_ctx *c, int which, float *out, int64_t n)
 int soc_write_tally(soc_ctx *c, int which, const float *in, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_write_tally: call soc_set_grid first");
     float *b = tally_buf(c, which);
     if (!b || !in || n < 0 || n > c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_write_tally: which=%d n=%lld", which, (long long)n);
@@ -698,6 +788,7 @@ void *soc_tally_ptr(soc_ctx *c, int which) { return c ? (void *)tally_buf(c, whi
 int soc_bind_tally(soc_ctx *c, int which, void *device_ptr)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!device_ptr || (which != SOC_TALLY_TABS && which != SOC_TALLY_INT)) return fail(c, SOC_ERR_ARG, "soc_bind_tally: which=%d ptr=%p", which, device_ptr);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -714,6 +805,7 @@ int soc_bind_tally(soc_ctx *c, int which, void *device_ptr)
 int soc_read_par(soc_ctx *c, int32_t *out, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_read_par: call soc_set_grid first");
     if (!out || n < 0 || n > c->npar) return fail(c, SOC_ERR_ARG, "soc_read_par: n=%lld (have %lld)", (long long)n, (long long)c->npar);
     HIPCHK(c, hipSetDevice(c->device));
@@ -724,6 +816,7 @@ int soc_read_par(soc_ctx *c, int32_t *out, int64_t n)
 int soc_stats(soc_ctx *c, uint64_t out[3], int reset)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     unsigned long long h[3];
@@ -744,6 +837,7 @@ int soc_timer_start(soc_ctx *c)
 int soc_timer_stop(soc_ctx *c, float *elapsed_ms)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -761,6 +855,7 @@ int soc_a2e_set_size(soc_ctx *c, int NE, int NFREQ, int noIw, const float *Iw, c
                      const int32_t *L2, const float *Tdown, const float *EA, const int32_t *Ibeg, const float *AF)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (NE < 3 || NE > 280 || NFREQ < 2 || noIw < 0 || !Iw || !L1 || !L2 || !Tdown || !EA || !Ibeg || !AF)
         return fail(c, SOC_ERR_ARG, "soc_a2e_set_size: bad arguments (3 <= NE <= 280, NFREQ >= 2)");
     // pair tables in the reference's (l, u) loop order; validate every window on the host
@@ -832,6 +927,7 @@ int soc_a2e_upload(soc_ctx *c, int batch, const float *AABS)
 int soc_a2e_run(soc_ctx *c, int batch)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->a2e_NE == 0 || batch < 1 || batch > c->a2e_cap) return fail(c, SOC_ERR_STATE, "soc_a2e_run: upload a batch first");
     SocA2EArgs A{};
@@ -866,6 +962,7 @@ int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int N
                    const float *ABS, float *T, float *EMIT)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (batch < 1 || NFREQ < 2 || NIP < 2 || !FREQ || !KABS || !TTT || !ABS || !T || !EMIT)
         return fail(c, SOC_ERR_ARG, "soc_a2e_eqtemp: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
@@ -898,6 +995,7 @@ int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int N
 int soc_probe_rng(soc_ctx *c, float SEED, uint32_t gid_first, uint32_t n, int ndraw, uint32_t *state_xc, uint32_t *draws)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!state_xc || !draws || ndraw < 0 || n == 0) return fail(c, SOC_ERR_ARG, "soc_probe_rng: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t *dS = nullptr, *dD = nullptr;
@@ -916,6 +1014,7 @@ int soc_probe_rng(soc_ctx *c, float SEED, uint32_t gid_first, uint32_t n, int nd
 int soc_probe_math(soc_ctx *c, int fn, const float *x, float *y, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!x || !y || n <= 0) return fail(c, SOC_ERR_ARG, "soc_probe_math: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     float *dx = nullptr, *dy = nullptr;
@@ -935,6 +1034,7 @@ int soc_probe_trace(soc_ctx *c, const float pos[3], const float dir[3], int maxs
                     int32_t *levels, int32_t *inds, float *ds, float endpos[3], int32_t *nsteps)
 {
     if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_probe_trace: call soc_set_grid first");
     if (!pos || !dir || maxsteps < 1 || !levels || !inds || !ds || !endpos || !nsteps) return fail(c, SOC_ERR_ARG, "soc_probe_trace: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));

@@ -38,6 +38,15 @@ struct SocSim {
     unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
 };
 
+// Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the
+// sweep's work items [first[l], first[l+1]); geometry and tallies are shared.
+#define SOC_MAXLAUNCH 8
+struct SocSimPack {
+    int      n;
+    uint32_t first[SOC_MAXLAUNCH + 1];
+    SocSim   S[SOC_MAXLAUNCH];
+};
+
 // feature switches that the reference selects with #if; compiled ahead of time here
 struct SocVariant {
     int octree;                /* LEVELS > 1                                              */
@@ -97,7 +106,7 @@ hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st);
 hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
 
 // brick-sweep execution (soc_brick.hip): LDS-resident tallies, packets sorted by brick
-hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim &S, const SocVariant &V, int LB,
+hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *S, int nlaunch, const SocVariant &V, int LB,
                             hipStream_t st, int *passes_out);
 void soc_brick_release(int device);
 

@@ -38,6 +38,8 @@ API = {
                              _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
     "soc_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int]),
+    "soc_batch_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_batch_end": (C.c_int, [C.c_void_p]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
     "soc_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
@@ -156,6 +158,13 @@ class Engine:
 
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self._chk(self.lib.soc_set_features(self.h, int(with_int), int(ps_method), int(use_emweight)))
+
+    def batch_begin(self, max_launches=0):
+        """Defer the following sim_pb launches and run them together (brick sweep, TABS only)."""
+        self._chk(self.lib.soc_batch_begin(self.h, int(max_launches)))
+
+    def batch_end(self):
+        self._chk(self.lib.soc_batch_end(self.h))
 
     def set_mirror(self, mask=0):
         """reflecting faces, bits x,X,y,Y,z,Z = 1,2,4,8,16,32"""
