@@ -158,6 +158,11 @@ int soc_timer_stop(soc_ctx *ctx, float *elapsed_ms);
 int soc_sca_set_view(soc_ctx *ctx, int NDIR, const float *ODIR, const float *RA, const float *DE,
                      int NPIX_X, int NPIX_Y, float MAP_DX, const float *CENTRE, int FFS);
 
+/* the other form of the view: one Healpix map (RING, NSIDE = USER.OUT_NSIDE) seen by an observer at a
+ * position in root-grid units (`perspective x y z`; ASOCS.py:44-48: NDIR = -NSIDE, ODIR[0] = the
+ * position).  The image has 12*NSIDE^2 pixels; each contribution carries 1/d^2. */
+int soc_sca_set_healpix(soc_ctx *ctx, int NSIDE, const float *OBSERVER, int FFS);
+
 /* replaces zero_out (kernel_ASOC_sca.c:14-35; ASOCS.py:515, 781) */
 int soc_sca_zero(soc_ctx *ctx);
 
@@ -179,7 +184,11 @@ int soc_sca_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED,
  * kernel_ASOC_sca.c:1098-1122); uses EMIT/EMWEI from soc_set_emission() */
 int soc_sca_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count);
 
-/* replaces cl.enqueue_copy(OUT, OUT_buf) (ASOCS.py:715, 874); n = NDIR*NPIX_Y*NPIX_X */
+/* replaces the kernel_HP launch (ASOCS.py:673-679 -> SimRAM_HP, kernel_ASOC_sca.c:40-63): background from
+ * the Healpix sky given to soc_set_hpbg (49152 pixels, photons per package) */
+int soc_sca_sim_hp(soc_ctx *ctx, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count);
+
+/* replaces cl.enqueue_copy(OUT, OUT_buf) (ASOCS.py:715, 874); n = NDIR*NPIX_Y*NPIX_X, or 12*NSIDE^2 */
 int soc_sca_read_out(soc_ctx *ctx, float *out, int64_t n);
 
 /* device address of the image, or bind caller-owned device memory as the image (for an RCCL

@@ -436,16 +436,18 @@ class RefA2E:
 class ScaView:
     """Observer set-up of one scattered-light launch: directions, image size, pixel, centre."""
 
-    def __init__(self, ODIR, RA, DE, NPIX=(16, 16), MAP_DX=1.0, CENTRE=(4.0, 4.0, 4.0), FFS=1):
+    def __init__(self, ODIR, RA, DE, NPIX=(16, 16), MAP_DX=1.0, CENTRE=(4.0, 4.0, 4.0), FFS=1, nside=0):
+        """nside > 0: Healpix map of that NSIDE seen from the position ODIR[0] (NDIR = -nside in the kernels)"""
         self.ODIR, self.RA, self.DE = (np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (ODIR, RA, DE))
-        self.NDIR = len(self.ODIR)
+        self.NDIR = -int(nside) if nside else len(self.ODIR)
+        self.nside = int(nside)
         self.NPIX = (int(NPIX[0]), int(NPIX[1]))
         self.MAP_DX = np.float32(MAP_DX)
         self.CENTRE = tuple(np.float32(c) for c in CENTRE)
         self.FFS = int(FFS)
 
     def out_size(self):
-        return self.NDIR * self.NPIX[0] * self.NPIX[1]
+        return 12 * self.nside * self.nside if self.nside else self.NDIR * self.NPIX[0] * self.NPIX[1]
 
 
 class SArgs(C.Structure):
@@ -454,11 +456,11 @@ class SArgs(C.Structure):
                 ("SEED", C.c_float), ("BG", C.c_float), ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
                 ("ABS", _F), ("SCA", _F), ("PSPOS", _F), ("PS", _F), ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
                 ("DENS", _F), ("EMIT", _F), ("DSC", _F), ("CSC", _F), ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("OUT", _F),
-                ("OPT", _F), ("EMWEI", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F)]
+                ("OPT", _F), ("EMWEI", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("HPBG", _F), ("HPBGP", _F)]
 
 
 def oracle_sim_sca(orc, job, view, kind=0, gid0=0, gid1=None, nthreads=1, stride=1, OUT=None):
-    """kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS (sca versions).  Returns (OUT, contributions)."""
+    """kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS, 3 = SimRAM_HP (sca versions).  Returns (OUT, contributions)."""
     L = orc.lib
     L.orc_sim_sca.restype = C.c_long
     L.orc_sim_sca.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -517,6 +519,8 @@ class RefSca:
         a.OPT = _fp(job.OPT) if job.OPT is not None else None
         a.EMWEI = _fp(job.EMWEI)
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
+        a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
+        assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sca_sim(C.byref(a), kind, gid0, gid1, stride)
         return OUT

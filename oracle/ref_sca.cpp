@@ -10,6 +10,9 @@ void SimRAM_PB(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float
                int *LCELLS, int *OFF, int *PAR, float *DENS, float *DSC, float *CSC, int NDIR, float3 *ODIRS, int2 NPIX,
                float MAP_DX, float3 CENTRE, float3 *ORA, float3 *ODE, float *OUT, float *ABU, float *OPT,
                float *XPS_NSIDE, float *XPS_SIDE, float *XPS_AREA, int *ROI_DIM, float *ROI_LOAD);
+void SimRAM_HP(int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, int *LCELLS, int *OFF, int *PAR, float *DENS,
+               float *DSC, float *CSC, int NDIR, float3 *ODIRS, int2 NPIX, float MAP_DX, float3 CENTRE, float3 *ORA,
+               float3 *ODE, float *OUT, float *ABU, float *OPT, float *BG, float *HPBGP);
 void SimRAM_PS(int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float BG, float3 *PSPOS, float *PS,
                int *LCELLS, int *OFF, int *PAR, float *DENS, float *DSC, float *CSC, int NDIR, float3 *ODIRS, int2 NPIX,
                float MAP_DX, float3 CENTRE, float3 *ORA, float3 *ODE, float *OUT, float *ABU, float *OPT,
@@ -27,9 +30,10 @@ struct sca_args {
     float *DENS, *EMIT, *DSC, *CSC, *ODIRS, *ORA, *ODE, *OUT, *OPT, *EMWEI;
     int   *XPS_NSIDE, *XPS_SIDE;      // int32 on the host, float* in the kernel (as in ASOCS.py)
     float *XPS_AREA;
+    float *HPBG, *HPBGP;              // Healpix sky of the current frequency (sca SimRAM_HP)
 };
 
-// kind 0: SimRAM_PB, 1: SimRAM_CL, 2: SimRAM_PS; work items gid0, gid0+stride, ... < gid1
+// kind 0: SimRAM_PB, 1: SimRAM_CL, 2: SimRAM_PS, 3: SimRAM_HP; work items gid0, gid0+stride, ... < gid1
 void ref_sca_sim(const sca_args *a, int kind, int gid0, int gid1, int stride)
 {
     float dummy[8] = { 0 };
@@ -49,6 +53,10 @@ void ref_sca_sim(const sca_args *a, int kind, int gid0, int gid1, int stride)
             SimRAM_CL(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
                       a->DSC, a->CSC, a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA, (float3 *)a->ODE,
                       a->OUT, a->OPT ? a->OPT : dummy, dummy, a->EMWEI ? a->EMWEI : dummy);
+        else if (kind == 3)
+            SimRAM_HP(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->LCELLS, a->OFF, a->PAR, a->DENS, a->DSC, a->CSC,
+                      a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA, (float3 *)a->ODE, a->OUT, dummy,
+                      a->OPT ? a->OPT : dummy, a->HPBG, a->HPBGP ? a->HPBGP : dummy);
         else
             SimRAM_PS(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->BG, (float3 *)a->PSPOS, a->PS, a->LCELLS, a->OFF,
                       a->PAR, a->DENS, a->DSC, a->CSC, a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA,

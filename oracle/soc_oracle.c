@@ -42,6 +42,7 @@
 #  define M_LDEXP_DN(x, l) ldexpf((x), -(l))
 #  define M_LDEXP_UP(x, l) ldexpf((x), (l))
 #  define M_FLOOR(x) floorf(x)
+#  define M_ATAN2(y, x) atan2f((y), (x))
 #  define M_EXPM1(x) expm1f(x)
 #  define M_POW15(x) powf((x), 1.5f)
 static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
@@ -59,6 +60,7 @@ static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = co
 #  define M_LDEXP_DN(x, l) soc_scale_down((x), (l))
 #  define M_LDEXP_UP(x, l) soc_scale_up((x), (l))
 #  define M_FLOOR(x) soc_floorf(x)
+#  define M_ATAN2(y, x) soc_atan2f((y), (x))
 #  define M_EXPM1(x) soc_expm1f(x)
 #  define M_POW15(x) soc_pow15f(x)
 static inline void M_SINCOS(float x, float *s, float *c) { soc_sincosf(x, s, c); }
@@ -870,8 +872,70 @@ static inline void out_add(const orc_model *M, int i, float v)
  * first free path is evaluated in fp32, -log(1.0f - W*u) (:1742), where PB/CL promote to
  * double through the literal 1.0 (:906, :1256).
  * Returns the number of peel-off contributions added to OUT. */
+/* RootPos (kernel_ASOC_aux.c:169-190): local position of cell (level, ind) -> root-grid coordinates */
+static void RootPos(const orc_model *M, f3 *POS, const int ilevel, const int iind)
+{
+    int level = ilevel, ind = iind, sid;
+    if (level == 0) return;
+    while (level > 0) {
+        ind = M->PAR[M->OFF[level] + ind - M->NX * M->NY * M->NZ];
+        level--;
+        if (level == 0) {
+            POS->x *= 0.5f;  POS->y *= 0.5f;  POS->z *= 0.5f;
+            POS->x += ind % M->NX;
+            POS->y += (ind / M->NX) % M->NY;
+            POS->z += ind / (M->NX * M->NY);
+            return;
+        } else {
+            sid = ind % 8;
+            POS->x *= 0.5f;  POS->y *= 0.5f;  POS->z *= 0.5f;
+            POS->x += sid % 2;  POS->y += (sid / 2) % 2;  POS->z += sid / 4;
+        }
+    }
+}
+
+/* Angles2PixelRing (kernel_ASOC_aux.c:945-984): (phi, theta) -> Healpix RING pixel */
+static int angles2pixel_ring(const int nside, float phi, float theta)
+{
+    int   nl2, nl4, ncap, npix, jp, jm, ipix1, ir, ip, kshift;
+    float z, za, tt, tp, tmp;
+    if ((theta < 0.0f) || (theta > PI_F)) return -1;
+    z  = M_COS(theta);
+    za = fabsf(z);
+    if (phi >= TWOPI) phi -= TWOPI;
+    if (phi < 0.0f)   phi += TWOPI;
+    tt   = phi / 1.5707963268f;
+    nl2  = 2 * nside;
+    nl4  = 4 * nside;
+    ncap = nl2 * (nside - 1);
+    npix = 12 * nside * nside;
+    if (za <= 0.6666666667f) {
+        jp = (int)(nside * (0.5f + tt - z * 0.75f));
+        jm = (int)(nside * (0.5f + tt + z * 0.75f));
+        ir = nside + 1 + jp - jm;
+        kshift = 0;
+        if (ir % 2 == 0) kshift = 1;
+        ip = (int)((jp + jm - nside + kshift + 1) / 2) + 1;
+        if (ip > nl4) ip -= nl4;
+        ipix1 = ncap + nl4 * (ir - 1) + ip;
+    } else {
+        tp  = tt - (int)(tt);
+        tmp = M_SQRT(3.0f * (1.0f - za));
+        jp  = (int)(nside * tp * tmp);
+        jm  = (int)(nside * (1.0f - tp) * tmp);
+        ir  = jp + jm + 1;
+        ip  = (int)(tt * ir) + 1;
+        if (ip > (4 * ir)) ip -= 4 * ir;
+        ipix1 = 2 * ir * (ir - 1) + ip;
+        if (z <= 0.0f) ipix1 = npix - 2 * ir * (ir + 1) + ip;
+    }
+    return (ipix1 - 1);
+}
+
 static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS, int level, int ind, int variant)
 {
+    const int conditioned = variant & 4;        /* direction already clamped + normalised by the caller (SimRAM_HP) */
+    variant &= 3;
     const int is_cl = (variant == 1);
     const float *DENS = M->DENS;
     const int *OFF = M->OFF;
@@ -882,10 +946,12 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
     f3    POS0, ODIR;
     long  nadd = 0;
 
-    if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
-    if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
-    if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
-    normalize3(&DIR);
+    if (!conditioned) {
+        if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+        if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+        if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+        normalize3(&DIR);
+    }
     if (M->FFS > 0) {
         POS0 = POS;  ind0 = ind;  level0 = level;
         tau = 0.0f;
@@ -937,6 +1003,45 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
         POS0.z = POS0.z + dx * DIR.z;
         if (M->WITH_ABU) PHOTONS *= M_EXP(-free_path * M->OPT[2 * (long)oind] / M->OPT[2 * (long)oind + 1]);
         else             PHOTONS *= M_EXP(-free_path * ABS / SCA);
+        if (M->NDIR < 0) {
+            /* Healpix map seen by an observer at ODIRS[0] (kernel_ASOC_sca.c:319-361, :1021-1061, :1312-1358,
+             * :1806-1846): direction and distance from the root position of the scattering, optical depth along
+             * at most that distance, 1/d^2, pixel from the direction */
+            f3 RP;
+            POS = POS0;  ind = ind0;  level = level0;
+            RP = POS;
+            RootPos(M, &RP, level, ind);
+            ODIR.x = M->ODIRS[0] - RP.x;  ODIR.y = M->ODIRS[1] - RP.y;  ODIR.z = M->ODIRS[2] - RP.z;
+            dx = M_SQRT(ODIR.x * ODIR.x + ODIR.y * ODIR.y + ODIR.z * ODIR.z);
+            delta = 1.0f / (dx * dx);
+            normalize3(&ODIR);
+            tau = 0.0f;
+            while ((dx > 0) && (ind >= 0)) {
+                oind = OFF[level] + ind;
+                ds   = GetStep(M, &POS, &ODIR, &level, &ind);
+                ds   = (dx < ds) ? dx : ds;
+                if (variant == 0) ds = (float)((double)ds + 1.0e-6);      /* SimRAM_PB writes "+ 1.0e-6" (:982): double add */
+                else              ds = ds + 1.0e-6f;                      /* :329, :1323, :1821 */
+                dx  -= ds;
+                if (M->WITH_ABU) tau += ds * DENS[oind] * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
+                else             tau += ds * DENS[oind] * (ABS + SCA);
+            }
+            cos_theta = clampf(DIR.x * ODIR.x + DIR.y * ODIR.y + DIR.z * ODIR.z, -CLAMP, +CLAMP);
+            if (is_cl) {
+                const float G = 0.65f;
+                const float fraction = (1.0f / (4.0f * PI_F)) * (1.0f - G * G) / M_POW15(1.0f + G * G - 2.0f * G * cos_theta);
+                delta *= PHOTONS * fraction * ((tau > TAULIM) ? (1.0f - M_EXP(-tau)) : (tau * (1.0f - 0.5f * tau)));
+            } else {
+                delta *= PHOTONS * M_EXP(-tau) * M->DSC[clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
+            }
+            {
+                const float theta = M_ACOS(-ODIR.z);
+                const float phi   = M_ATAN2(+ODIR.y, +ODIR.x);
+                i = angles2pixel_ring(-M->NDIR, phi, theta);
+                out_add(M, i, delta);
+                nadd++;
+            }
+        }
         for (int idir = 0; idir < M->NDIR; idir++) {
             POS = POS0;  ind = ind0;  level = level0;
             tau = 0.0f;
@@ -1053,6 +1158,53 @@ static long sim_sca_cl_workitem(const orc_model *M, int id)
         DIR.z = cos_theta;
         n += walk_packet_sca(M, &rng, POS, DIR, PHOTONS, level, ind, 1);
     }
+}
+
+/* One work item of the sca SimRAM_HP (kernel_ASOC_sca.c:40-470): Healpix background; the packet is
+ * aimed at a disc of radius Rout perpendicular to its direction, on the upstream side of the cloud, and
+ * enters through Surface() -- packets that miss are skipped.  The walk is SimRAM_CL's (same clamp,
+ * HG_TEST weight, no draw when the line of sight is empty). */
+static long sim_sca_hp_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const float Rout = 0.5f * M_SQRT(1.0f * NX * NX + NY * NY + NZ * NZ);
+    int   level = 0, ind = -1;
+    float phi, theta, ds, dx, PHOTONS;
+    f3    DIR, POS, POS0;
+    rng_t rng;
+    long  n = 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    for (int III = 0; III < M->BATCH; III++) {
+        ind     = hp_select_pixel(M, &rng, 12);
+        PHOTONS = M->HPBG[ind];
+        pixel2angles_ring(64, ind, &phi, &theta);
+        DIR.x = +M_SIN(theta) * M_COS(phi);
+        DIR.y = +M_SIN(theta) * M_SIN(phi);
+        DIR.z = -M_COS(theta);
+        if (fabsf(DIR.x) < DEPS) DIR.x = DEPS;
+        if (fabsf(DIR.y) < DEPS) DIR.y = DEPS;
+        if (fabsf(DIR.z) < DEPS) DIR.z = DEPS;
+        normalize3(&DIR);
+        ds = 2.0f * PI_F * Rand(&rng);
+        dx = M_SQRT(Rand(&rng));
+        POS.x = dx * M_COS(ds);
+        POS.y = dx * M_SIN(ds);
+        POS.z = M_SQRT(1.001f - dx * dx);
+        POS0.x = POS.x * M_COS(theta) + POS.z * M_SIN(theta);
+        POS0.y = POS.y;
+        POS0.z = -POS.x * M_SIN(theta) + POS.z * M_COS(theta);
+        POS.x = POS0.x * M_COS(PI_F - phi) + POS0.y * M_SIN(PI_F - phi);
+        POS.y = -POS0.x * M_SIN(PI_F - phi) + POS0.y * M_COS(PI_F - phi);
+        POS.z = POS0.z;
+        POS.x = 0.5f * NX + Rout * POS.x;
+        POS.y = 0.5f * NY + Rout * POS.y;
+        POS.z = 0.5f * NZ + Rout * POS.z;
+        Surface(M, &POS, &DIR);
+        IndexG(M, &POS, &level, &ind);
+        if (ind < 0) continue;
+        n += walk_packet_sca(M, &rng, POS, DIR, PHOTONS, level, ind, 1 | 4);
+    }
+    return n;
 }
 
 /* ================================ exported API ========================================= */
@@ -1181,14 +1333,14 @@ EXPORT long orc_sim_sca(orc_model *M, int kind, int gid0, int gid1, int stride, 
     if (nthreads <= 1) {
         M->threaded = 0;
         for (int id = gid0; id < gid1; id += stride)
-            total += (kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind);
+            total += (kind == 3) ? sim_sca_hp_workitem(M, id) : ((kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind));
     } else {
         M->threaded = 1;
         const long n = ((long)gid1 - gid0 + stride - 1) / stride;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
         for (long k = 0; k < n; k++) {
             int id = (int)(gid0 + k * stride);
-            total += (kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind);
+            total += (kind == 3) ? sim_sca_hp_workitem(M, id) : ((kind == 1) ? sim_sca_cl_workitem(M, id) : sim_sca_pb_workitem(M, id, kind));
         }
     }
     return total;

@@ -10,8 +10,9 @@ OUTCOMING[NFREQ, NDIR, NPIX.y, NPIX.x] in Jy/sr (ASOCS.py:887-899) with the refe
 The host loop (source block II -> frequency; then the CLPAC loop) and every launch formula
 are the reference's; the kernels are soc_amd/csrc/soc_sca.hip.  With several ranks each
 launch is split by logical work-item id and the image is summed with one all-reduce.
-Not covered (refused with a clear message): Healpix output maps / internal observer
-(``perspective``), Healpix background (``hpbg``), ROI files, several scattering functions.
+``perspective x y z`` switches to one Healpix map (``outnside``) seen from that position,
+``hpbg`` to the Healpix background (sca SimRAM_HP).  Not covered (refused with a clear
+message): ROI files, several scattering functions.
 """
 import sys
 import time
@@ -26,15 +27,17 @@ from .launch import PLANCK, PARSEC, Fix
 
 class ScatteringRun(AbsorptionRun):
     def _load_inputs(self):
-        if len(self.U.file_hpbg) > 2:
-            raise UnsupportedOption("hpbg (HEALPix background) in the scattering run")
         super()._load_inputs()
         U, c = self.U, self.cloud
-        if U.INTOBS[0] > -10000.0:
-            raise UnsupportedOption("perspective / Healpix output maps (ASOCS.py:44-48) are not supported by this engine")
         if U.ROIPAC > 0:
             raise UnsupportedOption("roiload in the scattering run")
-        self.NDIR, self.ODIR, self.RA, self.DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+        if len(U.file_hpbg) > 2:                                   # ASOCS.py:104-107: no user scaling here
+            self.HPBG = np.fromfile(U.file_hpbg, np.float32).reshape(self.NFREQ, 49152)
+        self.healpix = U.INTOBS[0] > -10000.0                      # ASOCS.py:44-48: one Healpix map seen from INTOBS
+        if self.healpix:
+            self.NDIR = -int(U.OUT_NSIDE)
+        else:
+            self.NDIR, self.ODIR, self.RA, self.DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
         if U.MAPCENTRE[0] < -1e7:                                  # ASOC_aux.py:791-793
             U.MAPCENTRE = (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)
         m = np.nonzero((self.FFREQ >= U.REMIT_F[0]) & (self.FFREQ <= U.REMIT_F[1]))[0]
@@ -71,9 +74,14 @@ class ScatteringRun(AbsorptionRun):
         e.set_cloud(c)
         e.set_features(with_int=0, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 1))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
-        e.sca_set_view(self.ODIR, self.RA, self.DE, U.NPIX, U.MAP_DX, U.MAPCENTRE, U.FFS)
+        if self.healpix:
+            e.sca_set_healpix(U.OUT_NSIDE, U.INTOBS, U.FFS)
+            npix = 12 * U.OUT_NSIDE * U.OUT_NSIDE
+        else:
+            e.sca_set_view(self.ODIR, self.RA, self.DE, U.NPIX, U.MAP_DX, U.MAPCENTRE, U.FFS)
+            npix = self.NDIR * U.NPIX[0] * U.NPIX[1]
         if self.comm:
-            self.comm.attach_image(e, self.NDIR * U.NPIX[0] * U.NPIX[1])
+            self.comm.attach_image(e, npix)
 
     def _update_emwei(self, IFREQ):
         """Packets per cell from the emission, every third frequency (ASOCS.py:546-595)."""
@@ -114,7 +122,8 @@ class ScatteringRun(AbsorptionRun):
         """-> OUTCOMING[NFREQ, NDIR, NPIX.y, NPIX.x], photons per pixel before the final scaling"""
         U, e, c = self.U, self.eng, self.cloud
         CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
-        OUTCOMING = np.zeros((NFREQ, self.NDIR, U.NPIX[1], U.NPIX[0]), np.float32)
+        OUTCOMING = np.zeros((NFREQ, 12 * U.OUT_NSIDE * U.OUT_NSIDE), np.float32) if self.healpix else \
+            np.zeros((NFREQ, self.NDIR, U.NPIX[1], U.NPIX[0]), np.float32)
         EMIT = np.zeros(CELLS, np.float32)
         for II in range(3):                                        # ASOCS.py:428-723
             WPS = WBG = 0.0
@@ -126,9 +135,8 @@ class ScatteringRun(AbsorptionRun):
             elif II == 1:
                 if self.BGPAC < 1:
                     continue
-                if len(U.file_hpbg) > 2:
-                    raise UnsupportedOption("hpbg (HEALPix background)")
-                L = launch.bg_launch(self.BGPAC, int(U.AREA))
+                L = launch.hpbg_sca_launch(self.BGPAC, c.NX, c.NY, c.NZ) if len(self.HPBG) > 0 else \
+                    launch.bg_launch(self.BGPAC, int(U.AREA))
                 WBG = L["WBG"]
             else:
                 if len(self.DIFFUSERAD) < 1 or self.DFPAC < 1:
@@ -159,9 +167,15 @@ class ScatteringRun(AbsorptionRun):
                         EMIT[a:b] = self.DIFFUSERAD[a:b, IFREQ] * coeff
                     EMIT[c.DENS < 1.0e-10] = 0.0
                     e.set_emission(EMIT, self.EMWEI)
+                hp = (II == 1) and len(self.HPBG) > 0
+                if hp:
+                    sky = files.hpbg_for_frequency(self.HPBG[IFREQ], WBG / FREQ, U.HPBG_WEIGHTED, clip_low=1.0e-2, skip_empty=False)
+                    e.set_hpbg(*sky)
                 self.timers["Tpush"] += time.time() - t0
                 t0 = time.time()
-                if II == 0:
+                if hp:
+                    e.sca_sim_hp(L["PACKETS"], L["BATCH"], seed, L["GLOBAL"], gid_first=first, gid_count=count)
+                elif II == 0:
                     e.sca_sim_ps(L["PACKETS"], L["BATCH"], seed, BG, U.PSPOS[:U.NO_PS, :3], PS, XPS=self.XPS,
                                  GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
                 elif II == 1:
@@ -216,13 +230,19 @@ class ScatteringRun(AbsorptionRun):
         self.setup_engine()
         OUTCOMING = self.simulate()
         U = self.U
-        for IFREQ in range(self.NFREQ):                            # ASOCS.py:887-893: photons -> Jy/sr
-            k = float(self.FFREQ[IFREQ]) * 1.0e23 * PLANCK / (U.MAP_DX * U.MAP_DX)
+        for IFREQ in range(self.NFREQ):                            # ASOCS.py:887-897: photons -> Jy/sr
+            if self.healpix:
+                k = float(self.FFREQ[IFREQ]) * 1.0e23 * PLANCK / (4.0 * np.pi / (12.0 * self.NDIR * self.NDIR))
+            else:
+                k = float(self.FFREQ[IFREQ]) * 1.0e23 * PLANCK / (U.MAP_DX * U.MAP_DX)
             OUTCOMING[IFREQ] *= k
         if self.rank == 0:
             if U.FITS > 0 and self.NDIR == 1:
                 self.log("fits output requested: writing outcoming.socs (same data; FITS container not produced)")
-            files.write_outcoming("outcoming.socs", self.FFREQ, OUTCOMING)
+            if self.healpix:
+                files.write_outcoming_healpix("outcoming.socs", U.OUT_NSIDE, self.FFREQ, OUTCOMING)
+            else:
+                files.write_outcoming("outcoming.socs", self.FFREQ, OUTCOMING)
         if self.rank == 0 and self.verbose:
             print("Tkernel %.3f  Tpush %.3f  Tpull %.3f" % (self.timers["Tkernel"], self.timers["Tpush"], self.timers["Tpull"]))
             if self.timers["Tkernel"] > 0:

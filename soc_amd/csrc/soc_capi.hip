@@ -96,6 +96,14 @@ static hipError_t dev_alloc(T **p, size_t n)
     return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
 }
 
+// number of floats of the scattered-light image: NDIR maps of NPIX_X x NPIX_Y pixels, or one Healpix map
+static size_t view_pixels(const soc_ctx *c)
+{
+    if (!c->have_view) return 0;
+    if (c->view.NDIR < 0) return (size_t)12 * c->view.NDIR * c->view.NDIR;
+    return (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y;
+}
+
 // Execute the launches deferred since soc_batch_begin: one brick sweep for all of them.
 static int flush_pending(soc_ctx *c)
 {
@@ -611,8 +619,9 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t npix = (size_t)NDIR * NPIX_X * NPIX_Y;
-    const size_t old = c->have_view ? (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y : 0;
+    const size_t old = view_pixels(c);
     if (NDIR != c->view.NDIR || !c->dODIR) {
+        c->view.NDIR = 0;
         HIPCHK(c, dev_alloc(&c->dODIR, (size_t)NDIR));
         HIPCHK(c, dev_alloc(&c->dORA, (size_t)NDIR));
         HIPCHK(c, dev_alloc(&c->dODE, (size_t)NDIR));
@@ -637,20 +646,55 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
     return SOC_OK;
 }
 
+int soc_sca_set_healpix(soc_ctx *c, int NSIDE, const float *OBSERVER, int FFS)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (NSIDE < 1 || NSIDE > 8192 || (NSIDE & (NSIDE - 1)) || !OBSERVER)
+        return fail(c, SOC_ERR_ARG, "soc_sca_set_healpix: NSIDE %d (power of two up to 8192) and the observer position are needed", NSIDE);
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(OBSERVER[k])) return fail(c, SOC_ERR_ARG, "soc_sca_set_healpix: observer position is not finite");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t npix = (size_t)12 * NSIDE * NSIDE, old = view_pixels(c);
+    if (!c->dODIR || c->view.NDIR < 1) {
+        HIPCHK(c, dev_alloc(&c->dODIR, (size_t)1));
+        HIPCHK(c, dev_alloc(&c->dORA, (size_t)1));
+        HIPCHK(c, dev_alloc(&c->dODE, (size_t)1));
+    }
+    if (npix != old || !c->dOUT) {
+        if (!c->own_OUT && c->dOUT && npix != old)
+            return fail(c, SOC_ERR_STATE, "soc_sca_set_healpix: image size changed while a caller-owned image is bound");
+        if (c->own_OUT || !c->dOUT) {
+            c->dOUT = nullptr;
+            HIPCHK(c, dev_alloc(&c->dOUT, npix));
+            c->own_OUT = true;
+            HIPCHK(c, hipMemset(c->dOUT, 0, npix * 4));
+        }
+    }
+    const float obs[4] = { OBSERVER[0], OBSERVER[1], OBSERVER[2], 0.0f };
+    HIPCHK(c, hipMemcpy(c->dODIR, obs, 16, hipMemcpyHostToDevice));
+    c->view.NDIR = -NSIDE;  c->view.NPIX_X = 1;  c->view.NPIX_Y = 1;  c->view.FFS = FFS ? 1 : 0;
+    c->view.MAP_DX = 1.0f;  c->view.CX = c->view.CY = c->view.CZ = 0.0f;
+    c->view.ODIRS = c->dODIR;  c->view.ORA = c->dORA;  c->view.ODE = c->dODE;
+    c->have_view = true;
+    return SOC_OK;
+}
+
 int soc_sca_zero(soc_ctx *c)
 {
     if (!c) return SOC_ERR_ARG;
     FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_zero: call soc_sca_set_view first");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->dOUT, 0, (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dOUT, 0, view_pixels(c) * 4, c->stream));
     return SOC_OK;
 }
 
 static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVariant &V)
 {
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "%s: call soc_sca_set_view first", who);
-    if (kind != SOC_SCA_CL && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
+    if (kind != SOC_SCA_CL && kind != SOC_SCA_HP && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
     if (c->BINS > 8000) return fail(c, SOC_ERR_ARG, "%s: BINS=%d > 8000", who, c->BINS);
     SocSca X = c->view;
     X.kind = kind;
@@ -719,12 +763,28 @@ int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, i
     return sca_launch(c, "soc_sca_sim_cl", SOC_SCA_CL, S, V);
 }
 
+int soc_sca_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count)
+{
+    (void)PACKETS;
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    int r = check_launch(c, "soc_sca_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
+    if (r) return r;
+    if (!c->have_hpbg) return fail(c, SOC_ERR_STATE, "soc_sca_sim_hp: call soc_set_hpbg first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SocSim S;
+    SocVariant V;
+    fill_sim(c, S, V, 1, BATCH, SEED, 0.0f, 0.0f, GLOBAL, gid_first, gid_count);
+    S.NO_PS = 1;
+    return sca_launch(c, "soc_sca_sim_hp", SOC_SCA_HP, S, V);
+}
+
 int soc_sca_read_out(soc_ctx *c, float *out, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
     FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_read_out: call soc_sca_set_view first");
-    const int64_t npix = (int64_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y;
+    const int64_t npix = (int64_t)view_pixels(c);
     if (!out || n < 0 || n > npix) return fail(c, SOC_ERR_ARG, "soc_sca_read_out: n=%lld (image has %lld values)", (long long)n, (long long)npix);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->dOUT, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

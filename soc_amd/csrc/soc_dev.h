@@ -69,9 +69,9 @@ hipError_t soc_launch_trace(const SocGrid &G, const SocVariant &V, const float *
 
 // scattered-light images (soc_sca.hip): observers and image of one launch of the
 // kernel_ASOC_sca.c kernels (argument lists :471-501, :1098-1122, :1462-1489)
-enum { SOC_SCA_PB = 0, SOC_SCA_CL = 1, SOC_SCA_PS = 2 };
+enum { SOC_SCA_PB = 0, SOC_SCA_CL = 1, SOC_SCA_PS = 2, SOC_SCA_HP = 3 };
 struct SocSca {
-    int   kind, NDIR, NPIX_X, NPIX_Y, FFS;
+    int   kind, NDIR, NPIX_X, NPIX_Y, FFS;   /* NDIR < 0: Healpix map of NSIDE = -NDIR seen from ODIRS[0] (a position) */
     float MAP_DX, CX, CY, CZ;
     const float4 *ODIRS, *ORA, *ODE;   /* [NDIR] cl float3 = 16 bytes                      */
     const float  *DSC;                 /* [BINS] discrete scattering function              */

@@ -277,4 +277,28 @@ SOC_HD float soc_acosf(float x)
     return 1.57079632679489661923f - soc_asin_core(x);
 }
 
+// atan2(y, x) (direction -> Healpix longitude in the scattered-light kernels,
+// kernel_ASOC_sca.c:357).  atan on [0,1] by a degree-19 odd polynomial (least-squares fit reweighted
+// towards minimax), then the usual reflections; error < 2 ulp (tests/test_math.py).  atan2(0,0) = 0.
+SOC_HD float soc_atan2f(float y, float x)
+{
+    const float ax = soc_fabsf(x), ay = soc_fabsf(y);
+    const float mx = soc_fmaxf(ax, ay), mn = soc_fminf(ax, ay);
+    float a = (mx > 0.0f) ? (mn / mx) : 0.0f;                      // [0, 1]
+    const float s = a * a;
+    float p = -1.7934360529e-03f;
+    p = SOC_FMA(p, s, 1.0913770722e-02f);
+    p = SOC_FMA(p, s, -3.1176284444e-02f);
+    p = SOC_FMA(p, s, 5.7956025310e-02f);
+    p = SOC_FMA(p, s, -8.4033591855e-02f);
+    p = SOC_FMA(p, s, 1.0952155088e-01f);
+    p = SOC_FMA(p, s, -1.4264236043e-01f);
+    p = SOC_FMA(p, s, 1.9998547802e-01f);
+    p = SOC_FMA(p, s, -3.3333299077e-01f);
+    float r = SOC_FMA(p * s, a, a);                                  // atan(a)
+    if (ay > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return (y < 0.0f) ? -r : r;
+}
+
 #endif  // SOC_MATH_H

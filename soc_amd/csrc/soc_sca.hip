@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
     const int AREA = 2 * (G.NX * G.NY + G.NY * G.NZ + G.NZ * G.NX);
     if (KIND == SOC_SCA_PB) { if ((S.SOURCE == 1) && (id >= 8 * AREA)) return; }
     if (KIND == SOC_SCA_CL) { if (id >= G.CELLS) return; }
+    // SimRAM_CL and SimRAM_HP share the walk's details: +-0.9999 clamp, HG_TEST weight, no draw on an empty line of sight
+    constexpr bool CLW = (KIND == SOC_SCA_CL) || (KIND == SOC_SCA_HP);
+    const bool HPX = V.NDIR < 0;                         // Healpix map seen from the position ODIRS[0]
+    const int  NDIRS = HPX ? 1 : V.NDIR;
 
     ScaRay w;                                  // the current ray
     w.rng = soc_seed_stream(S.seed_mul, S.seed_tab, (uint32_t)id);
@@ -64,11 +68,12 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
     float mx = 0.0f, my = 0.0f, mz = 0.0f, dx_ = 0.0f, dy_ = 0.0f, dz_ = 0.0f, mdens = 0.0f;
     int   mlevel = 0, mind = -1, lvl_post = 0;
     float free_path = 0.0f, tau = 0.0f, taup = 0.0f;
+    float dxrem = 0.0f, invd2 = 0.0f;                    // Healpix: distance left to the observer, 1/d^2
     int   scat = 0, idir = 0;
     unsigned int n_add = 0, n_pkt = 0, n_scat = 0;
 
     SocSurfElem E;
-    if (KIND != SOC_SCA_CL) E = soc_surface_element(G, S, id);
+    if (KIND == SOC_SCA_PB || KIND == SOC_SCA_PS) E = soc_surface_element(G, S, id);
     int   III = 0;
     long long ICELL = (long long)id - S.GLOBAL;
     int   IRAY = 0, batch = -1;
@@ -98,7 +103,18 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                 mx = w.px;  my = w.py;  mz = w.pz;  dx_ = w.ux;  dy_ = w.uy;  dz_ = w.uz;
                 mlevel = w.level;  mind = w.ind;  mdens = w.dens;
                 idir = 0;
-                if (V.NDIR > 0) {
+                if (HPX) {
+                    // direction and distance to the observer from the root position of the scattering (:319-327)
+                    float rx = w.px, ry = w.py, rz = w.pz;
+                    if (OCT) soc_rootpos(G, sOFF, rx, ry, rz, w.level, w.ind);
+                    const float4 o = V.ODIRS[0];
+                    w.ux = o.x - rx;  w.uy = o.y - ry;  w.uz = o.z - rz;
+                    dxrem = soc_sqrtf(w.ux * w.ux + w.uy * w.uy + w.uz * w.uz);
+                    invd2 = 1.0f / (dxrem * dxrem);
+                    soc_normalize(w.ux, w.uy, w.uz);
+                    taup = 0.0f;
+                    mode = (dxrem > 0.0f) ? SCA_M_PEEL : SCA_M_PEEL_END;
+                } else if (V.NDIR > 0) {
                     const float4 o = V.ODIRS[0];
                     w.ux = o.x;  w.uy = o.y;  w.uz = o.z;
                     taup = 0.0f;
@@ -111,10 +127,10 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
             // ---- a peel-off ray has reached the surface: image contribution, next observer or deflection
             if (mode == SCA_M_PEEL_END) {
                 if (idir >= 0) {
-                    const float CL = (KIND == SOC_SCA_CL) ? 0.9999f : 0.999f;
+                    const float CL = CLW ? 0.9999f : 0.999f;
                     const float cos_theta = soc_clampf(dx_ * w.ux + dy_ * w.uy + dz_ * w.uz, -CL, +CL);
                     float delta;
-                    if (KIND == SOC_SCA_CL) {
+                    if (CLW) {
                         const float g = 0.65f;
                         const float fraction = (1.0f / (4.0f * SOC_PI)) * (1.0f - g * g) / soc_pow15f(1.0f + g * g - 2.0f * g * cos_theta);
                         delta = w.photons * fraction * ((taup > SOC_TAULIM) ? (1.0f - soc_expf(-taup)) : (taup * (1.0f - 0.5f * taup)));
@@ -123,18 +139,28 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                         b = b < 0 ? 0 : (b > S.BINS - 1 ? S.BINS - 1 : b);
                         delta = w.photons * soc_expf(-taup) * sDSC[b];
                     }
-                    const float qx = w.px - V.CX, qy = w.py - V.CY, qz = w.pz - V.CZ;
-                    const float4 ra = V.ORA[idir], de = V.ODE[idir];
-                    int i = (int)((0.5f * V.NPIX_X - 0.00005f) + (qx * ra.x + qy * ra.y + qz * ra.z) / V.MAP_DX);
-                    int j = (int)((0.5f * V.NPIX_Y - 0.00005f) + (qx * de.x + qy * de.y + qz * de.z) / V.MAP_DX);
-                    if ((i >= 0) && (j >= 0) && (i < V.NPIX_X) && (j < V.NPIX_Y)) {
-                        i += idir * V.NPIX_X * V.NPIX_Y + j * V.NPIX_X;
-                        soc_tally(V.OUT, i, delta);
+                    if (HPX) {
+                        // 1/d^2 and the pixel of the direction towards the observer (:352-360)
+                        delta = invd2 * delta;
+                        const float theta = soc_acosf(-w.uz);
+                        const float phi   = soc_atan2f(w.uy, w.ux);
+                        const int pix = soc_angles2pixel_ring(-V.NDIR, phi, theta);
+                        if (pix >= 0) soc_tally(V.OUT, pix, delta);
                         n_add++;
+                    } else {
+                        const float qx = w.px - V.CX, qy = w.py - V.CY, qz = w.pz - V.CZ;
+                        const float4 ra = V.ORA[idir], de = V.ODE[idir];
+                        int i = (int)((0.5f * V.NPIX_X - 0.00005f) + (qx * ra.x + qy * ra.y + qz * ra.z) / V.MAP_DX);
+                        int j = (int)((0.5f * V.NPIX_Y - 0.00005f) + (qx * de.x + qy * de.y + qz * de.z) / V.MAP_DX);
+                        if ((i >= 0) && (j >= 0) && (i < V.NPIX_X) && (j < V.NPIX_Y)) {
+                            i += idir * V.NPIX_X * V.NPIX_Y + j * V.NPIX_X;
+                            soc_tally(V.OUT, i, delta);
+                            n_add++;
+                        }
                     }
                     idir++;
                 }
-                if ((idir >= 0) && (idir < V.NDIR)) {
+                if ((idir >= 0) && (idir < NDIRS)) {
                     const float4 o = V.ODIRS[idir];
                     w.px = mx;  w.py = my;  w.pz = mz;  w.level = mlevel;  w.ind = mind;  w.dens = mdens;
                     w.ux = o.x;  w.uy = o.y;  w.uz = o.z;
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                 bool alive = true;
                 if (tau < 1.0e-22f) {
                     w.ind = -1;
-                    if (KIND == SOC_SCA_CL) alive = false;             // no random number drawn
+                    if (CLW) alive = false;                            // no random number drawn
                 }
                 if (alive) {
                     float W;
@@ -231,6 +257,15 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                         w.uz = cos_theta;
                         have = true;
                     }
+                } else if (KIND == SOC_SCA_HP) {
+                    if (III >= S.BATCH) {
+                        mode = SCA_M_DONE;
+                    } else {
+                        soc_hp_sca_create<OCT>(G, S, sOFF, w);
+                        III++;
+                        n_pkt++;
+                        have = (w.ind >= 0);                   // a packet that misses the cloud is skipped (:222)
+                    }
                 } else {
                     if (III >= S.BATCH) {
                         mode = SCA_M_DONE;
@@ -241,11 +276,13 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                     }
                 }
                 if (have) {
-                    n_pkt++;
-                    if (soc_fabsf(w.ux) < SOC_DEPS) w.ux = SOC_DEPS;
-                    if (soc_fabsf(w.uy) < SOC_DEPS) w.uy = SOC_DEPS;
-                    if (soc_fabsf(w.uz) < SOC_DEPS) w.uz = SOC_DEPS;
-                    soc_normalize(w.ux, w.uy, w.uz);
+                    if (KIND != SOC_SCA_HP) {                  // SimRAM_HP has conditioned the direction itself
+                        n_pkt++;
+                        if (soc_fabsf(w.ux) < SOC_DEPS) w.ux = SOC_DEPS;
+                        if (soc_fabsf(w.uy) < SOC_DEPS) w.uy = SOC_DEPS;
+                        if (soc_fabsf(w.uz) < SOC_DEPS) w.uz = SOC_DEPS;
+                        soc_normalize(w.ux, w.uy, w.uz);
+                    }
                     tau  = 0.0f;
                     scat = 0;
                     if (V.FFS > 0) {
@@ -270,8 +307,17 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
             else     { kabs = S.ABS;  ksca = S.SCA; }
             const float ds = soc_getstep<OCT, DBL>(G, sOFF, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
             if (mode == SCA_M_PEEL) {
-                taup += ds * d0 * (kabs + ksca);
-                if (w.ind < 0) mode = SCA_M_PEEL_END;
+                if (HPX) {
+                    // only as far as the observer (:329-335); SimRAM_PB adds its 1.0e-6 in double (:982)
+                    float d = (dxrem < ds) ? dxrem : ds;
+                    d = (KIND == SOC_SCA_PB) ? (float)((double)d + 1.0e-6) : (d + 1.0e-6f);
+                    dxrem -= d;
+                    taup += d * d0 * (kabs + ksca);
+                    if (!(dxrem > 0.0f) || (w.ind < 0)) mode = SCA_M_PEEL_END;
+                } else {
+                    taup += ds * d0 * (kabs + ksca);
+                    if (w.ind < 0) mode = SCA_M_PEEL_END;
+                }
             } else {
                 const float dtau = ds * d0 * ksca;
                 if (mode == SCA_M_FFS) {
@@ -322,6 +368,7 @@ hipError_t soc_launch_sca(const SocGrid &G, const SocSim &S, const SocSca &V, co
     case SOC_SCA_PB: return sca_dispatch<SOC_SCA_PB>(G, S, V, X, st);
     case SOC_SCA_CL: return sca_dispatch<SOC_SCA_CL>(G, S, V, X, st);
     case SOC_SCA_PS: return sca_dispatch<SOC_SCA_PS>(G, S, V, X, st);
+    case SOC_SCA_HP: return sca_dispatch<SOC_SCA_HP>(G, S, V, X, st);
     default: return hipErrorInvalidValue;
     }
 }

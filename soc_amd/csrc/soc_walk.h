@@ -578,6 +578,56 @@ __device__ __forceinline__ void soc_pixel2angles_ring(const int nside, const int
     }
 }
 
+// Angles2PixelRing (kernel_ASOC_aux.c:945-984): (phi, theta) -> Healpix RING pixel, -1 outside [0, pi]
+__device__ __forceinline__ int soc_angles2pixel_ring(const int nside, float phi, const float theta)
+{
+    if ((theta < 0.0f) || (theta > SOC_PI)) return -1;
+    const float z = soc_cosf(theta), za = soc_fabsf(z);
+    if (phi >= SOC_TWOPI) phi -= SOC_TWOPI;
+    if (phi < 0.0f)       phi += SOC_TWOPI;
+    const float tt = phi / 1.5707963268f;
+    const int nl2 = 2 * nside, nl4 = 4 * nside, ncap = nl2 * (nside - 1), npix = 12 * nside * nside;
+    int ipix1;
+    if (za <= 0.6666666667f) {
+        const int jp = (int)(nside * (0.5f + tt - z * 0.75f));
+        const int jm = (int)(nside * (0.5f + tt + z * 0.75f));
+        const int ir = nside + 1 + jp - jm;
+        const int kshift = (ir % 2 == 0) ? 1 : 0;
+        int ip = (int)((jp + jm - nside + kshift + 1) / 2) + 1;
+        if (ip > nl4) ip -= nl4;
+        ipix1 = ncap + nl4 * (ir - 1) + ip;
+    } else {
+        const float tp = tt - (float)(int)tt;
+        const float tmp = soc_sqrtf(3.0f * (1.0f - za));
+        const int jp = (int)(nside * tp * tmp);
+        const int jm = (int)(nside * (1.0f - tp) * tmp);
+        const int ir = jp + jm + 1;
+        int ip = (int)(tt * ir) + 1;
+        if (ip > (4 * ir)) ip -= 4 * ir;
+        ipix1 = 2 * ir * (ir - 1) + ip;
+        if (z <= 0.0f) ipix1 = npix - 2 * ir * (ir + 1) + ip;
+    }
+    return ipix1 - 1;
+}
+
+// RootPos (kernel_ASOC_aux.c:169-190): local position of cell (level, ind) -> root-grid coordinates
+__device__ __forceinline__ void soc_rootpos(const SocGrid &G, const int *sOFF, float &px, float &py, float &pz, int level, int ind)
+{
+    while (level > 0) {
+        ind = G.PAR[sOFF[level] + ind - G.NXYZ];
+        level--;
+        px *= 0.5f;  py *= 0.5f;  pz *= 0.5f;
+        if (level == 0) {
+            px += (float)(ind % G.NX);
+            py += (float)((ind / G.NX) % G.NY);
+            pz += (float)(ind / (G.NX * G.NY));
+        } else {
+            const int sid = ind % 8;
+            px += (float)(sid % 2);  py += (float)((sid / 2) % 2);  pz += (float)(sid / 4);
+        }
+    }
+}
+
 // Healpix pixel of the next background packet (kernel_ASOC.c:881-902): uniform, or bisection
 // (n_bisect halvings + linear scan) on the cumulative probability HPBGP
 __device__ __forceinline__ int soc_hp_select_pixel(const SocSim &S, soc_rng_t *rng, int n_bisect)
@@ -637,6 +687,45 @@ __device__ __forceinline__ void soc_hp_create(const SocGrid &G, const SocSim &S,
         w.pz = (w.uz > 0.0f) ? SOC_PEPS : (NZ - SOC_PEPS);
     }
     (void)z;
+    soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+}
+
+// Creation of a packet of the scattered-light SimRAM_HP (kernel_ASOC_sca.c:107-222): direction from the
+// sky pixel (12 bisections when weighted), start on a disc of radius Rout across the direction on the
+// upstream side of the cloud, entry through Surface(); w.ind < 0 when the packet misses the cloud.
+template <bool OCT, typename W>
+__device__ __forceinline__ void soc_hp_sca_create(const SocGrid &G, const SocSim &S, const int *sOFF, W &w)
+{
+    const int NX = G.NX, NY = G.NY, NZ = G.NZ;
+    const float Rout = 0.5f * soc_sqrtf(1.0f * NX * NX + NY * NY + NZ * NZ);
+    const int pix = soc_hp_select_pixel(S, &w.rng, 12);
+    w.photons = S.HPBG[pix];
+    float phi, theta, st, ct, sp, cp;
+    soc_pixel2angles_ring(64, pix, phi, theta);
+    soc_sincosf(theta, &st, &ct);
+    soc_sincosf(phi, &sp, &cp);
+    w.ux = +st * cp;
+    w.uy = +st * sp;
+    w.uz = -ct;
+    if (soc_fabsf(w.ux) < SOC_DEPS) w.ux = SOC_DEPS;
+    if (soc_fabsf(w.uy) < SOC_DEPS) w.uy = SOC_DEPS;
+    if (soc_fabsf(w.uz) < SOC_DEPS) w.uz = SOC_DEPS;
+    soc_normalize(w.ux, w.uy, w.uz);
+    const float ds = 2.0f * SOC_PI * soc_rand(&w.rng);
+    const float dx = soc_sqrtf(soc_rand(&w.rng));
+    float sd, cd;
+    soc_sincosf(ds, &sd, &cd);
+    float x = dx * cd, y = dx * sd, z = soc_sqrtf(1.001f - dx * dx);
+    const float x0 = x * ct + z * st, y0 = y, z0 = -x * st + z * ct;
+    float sq, cq;
+    soc_sincosf(SOC_PI - phi, &sq, &cq);
+    x = x0 * cq + y0 * sq;
+    y = -x0 * sq + y0 * cq;
+    z = z0;
+    w.px = 0.5f * NX + Rout * x;
+    w.py = 0.5f * NY + Rout * y;
+    w.pz = 0.5f * NZ + Rout * z;
+    soc_surface(G, w.px, w.py, w.pz, w.ux, w.uy, w.uz);
     soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
 }
 

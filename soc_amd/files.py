@@ -255,22 +255,33 @@ def read_outcoming(filename, NDIR):
     return FFREQ, data.reshape(int(nfreq), NDIR, int(ny), int(nx))
 
 
-def hpbg_for_frequency(sky, scale, weighted):
+def hpbg_for_frequency(sky, scale, weighted, clip_low=1.0e-3, skip_empty=True):
     """Device arrays of the Healpix background for one frequency (ASOC.py:1196-1214): sky[49152]
     (file units x user scaling) -> photons per package BG = scale*sky, and with `weighted`
     the cumulative pixel probability HPBGP (pixels chosen in proportion to their clipped
     intensity, the packet weight corrected by HPBGW).  Returns (BG, HPBGP or None), or None
-    for an empty sky in weighted mode."""
+    for an empty sky in weighted mode.  ASOCS.py:598-611 clips at 1e-2 instead of 1e-3 and has
+    no empty-sky test (clip_low, skip_empty)."""
     sky = np.asarray(sky, np.float32)
     if not weighted:
         return np.asarray(np.float32(scale) * sky, np.float32), None
     tmp = np.asarray(sky, np.float64)
-    if np.max(tmp) < 1.0e-40:
+    if skip_empty and np.max(tmp) < 1.0e-40:
         return None
     tmp = tmp / np.mean(tmp)
-    tmp = np.clip(tmp, 1.0e-3, 1.0e4)
+    tmp = np.clip(tmp, clip_low, 1.0e4)
     tmp /= np.sum(tmp)
     HPBGW = (1.0 / 49152.0) / tmp
     HPBGP = np.cumsum(tmp)
     HPBGP[-1] = 1.00001
     return np.asarray(scale * sky * HPBGW, np.float32), np.asarray(HPBGP, np.float32)
+
+
+def write_outcoming_healpix(filename, NSIDE, FFREQ, OUTCOMING):
+    """outcoming.socs for a Healpix map (ASOCS.py:418-426): int32 NSIDE, NFREQ; float32 FFREQ[NFREQ];
+    float32 OUTCOMING[NFREQ, 12*NSIDE^2]"""
+    OUTCOMING = np.asarray(OUTCOMING, np.float32)
+    with open(filename, 'wb') as fp:
+        np.asarray([NSIDE, OUTCOMING.shape[0]], np.int32).tofile(fp)
+        np.asarray(FFREQ, np.float32).tofile(fp)
+        OUTCOMING.tofile(fp)

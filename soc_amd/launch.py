@@ -78,6 +78,18 @@ def hpbg_launch(BGPAC, NX, NY, NZ):
     return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
 
 
+def hpbg_sca_launch(BGPAC, NX, NY, NZ):
+    """Healpix background of the scattering run (ASOCS.py:480-497): one packet per work item, aimed at a
+    sphere of radius Rout that contains the cloud; the kernel rejects those that miss.
+    Returns dict(GLOBAL, BATCH, PACKETS, WBG)."""
+    BATCH = 1
+    GLOBAL = Fix(int(BGPAC / BATCH), 64)
+    PACKETS = GLOBAL * BATCH
+    Rout = 0.5 * math.sqrt(NX * NX + NY * NY + NZ * NZ)
+    WBG = np.pi * 4.0 * np.pi * Rout ** 2.0 / (PLANCK * PACKETS)
+    return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
+
+
 def cl_launch(PAC, CELLS, GLOBAL=GLOBAL_0):
     """Cell emission: diffuse (ASOC.py:1086-1090) or dust re-emission (ASOC.py:1640).
     Returns dict(GLOBAL, BATCH, PACKETS)."""

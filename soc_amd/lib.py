@@ -44,6 +44,8 @@ API = {
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
     "soc_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_set_view": (C.c_int, [C.c_void_p, C.c_int, _F, _F, _F, C.c_int, C.c_int, C.c_float, _F, C.c_int]),
+    "soc_sca_set_healpix": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int]),
+    "soc_sca_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_zero": (C.c_int, [C.c_void_p]),
     "soc_sca_sim_ps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, _F, _F, C.c_int, _I, _I, _F,
                                  C.c_int, C.c_int, C.c_int]),
@@ -270,6 +272,17 @@ class Engine:
         self.sca_shape = (len(ODIR), int(NPIX[1]), int(NPIX[0]))
         self._chk(self.lib.soc_sca_set_view(self.h, len(ODIR), _f(ODIR), _f(RA), _f(DE), int(NPIX[0]), int(NPIX[1]),
                                             np.float32(MAP_DX), _f(cen), int(FFS)))
+
+    def sca_set_healpix(self, NSIDE, OBSERVER, FFS=1):
+        """one Healpix map (RING) of scattered light seen from the position OBSERVER [root-grid units]"""
+        obs = np.asarray(OBSERVER, np.float32).ravel()[:3].copy()
+        self.sca_shape = (12 * int(NSIDE) * int(NSIDE),)
+        self._chk(self.lib.soc_sca_set_healpix(self.h, int(NSIDE), _f(obs), int(FFS)))
+
+    def sca_sim_hp(self, PACKETS, BATCH, SEED, GLOBAL, gid_first=0, gid_count=None):
+        gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
+        self._chk(self.lib.soc_sca_sim_hp(self.h, int(PACKETS), int(BATCH), np.float32(SEED), int(GLOBAL), int(gid_first),
+                                          int(gid_count)))
 
     def sca_zero(self):
         self._chk(self.lib.soc_sca_zero(self.h))

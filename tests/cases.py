@@ -111,14 +111,20 @@ CASES = {
 
 # ---- scattered-light images (kernel_ASOC_sca.c) --------------------------------------------
 # name: (ref build of oracle/build.py: sca_ref_models, kernel kind, job factory, view kwargs)
-# kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS
+# kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_PS, 3 = SimRAM_HP
 _PS_EXT2 = np.array([[14.3, 4.2, 4.1], [4.0, -3.0, 20.0]], np.float32)
 
 
-def sca_view(NPIX=(12, 10), MAP_DX=1.1, FFS=1, angles=((30.0, 40.0), (90.0, 0.0), (0.0, 0.0))):
+def sca_view(NPIX=(12, 10), MAP_DX=1.1, FFS=1, angles=((30.0, 40.0), (90.0, 0.0), (0.0, 0.0)), healpix=None):
+    """healpix = (nside, (x, y, z)): one Healpix map seen from that position instead of orthographic maps"""
     import math
     from oracle.pyoracle import ScaView
     from soc_amd import launch
+    if healpix is not None:
+        z = np.zeros((1, 4), np.float32)
+        o = np.zeros((1, 4), np.float32)
+        o[0, :3] = healpix[1]
+        return ScaView(o, z, z, NPIX=(1, 1), MAP_DX=1.0, CENTRE=(0.0, 0.0, 0.0), FFS=FFS, nside=healpix[0])
     th = [math.radians(a[0]) for a in angles]
     ph = [math.radians(a[1]) for a in angles]
     _, OD, RA, DE = launch.set_observer_directions(th, ph)
@@ -156,6 +162,20 @@ SCA_CASES = {
                                                   EMIT=_emit(_c8()), DSC=_DSC, MIRROR=5), {}),
     "sca_ps_c8_mirror": ("c8mir", 2, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256,
                                                   PSPOS=[[4.3, 4.2, 4.1]], PS=[1.0], DSC=_DSC, MIRROR=5), {}),
+    # Healpix maps seen from a position inside / outside the cloud (`perspective`)
+    "sca_hpx_bg_c8_in": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=6, SEED=0.6, DSC=_DSC),
+                         dict(healpix=(8, (4.2, 4.1, 3.9)))),
+    "sca_hpx_bg_oct8_out": ("oct8", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=6, SEED=0.41, DSC=_DSC),
+                            dict(healpix=(8, (20.0, 5.0, 5.5)))),
+    "sca_hpx_cl_oct8_in": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                   EMIT=_emit(_oct8()), DSC=_DSC), dict(healpix=(8, (4.2, 4.1, 3.9)))),
+    "sca_hpx_ps_c8_in": ("c8ps", 2, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256,
+                                                 PSPOS=_PS_EXT, PS=[1.0, 2.0], DSC=_DSC), dict(healpix=(4, (4.2, 4.1, 3.9)))),
+    # Healpix background (sca SimRAM_HP), kind 3
+    "sca_hp_c8": ("c8", 3, lambda: _hpjob(_c8(), False, BATCH=8, SEED=0.37, GLOBAL=4096, DSC=_DSC), {}),
+    "sca_hp_c8_weighted": ("c8hpw", 3, lambda: _hpjob(_c8(), True, BATCH=8, SEED=0.37, GLOBAL=4096, DSC=_DSC), {}),
+    "sca_hp_oct8_hpx": ("oct8", 3, lambda: _hpjob(_oct8(), False, BATCH=8, SEED=0.11, GLOBAL=4096, DSC=_DSC),
+                        dict(healpix=(8, (4.2, 4.1, 3.9)))),
     "sca_cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
                                         EMIT=_emit(_c8()), DSC=_DSC), {}),
     "sca_cl_oct8": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,

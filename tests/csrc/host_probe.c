@@ -53,3 +53,8 @@ void hp_div_by_rcp(const float *n, const float *u, float *q, long cnt)
 {
     for (long i = 0; i < cnt; i++) q[i] = soc_div_by_rcp(n[i], u[i], 1.0f / u[i]);
 }
+
+void hp_atan2(const float *y, const float *x, float *r, long cnt)
+{
+    for (long i = 0; i < cnt; i++) r[i] = soc_atan2f(y[i], x[i]);
+}

@@ -131,7 +131,7 @@ def sca_main():
     for name, (ref, kind, mk, vkw) in cases.SCA_CASES.items():
         job, view = mk(), cases.sca_view(**vkw)
         OUT = RefSca(ref).sim(job, view, kind)
-        out[name] = OUT.reshape(view.NDIR, view.NPIX[1], view.NPIX[0])
+        out[name] = OUT if view.nside else OUT.reshape(view.NDIR, view.NPIX[1], view.NPIX[0])
         print("%-18s sum(OUT) = %.9e   nonzero pixels %d / %d" % (name, OUT.sum(dtype=np.float64), (OUT != 0).sum(), OUT.size))
     np.savez_compressed(os.path.join(HERE, "sca.npz"), **out)
 

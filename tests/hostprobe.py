@@ -66,3 +66,10 @@ class HostProbe:
         q = np.zeros_like(n)
         self.lib.hp_div_by_rcp(n.ctypes.data_as(_F), u.ctypes.data_as(_F), q.ctypes.data_as(_F), n.size)
         return q
+
+    def atan2(self, y, x):
+        y = np.ascontiguousarray(y, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        r = np.zeros_like(y)
+        self.lib.hp_atan2(y.ctypes.data_as(_F), x.ctypes.data_as(_F), r.ctypes.data_as(_F), y.size)
+        return r

@@ -86,6 +86,19 @@ class OracleEngine:
         self.OUT = np.zeros(self.view.out_size(), np.float32)
         self.sca_shape = (self.view.NDIR, int(NPIX[1]), int(NPIX[0]))
 
+    def sca_set_healpix(self, NSIDE, OBSERVER, FFS=1):
+        z = np.zeros((1, 4), np.float32)
+        o = np.zeros((1, 4), np.float32)
+        o[0, :3] = OBSERVER
+        self.view = ScaView(o, z, z, NPIX=(1, 1), MAP_DX=1.0, CENTRE=(0, 0, 0), FFS=FFS, nside=NSIDE)
+        self.OUT = np.zeros(self.view.out_size(), np.float32)
+        self.sca_shape = (self.view.out_size(),)
+
+    def sca_sim_hp(self, PACKETS, BATCH, SEED, GLOBAL, gid_first=0, gid_count=None):
+        job = self._job(1, PACKETS, BATCH, SEED, 0.0, 0.0, GLOBAL)
+        job.HPBG, job.HPBGP = self.HPBG, self.HPBGP
+        self._sca(3, job, GLOBAL, gid_first, gid_count)
+
     def sca_zero(self):
         self.OUT[:] = 0
 

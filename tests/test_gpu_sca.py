@@ -21,13 +21,19 @@ def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True):
     eng.set_optical(job.ABS, job.SCA)
     eng.set_opt(job.OPT)
     eng.set_mirror(job.MIRROR)
-    eng.sca_set_view(view.ODIR, view.RA, view.DE, view.NPIX, view.MAP_DX, view.CENTRE, view.FFS)
+    if view.nside:
+        eng.sca_set_healpix(view.nside, view.ODIR[0, :3], view.FFS)
+    else:
+        eng.sca_set_view(view.ODIR, view.RA, view.DE, view.NPIX, view.MAP_DX, view.CENTRE, view.FFS)
     if zero:
         eng.sca_zero()
     eng.stats(reset=True)
     gid_count = job.GLOBAL - gid_first if gid_count is None else gid_count
     xps = (job.XPS_NSIDE, job.XPS_SIDE, job.XPS_AREA)
-    if kind == 2:
+    if kind == 3:
+        eng.set_hpbg(job.HPBG, job.HPBGP)
+        eng.sca_sim_hp(job.PACKETS, job.BATCH, job.SEED, job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
+    elif kind == 2:
         eng.sca_sim_ps(job.PACKETS, job.BATCH, job.SEED, job.BG, job.PSPOS[:, :3], job.PS, XPS=xps, GLOBAL=job.GLOBAL,
                        gid_first=gid_first, gid_count=gid_count)
     elif kind == 0:

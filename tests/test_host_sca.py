@@ -121,6 +121,43 @@ def test_scattering_run_refuses_what_it_cannot_do(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("perspective 2 2 2\n", "hpbg sky.bin\n", "split 1\n"):
+    for extra in ("roipac 100\n", "split 1\n"):
         with pytest.raises(UnsupportedOption):
             ScatteringRun(User(_ini(d, cloud, extra=extra)), OracleEngine("soc"))
+
+
+def test_perspective_and_healpix_background(tmp_path):
+    """`perspective x y z` -> one Healpix map (NSIDE outnside) with the header of ASOCS.py:418-426 and the
+    solid-angle scaling of :894-896; `hpbg` -> sca SimRAM_HP with the launch of ASOCS.py:480-497."""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(6, seed=4)
+    sky = np.random.default_rng(3).lognormal(0, 1, (3, 49152)).astype(np.float32) * 1e-13
+    sky.tofile(os.path.join(d, "sky.bin"))
+    ini = _write_model(d, cloud, extra="perspective 2.5 3.5 9.0\noutnside 4\nhpbg %s/sky.bin\nbgpackets 30000\n" % d)
+    os.chdir(d)
+    run = ScatteringRun(User(ini), OracleEngine("soc"))
+    OUTC = run.run()
+    assert OUTC.shape == (3, 192)
+    head = np.fromfile("outcoming.socs", np.int32, 2)
+    assert list(head) == [4, 3]
+    data = np.fromfile("outcoming.socs", np.float32, offset=8 + 12).reshape(3, 192)
+    assert np.array_equal(data, OUTC)
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 3, 500)
+    L = launch.hpbg_sca_launch(run.BGPAC, 6, 6, 6)
+    assert L["BATCH"] == 1 and L["GLOBAL"] == launch.Fix(run.BGPAC, 64)
+    assert np.isclose(L["WBG"], np.pi * 4 * np.pi * (0.5 * math.sqrt(108.0)) ** 2 / (launch.PLANCK * L["GLOBAL"]))
+    z = np.zeros((1, 4), np.float32)
+    o = np.zeros((1, 4), np.float32)
+    o[0, :3] = [2.5, 3.5, 9.0]
+    view = ScaView(o, z, z, NPIX=(1, 1), FFS=1, nside=4)
+    i = 0
+    bg = (np.float32(L["WBG"] / float(FFREQ[i])) * sky[i]).astype(np.float32)
+    job = Job(cloud, FCSC[0, i], ABS=AFABS[0][i], SCA=AFSCA[0][i], BATCH=1, SEED=math.fmod(math.pi / 4 + launch.SEED0, 1.0),
+              GLOBAL=L["GLOBAL"], HPBG=bg, DSC=FDSC[0, i])
+    img, n = oracle_sim_sca(Oracle("soc"), job, view, 3)
+    want = img * np.float32(float(FFREQ[i]) * 1.0e23 * launch.PLANCK / (4.0 * np.pi / (12.0 * 16.0)))
+    np.testing.assert_allclose(OUTC[i], want, rtol=2e-6)
+    assert n > 0 and OUTC[i].sum() > 0

@@ -93,6 +93,21 @@ def test_division_by_cached_reciprocal_is_the_division(hp):
     assert np.array_equal(hp.div_by_rcp(n, u).view(np.uint32), (n / u).view(np.uint32))
 
 
+def test_atan2(hp):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(400000).astype(np.float32)
+    y = rng.standard_normal(400000).astype(np.float32)
+    y[:1000] *= np.float32(1e-6)
+    x[1000:2000] *= np.float32(1e-6)
+    got = hp.atan2(y, x)
+    want = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.abs(got - want).max() < 4.0e-7                      # absolute: angles up to pi
+    small = np.abs(want) < 0.5
+    assert ulp_err(got[small], want[small]).max() < 2.5
+    sp = hp.atan2(np.array([0.0, 1.0, -1.0, 0.0], np.float32), np.array([0.0, 0.0, 0.0, -1.0], np.float32))
+    assert sp[0] == 0 and abs(sp[1] - np.pi / 2) < 1e-6 and abs(sp[2] + np.pi / 2) < 1e-6 and abs(sp[3] - np.pi) < 1e-6
+
+
 def test_oracle_soc_mode_uses_this_header(hp, oracle_soc):
     x = np.random.default_rng(5).uniform(-20, 5, 20000).astype(np.float32)
     for fn, xx in (("exp", x), ("log", np.abs(x) + 1e-9), ("sin", x), ("cos", x), ("acos", np.clip(x / 20, -1, 1)),
