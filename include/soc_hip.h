@@ -196,6 +196,25 @@ int soc_sca_read_out(soc_ctx *ctx, float *out, int64_t n);
 void *soc_sca_out_ptr(soc_ctx *ctx);
 int   soc_sca_bind_out(soc_ctx *ctx, void *device_ptr);
 
+/* ---- equilibrium dust temperature and emission (ASOC.py `CLT`/`CLE` paths) ---- */
+
+/* replaces the EqTemperature launches per level (ASOC.py:2024-2040 -> kernel_ASOC_aux.c:745-790):
+ * EABS[CELLS] = integrated absorbed energy per cell (the array the reference calls EMIT at this
+ * point: TABS of the dust-emission iteration + CTABS), TTT[NE] the host's E->T table with
+ * E[i] = Emin*kE^i (ASOC.py:643-689); FACTOR and LENGTH = GL*PARSEC are the -D FACTOR / -D LENGTH
+ * literals (ASOC.py:345,348: %.4e and %.5e).  Temperatures stay on the device for soc_emission and
+ * are copied to TNEW[CELLS] unless NULL. */
+int soc_solve_temperature(soc_ctx *ctx, float adhoc, float kE, float Emin, int NE, const float *TTT, float FACTOR,
+                          float LENGTH, const float *EABS, float *TNEW);
+
+/* temperatures from elsewhere (`loadtemp`, ASOC.py:744-760) */
+int soc_set_temperature(soc_ctx *ctx, const float *T);
+
+/* replaces the Emission / Emission2 launches (ASOC.py:2154-2197 -> kernel_ASOC_aux.c:795-808, 862-888):
+ * EMITTED[CELLS][nfreq] = FACTOR x photons / Hz / cm3 of the modified black body at the device
+ * temperatures, for the nfreq frequencies FREQ with absorption cross sections FABS */
+int soc_emission(soc_ctx *ctx, int nfreq, const float *FREQ, const float *FABS, float FACTOR, float LENGTH, float *EMITTED);
+
 /* ---- stochastically heated grains: A2E.py / kernel_A2E.c ---- */
 
 /* replaces the per-size uploads of A2E.py:338-371 (AF, Iw, L1, L2, Tdown, EA, Ibeg) and the

@@ -214,6 +214,28 @@ class Oracle:
         n = self.lib.orc_sim(C.byref(m), kind, gid0, gid1, stride, nthreads)
         return TABS, INT, int(n)
 
+    def eqtemp(self, job, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS):
+        """EqTemperature (all levels) -> TNEW[CELLS]"""
+        m = self._model(job)
+        TTT = np.ascontiguousarray(TTT, np.float32)
+        EABS = np.ascontiguousarray(EABS, np.float32)
+        T = np.zeros(job.cloud.CELLS, np.float32)
+        self.lib.orc_eqtemp.argtypes = [C.POINTER(OrcModel), C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _F, _F, _F]
+        self.lib.orc_eqtemp(C.byref(m), np.float32(adhoc), np.float32(kE), np.float32(Emin), TTT.size, np.float32(FACTOR),
+                            np.float32(LENGTH), _fp(TTT), _fp(EABS), _fp(T))
+        return T
+
+    def emission(self, FREQ, FABS, FACTOR, LENGTH, T, c0=0, c1=None):
+        """Emission2 -> EMIT[c1-c0, nfreq]"""
+        FREQ = np.ascontiguousarray(FREQ, np.float32)
+        FABS = np.ascontiguousarray(FABS, np.float32)
+        T = np.ascontiguousarray(T, np.float32)
+        c1 = T.size if c1 is None else c1
+        out = np.zeros((c1 - c0, FREQ.size), np.float32)
+        self.lib.orc_emission.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _F, _F, _F, _F]
+        self.lib.orc_emission(c0, c1, FREQ.size, np.float32(FACTOR), np.float32(LENGTH), _fp(FREQ), _fp(FABS), _fp(T), _fp(out))
+        return out
+
     def math(self, fn, x):
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
@@ -314,6 +336,26 @@ class Ref:
         d = np.ascontiguousarray(direction, np.float32).copy()
         self.lib.ref_deflect(_fp(d), np.float32(cos_theta), np.float32(phi))
         return d
+
+    def eqtemp(self, job, adhoc, kE, Emin, TTT, EABS):
+        """the build's -D FACTOR / -D LENGTH apply (oracle/build.py: ref_defs)"""
+        TTT = np.ascontiguousarray(TTT, np.float32)
+        EABS = np.ascontiguousarray(EABS, np.float32)
+        T = np.zeros(job.cloud.CELLS, np.float32)
+        self.lib.ref_eqtemp.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _I, _I, _F, _F, _F, _F]
+        self.lib.ref_eqtemp(job.cloud.LEVELS, np.float32(adhoc), np.float32(kE), np.float32(Emin), TTT.size, _ip(job.OFF),
+                            _ip(job.LCELLS), _fp(TTT), _fp(job.DENS), _fp(EABS), _fp(T))
+        return T
+
+    def emission(self, job, FREQ, FABS, T, c0=0, c1=None):
+        FREQ = np.ascontiguousarray(FREQ, np.float32)
+        FABS = np.ascontiguousarray(FABS, np.float32)
+        T = np.ascontiguousarray(T, np.float32)
+        c1 = T.size if c1 is None else c1
+        out = np.zeros((c1 - c0, FREQ.size), np.float32)
+        self.lib.ref_emission2.argtypes = [C.c_int, C.c_int, C.c_int, _F, _F, _F, _F, _F]
+        self.lib.ref_emission2(c0, c1, FREQ.size, _fp(FREQ), _fp(FABS), _fp(job.DENS), _fp(T), _fp(out))
+        return out
 
     def sim(self, job, kind=0, gid0=0, gid1=None, nthreads=1, TABS=None, INT=None, stride=1):
         self._check(job)

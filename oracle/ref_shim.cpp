@@ -32,6 +32,9 @@ void SimRAM_PB(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float
                float *EMIT, float *TABS, float *DSC, float *CSC, float *XAB, float *EMWEI,
                float *INT, float *INTX, float *INTY, float *INTZ, float *OPT, float *ABU,
                int *XPS_NSIDE, int *XPS_SIDE, float *XPS_AREA);
+void EqTemperature(int level, float adhoc, float kE, float Emin, int NE, int *OFF, int *LCELLS, float *TTT, float *DENS,
+                   float *EMIT, float *TNEW);
+void Emission2(int c0, int c1, int nfreq, float *FREQ, float *FABS, float *DENS, float *T, float *EMIT);
 void SimRAM_HP(int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float TW, int *LCELLS, int *OFF, int *PAR,
                float *DENS, float *EMIT, float *TABS, float *DSC, float *CSC, float *XAB, float *INT, float *INTX,
                float *INTY, float *INTZ, float *OPT, float *BG, float *HPBGP, float *ABU);
@@ -96,6 +99,20 @@ void ref_sim(const ref_args *a, int kind, int gid0, int gid1, int stride, int nt
         });
     }
     for (auto &x : th) x.join();
+}
+
+// EqTemperature for every level, Emission2 for cells [c0, c1): one work item walks the whole grid-stride loop
+void ref_eqtemp(int LEVELS, float adhoc, float kE, float Emin, int NE, int *OFF, int *LCELLS, float *TTT, float *DENS,
+                float *EABS, float *TNEW)
+{
+    g_gid = 0;  g_gsize = 1;
+    for (int l = 0; l < LEVELS; l++) EqTemperature(l, adhoc, kE, Emin, NE, OFF, LCELLS, TTT, DENS, EABS, TNEW);
+}
+
+void ref_emission2(int c0, int c1, int nfreq, float *FREQ, float *FABS, float *DENS, float *T, float *EMIT)
+{
+    g_gid = 0;  g_gsize = 1;
+    Emission2(c0, c1, nfreq, FREQ, FABS, DENS, T, EMIT);
 }
 
 void ref_parents(float *DENS, int *LCELLS, int *OFF, int *PAR)

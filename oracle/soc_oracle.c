@@ -43,6 +43,8 @@
 #  define M_LDEXP_UP(x, l) ldexpf((x), (l))
 #  define M_FLOOR(x) floorf(x)
 #  define M_ATAN2(y, x) atan2f((y), (x))
+#  define M_LOG10(x) log10f(x)
+#  define M_POWN(x, n) powf((x), (float)(n))          /* as the reference shim resolves OpenCL pown */
 #  define M_EXPM1(x) expm1f(x)
 #  define M_POW15(x) powf((x), 1.5f)
 static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
@@ -61,6 +63,8 @@ static inline void M_SINCOS(float x, float *s, float *c) { *s = sinf(x); *c = co
 #  define M_LDEXP_UP(x, l) soc_scale_up((x), (l))
 #  define M_FLOOR(x) soc_floorf(x)
 #  define M_ATAN2(y, x) soc_atan2f((y), (x))
+#  define M_LOG10(x) soc_log10f(x)
+#  define M_POWN(x, n) soc_pownf((x), (n))
 #  define M_EXPM1(x) soc_expm1f(x)
 #  define M_POW15(x) soc_pow15f(x)
 static inline void M_SINCOS(float x, float *s, float *c) { soc_sincosf(x, s, c); }
@@ -1344,6 +1348,39 @@ EXPORT long orc_sim_sca(orc_model *M, int kind, int gid0, int gid1, int stride, 
         }
     }
     return total;
+}
+
+/* EqTemperature (kernel_ASOC_aux.c:745-790) for all levels; FACTOR and LENGTH are the -D literals */
+EXPORT void orc_eqtemp(const orc_model *M, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH,
+                       const float *TTT, const float *EABS, float *TNEW)
+{
+    const float scale  = (6.62607e-27f * FACTOR) / LENGTH;
+    const float oplgkE = 1.0f / M_LOG10(kE);
+    const float beta = 1.0f;
+    for (int level = 0; level < M->LEVELS; level++) {
+        for (int i = 0; i < M->LCELLS[level]; i++) {
+            const int   ind = M->OFF[level] + i;
+            const float Ein = (scale / adhoc) * EABS[ind] * M_POWN(8.0f, level) / M->DENS[ind];
+            const float a   = M_FLOOR(oplgkE * M_LOG10((Ein / beta) / Emin));
+            int   iE = (a != a) ? 0 : ((a < 0.0f) ? 0 : ((a > (float)(NE - 2)) ? NE - 2 : (int)a));
+            const float wi  = (Emin * M_POWN(kE, iE + 1) - (Ein / beta)) / (Emin * M_POWN(kE, iE) * (kE - 1.0f));
+            TNEW[ind] = (M->DENS[ind] > 1.0e-7f) ? clampf(wi * TTT[iE] + (1.0f - wi) * TTT[iE + 1], 3.0f, 1600.0f) : (10.0f);
+        }
+    }
+}
+
+/* Emission2 (kernel_ASOC_aux.c:862-888): EMIT[(icell-c0)*nfreq+ifreq] */
+EXPORT void orc_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
+                         const float *T, float *EMIT)
+{
+    for (int icell = c0; icell < c1; icell++) {
+        const float t = T[icell];
+        for (int ifreq = 0; ifreq < nfreq; ifreq++) {
+            const float freq = FREQ[ifreq];
+            EMIT[(long)(icell - c0) * nfreq + ifreq] =
+                (2.79639459e-20f * FACTOR) * FABS[ifreq] * (freq * freq / (M_EXP(4.7995074e-11f * freq / t) - 1.0f)) / LENGTH;
+        }
+    }
 }
 
 /* math probes for tests/test_math.py */

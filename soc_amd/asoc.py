@@ -52,6 +52,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("emweight 2")
     if USER.OPT_IS_HALF:
         bad.append("optishalf")
+    if USER.WITH_REFERENCE:
+        bad.append("reference (reference field)")
     if bad:
         raise UnsupportedOption("ini options not supported by this engine: " + ", ".join(bad))
 
@@ -275,6 +277,104 @@ class AbsorptionRun:
             self.log("******  CONSTANT   %10s   CTABS -> %12.4e" % (['PS', 'BG', 'DE'][II], float(np.mean(CTABS))))
         return CTABS, FABSORBED
 
+    # ---------------------------------------------------------------------------------
+    def emission_iterations(self, CTABS, FABSORBED):
+        """Simulation <-> temperature cycles (ASOC.py:1593-2260, the paths without reference field and
+        ALI): per iteration the dust emission of the previous one is simulated with SimRAM_CL
+        (`cellpackets`), the integrated absorptions TABS + CTABS give the equilibrium temperature of
+        every cell and that the emission at every frequency -- EqTemperature and Emission on the device
+        (the reference's `CLT`/`CLE` paths; its default host loop uses a different interpolation weight,
+        ASOC.py:2059, and is not reproduced).  Writes the temperature and emitted files.
+        Returns (TNEW or None, EMITTED[CELLS, REMIT_NFREQ])."""
+        U, e, c = self.U, self.eng, self.cloud
+        CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
+        m = np.nonzero((FFREQ >= U.REMIT_F[0]) & (FFREQ <= U.REMIT_F[1]))[0]
+        I1, I2 = int(m[0]), int(m[-1])
+        solve = (not U.NOSOLVE) and bool(U.NOABSORBED)
+        if solve and self.NDUST > 1:
+            raise ValueError("temperatures can be solved here for a single dust component only (ASOC.py:260-263)")
+        if (I2 - I1 + 1 < NFREQ) and U.ITERATIONS > 0 and self.CLPAC > 0:
+            raise ValueError("remit cannot restrict the frequencies when cell emission is simulated (ASOC.py:209-211)")
+        EMITTED = None
+        try:
+            EMITTED = np.array(files.mmap_emitted(U.file_emitted, CELLS, I2 - I1 + 1))
+        except (OSError, files.FileError, ValueError):
+            EMITTED = np.zeros((CELLS, I2 - I1 + 1), np.float32)
+        TNEW = None
+        if solve:
+            Emin, kE, TTT = launch.temperature_table(FFREQ, self.AFABS[0], U.GL)
+            FACTOR_f, LENGTH_f = launch.kernel_literals(U.GL)
+        EMWEI = np.ones(CELLS, np.float32) * np.float32(self.CLPAC / CELLS) if U.USE_EMWEIGHT > 0 else None
+        hostrng = np.random.default_rng(int(U.SEED * 2 ** 31) if U.SEED > 0 else None)
+        EMIT = np.zeros(CELLS, np.float32)
+        for iteration in range(U.ITERATIONS):
+            self.log("ITERATION %d/%d" % (iteration + 1, U.ITERATIONS))
+            e.zero(0)
+            if self.CLPAC > 0:
+                GLOBAL, BATCH = self.GLOBAL_0, max(1, int(self.CLPAC / CELLS))
+                first, count = self.comm.shard(GLOBAL) if self.comm else (0, GLOBAL)
+                skip = U.EMWEIGHT_SKIP - 1
+                for IFREQ in range(NFREQ):
+                    FREQ = float(FFREQ[IFREQ])
+                    if self.with_int:
+                        e.zero(1)
+                    if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
+                        continue
+                    t0 = time.time()
+                    self._optical_for(IFREQ)
+                    FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
+                    e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                    if IFREQ < I1 or IFREQ > I2:
+                        continue
+                    EMIT[:] = EMITTED[:, IFREQ - I1]
+                    for level in range(c.LEVELS):
+                        coeff = U.GL * PARSEC / (8.0 ** level) / launch.FACTOR
+                        a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
+                        EMIT[a:b] *= coeff * c.DENS[a:b]
+                    EMIT[c.DENS < 1.0e-10] = 0.0
+                    if U.USE_EMWEIGHT > 0:                         # ASOC.py:1745-1771
+                        skip += 1
+                        if skip % U.EMWEIGHT_SKIP == 0:
+                            tmp = np.asarray(EMITTED[:, IFREQ - I1], np.float64).copy()
+                            tmp[~np.isfinite(tmp)] = 0.0
+                            tmp[:] = self.CLPAC * tmp / (np.sum(tmp) + 1.0e-65)
+                            EMWEI[:] = np.clip(tmp, U.EMWEIGHT_LIM[0], U.EMWEIGHT_LIM[1])
+                            EMWEI[hostrng.random(CELLS) > EMWEI] = 0.0
+                            if U.EMWEIGHT_LIM[2] > 0.0:
+                                EMWEI[EMWEI < U.EMWEIGHT_LIM[2]] = 0.0
+                    e.set_emission(EMIT, EMWEI)
+                    if U.SEED > 0:
+                        seed = float(np.fmod(U.SEED + IFREQ * launch.SEED1, 1.0))      # ASOC.py:1807 (no SEED0 here)
+                    else:
+                        seed = float(hostrng.random())
+                        if self.comm and self.world > 1:
+                            seed = self._bcast_seed(seed)
+                    self.timers["Tpush"] += time.time() - t0
+                    t0 = time.time()
+                    e.sim_cl(2, self.CLPAC, BATCH, seed, FF, GLOBAL, gid_first=first, gid_count=count)
+                    if self.with_int and self.comm:
+                        self.comm.all_reduce_tally(e, 1)
+                    e.sync()
+                    self.timers["Tkernel"] += time.time() - t0
+                    self.packets += CELLS * BATCH
+                    if iteration == U.ITERATIONS - 1 and FABSORBED is not None:
+                        FABSORBED[:, IFREQ] += e.read_tally(1)
+                if self.comm:
+                    self.comm.all_reduce_tally(e, 0)
+                EABS = e.read_tally(0) + CTABS
+            else:
+                EABS = np.array(CTABS, np.float32)
+            if solve:
+                t0 = time.time()
+                TNEW = e.solve_temperature(launch.ADHOC, kE, Emin, TTT, FACTOR_f, LENGTH_f, EABS)
+                EMITTED[:, :] = e.emission(FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], FACTOR_f, LENGTH_f)
+                self.timers["Tsolve"] = self.timers.get("Tsolve", 0.0) + time.time() - t0
+        if self.rank == 0 and solve and U.ITERATIONS > 0:
+            if len(U.file_temperature) > 0:
+                files.write_temperature(U.file_temperature, c, TNEW)
+            files.write_emitted(U.file_emitted, EMITTED)
+        return TNEW, EMITTED
+
     def _bcast_seed(self, seed):
         t = self.comm.torch.tensor([seed], dtype=self.comm.torch.float64,
                                    device="cuda" if self.comm.backend == "nccl" else "cpu")
@@ -288,6 +388,9 @@ class AbsorptionRun:
         self.setup_engine()
         CTABS, FABSORBED = self.simulate_constant_sources()
         U = self.U
+        self.TNEW, self.EMITTED = None, None
+        if U.ITERATIONS > 0 and (self.CLPAC > 0 or ((not U.NOSOLVE) and U.NOABSORBED)) and hasattr(self.eng, "solve_temperature"):
+            self.TNEW, self.EMITTED = self.emission_iterations(CTABS, FABSORBED)
         if self.rank == 0:
             if len(U.file_constant_save) > 0:
                 CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549

@@ -62,6 +62,11 @@ struct soc_ctx {
     int with_int = 0, ps_method = 0, use_emweight = 0, mirror = 0;
     // execution
     int exec_mode = -1, brick_log2 = 4, last_passes = 0;
+    // equilibrium temperature / emission (soc_emit.hip)
+    float *dT = nullptr, *dTTT = nullptr, *dEbuf = nullptr, *dEF = nullptr;
+    int    ttt_cap = 0, ef_cap = 0;
+    size_t ebuf_cap = 0;
+    bool   have_T = false;
     // A2E
     int a2e_NE = 0, a2e_NFREQ = 0, a2e_npair = 0, a2e_cap = 0, a2e_noIw = 0;
     float *aIw = nullptr, *aTdown = nullptr, *aEA = nullptr, *aAF = nullptr, *aABS = nullptr, *aEMIT = nullptr;
@@ -176,7 +181,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP,
+    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -910,6 +915,71 @@ int soc_timer_stop(soc_ctx *c, float *elapsed_ms)
 // ---------------------------------------------------------------------------------------
 // A2E: stochastically heated grains
 // ---------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------
+// equilibrium temperature and emission (ASOC.py `CLT` / `CLE` paths)
+// ------------------------------------------------------------------------------------
+
+int soc_solve_temperature(soc_ctx *c, float adhoc, float kE, float Emin, int NE, const float *TTT, float FACTOR, float LENGTH,
+                          const float *EABS, float *TNEW)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_solve_temperature: call soc_set_grid first");
+    if (!TTT || !EABS || NE < 2 || !(kE > 1.0f) || !(Emin > 0.0f) || !(adhoc > 0.0f) || !(LENGTH > 0.0f))
+        return fail(c, SOC_ERR_ARG, "soc_solve_temperature: need TTT[NE>=2], EABS, kE>1, Emin>0, adhoc>0, LENGTH>0");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)c->G.CELLS;
+    if (!c->dT) HIPCHK(c, dev_alloc(&c->dT, cells));
+    if (NE > c->ttt_cap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dev_alloc(&c->dTTT, (size_t)NE)); c->ttt_cap = NE; }
+    if (c->ebuf_cap < cells) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dev_alloc(&c->dEbuf, cells)); c->ebuf_cap = cells; }
+    HIPCHK(c, hipMemcpyAsync(c->dTTT, TTT, (size_t)NE * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dEbuf, EABS, cells * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, soc_launch_eqtemp(c->G, adhoc, kE, Emin, NE, FACTOR, LENGTH, c->dTTT, c->dEbuf, c->dT, c->stream));
+    if (TNEW) HIPCHK(c, hipMemcpyAsync(TNEW, c->dT, cells * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_T = true;
+    return SOC_OK;
+}
+
+int soc_set_temperature(soc_ctx *c, const float *T)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid || !T) return fail(c, SOC_ERR_STATE, "soc_set_temperature: needs a grid and T[CELLS]");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->dT) HIPCHK(c, dev_alloc(&c->dT, (size_t)c->G.CELLS));
+    HIPCHK(c, hipMemcpyAsync(c->dT, T, (size_t)c->G.CELLS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_T = true;
+    return SOC_OK;
+}
+
+int soc_emission(soc_ctx *c, int nfreq, const float *FREQ, const float *FABS, float FACTOR, float LENGTH, float *EMITTED)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_T) return fail(c, SOC_ERR_STATE, "soc_emission: call soc_solve_temperature or soc_set_temperature first");
+    if (nfreq < 1 || !FREQ || !FABS || !EMITTED || !(LENGTH > 0.0f)) return fail(c, SOC_ERR_ARG, "soc_emission: nfreq %d", nfreq);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (2 * nfreq > c->ef_cap) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dev_alloc(&c->dEF, (size_t)2 * nfreq)); c->ef_cap = 2 * nfreq; }
+    HIPCHK(c, hipMemcpyAsync(c->dEF, FREQ, (size_t)nfreq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dEF + nfreq, FABS, (size_t)nfreq * 4, hipMemcpyHostToDevice, c->stream));
+    // batches of cells, all frequencies (the layout of the emitted file: EMITTED[CELLS][nfreq])
+    const int cells = c->G.CELLS;
+    int batch = (int)(((size_t)64 << 20) / (size_t)nfreq);            // <= 256 MB of floats per batch
+    if (batch < 1) batch = 1;
+    if (batch > cells) batch = cells;
+    const size_t need = (size_t)batch * nfreq;
+    if (c->ebuf_cap < need) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dev_alloc(&c->dEbuf, need)); c->ebuf_cap = need; }
+    for (int a = 0; a < cells; a += batch) {
+        const int b = (a + batch < cells) ? a + batch : cells;
+        HIPCHK(c, soc_launch_emission(a, b, nfreq, FACTOR, LENGTH, c->dEF, c->dEF + nfreq, c->dT, c->dEbuf, c->stream));
+        HIPCHK(c, hipMemcpyAsync(EMITTED + (size_t)a * nfreq, c->dEbuf, (size_t)(b - a) * nfreq * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return SOC_OK;
+}
 
 int soc_a2e_set_size(soc_ctx *c, int NE, int NFREQ, int noIw, const float *Iw, const int32_t *L1,
                      const int32_t *L2, const float *Tdown, const float *EA, const int32_t *Ibeg, const float *AF)

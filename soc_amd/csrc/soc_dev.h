@@ -79,6 +79,12 @@ struct SocSca {
 };
 hipError_t soc_launch_sca(const SocGrid &G, const SocSim &S, const SocSca &V, const SocVariant &X, hipStream_t st);
 
+// equilibrium temperature and thermal emission (soc_emit.hip)
+hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH,
+                             const float *TTT, const float *EABS, float *TNEW, hipStream_t st);
+hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
+                               const float *T, float *EMIT, hipStream_t st);
+
 // stochastic-heating solver (soc_a2e.hip)
 struct SocA2EArgs {
     int NE, NFREQ, npair, batch;

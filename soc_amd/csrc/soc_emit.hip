@@ -1,0 +1,65 @@
+// soc_emit.hip -- equilibrium dust temperature and thermal emission on the device:
+// EqTemperature, Emission and Emission2 of kernel_ASOC_aux.c (:745-790, :795-808, :862-888), the
+// `CLT` / `CLE` paths of ASOC.py (:2024-2040, :2154-2197).  Pure streaming over the cells; the
+// point of having them here is that the absorbed energies never leave the GPU between the
+// simulation and the next iteration's emission.
+//
+// The reference bakes FACTOR (%.4e) and LENGTH = GL*PARSEC (%.5e) into the kernel as float
+// literals (ASOC.py:344-362); here they are float arguments that the host rounds the same way.
+#include "soc_dev.h"
+#include "soc_math.h"
+
+// TNEW[cell] from the absorbed energy per cell (array "EMIT" in the reference), all levels in one launch
+__global__ void soc_eqtemp_kernel(const SocGrid G, const float adhoc, const float kE, const float Emin, const int NE,
+                                  const float FACTOR, const float LENGTH, const float *TTT, const float *EABS, float *TNEW)
+{
+    __shared__ int sOFF[SOC_MAXL + 1];
+    if (threadIdx.x <= SOC_MAXL) sOFF[threadIdx.x] = (threadIdx.x < G.LEVELS) ? G.OFF[threadIdx.x] : G.CELLS;
+    __syncthreads();
+    const float scale  = (6.62607e-27f * FACTOR) / LENGTH;
+    const float oplgkE = 1.0f / soc_log10f(kE);
+    const float beta   = 1.0f;
+    const long  stride = (long)gridDim.x * blockDim.x;
+    for (long ind = (long)blockIdx.x * blockDim.x + threadIdx.x; ind < G.CELLS; ind += stride) {
+        int level = 0;
+        while (level + 1 < G.LEVELS && ind >= sOFF[level + 1]) level++;
+        const float d   = G.DENS[ind];
+        const float Ein = (scale / adhoc) * EABS[ind] * soc_pownf(8.0f, level) / d;
+        int iE = (int)soc_floorf(oplgkE * soc_log10f((Ein / beta) / Emin));
+        iE = iE < 0 ? 0 : (iE > NE - 2 ? NE - 2 : iE);
+        const float wi = (Emin * soc_pownf(kE, iE + 1) - (Ein / beta)) / (Emin * soc_pownf(kE, iE) * (kE - 1.0f));
+        TNEW[ind] = (d > 1.0e-7f) ? soc_clampf(wi * TTT[iE] + (1.0f - wi) * TTT[iE + 1], 3.0f, 1600.0f) : 10.0f;
+    }
+}
+
+// EMITTED[cell - c0][ifreq] for cells [c0, c1) and nfreq frequencies (Emission2; Emission is nfreq == 1)
+__global__ void soc_emission_kernel(const int c0, const int c1, const int nfreq, const float FACTOR, const float LENGTH,
+                                    const float *FREQ, const float *FABS, const float *T, float *EMIT)
+{
+    const long n = (long)(c1 - c0) * nfreq;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const int   icell = c0 + (int)(k / nfreq), ifreq = (int)(k % nfreq);
+        const float t = T[icell], freq = FREQ[ifreq];
+        EMIT[k] = (2.79639459e-20f * FACTOR) * FABS[ifreq] * (freq * freq / (soc_expf(4.7995074e-11f * freq / t) - 1.0f)) / LENGTH;
+    }
+}
+
+hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH,
+                             const float *TTT, const float *EABS, float *TNEW, hipStream_t st)
+{
+    if (G.CELLS <= 0) return hipSuccess;
+    const int blocks = (int)(((long)G.CELLS + 255) / 256 < 65536 ? ((long)G.CELLS + 255) / 256 : 65536);
+    soc_eqtemp_kernel<<<blocks, 256, 0, st>>>(G, adhoc, kE, Emin, NE, FACTOR, LENGTH, TTT, EABS, TNEW);
+    return hipGetLastError();
+}
+
+hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
+                               const float *T, float *EMIT, hipStream_t st)
+{
+    const long n = (long)(c1 - c0) * nfreq;
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    soc_emission_kernel<<<blocks, 256, 0, st>>>(c0, c1, nfreq, FACTOR, LENGTH, FREQ, FABS, T, EMIT);
+    return hipGetLastError();
+}

@@ -285,3 +285,15 @@ def write_outcoming_healpix(filename, NSIDE, FFREQ, OUTCOMING):
         np.asarray([NSIDE, OUTCOMING.shape[0]], np.int32).tofile(fp)
         np.asarray(FFREQ, np.float32).tofile(fp)
         OUTCOMING.tofile(fp)
+
+
+def write_temperature(filename, cloud, TNEW):
+    """temperature file: the layout of the cloud file (ASOC.py:2125-2133): int32 NX,NY,NZ,LEVELS,CELLS;
+    per level int32 LCELLS[level] + float32 T of its cells"""
+    TNEW = np.asarray(TNEW, np.float32)
+    with open(filename, 'wb') as fp:
+        np.asarray([cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, cloud.CELLS], np.int32).tofile(fp)
+        for level in range(cloud.LEVELS):
+            a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+            np.asarray([cloud.LCELLS[level]], np.int32).tofile(fp)
+            TNEW[a:b].tofile(fp)

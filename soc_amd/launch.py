@@ -124,6 +124,43 @@ def shard_range(GLOBAL, rank, world):
     return first, last - first
 
 
+H_K_D = 4.79924335e-11                 # ASOC_aux.py:36
+H_CC20 = 7.372496678e-28                # ASOC_aux.py:40
+NE_TEMPERATURE = 30000                  # ASOC.py:641
+
+
+def planck_safe(f, T):
+    """ASOC_aux.py:60-62"""
+    return 2.0e-20 * ((H_CC20 * f) * f) * f / (np.exp(np.clip(H_K_D * f / T, -100, +100)) - 1.0)
+
+
+def kernel_literals(GL):
+    """The float literals the reference compiles into its kernels: -D FACTOR=%.4ef, -D LENGTH=%.5ef
+    with LENGTH = GL*PARSEC (ASOC.py:345-348).  Returns (FACTOR, LENGTH) as float32."""
+    return np.float32(float("%.4e" % FACTOR)), np.float32(float("%.5e" % (GL * PARSEC)))
+
+
+def temperature_table(FFREQ, FABS, GL, NE=NE_TEMPERATURE):
+    """E <-> T mapping of the equilibrium-temperature solve (ASOC.py:643-689): energies emitted by a
+    grain at T = 1 + i*1600/NE K (trapezoid integral of FABS*B_nu, with the FACTOR scaling), inverted on a
+    logarithmic energy grid E[i] = Emin*kE^i by linear interpolation.  Returns (Emin, kE, TTT float32[NE])."""
+    FFREQ = np.asarray(FFREQ, np.float64)
+    FABS = np.asarray(FABS, np.float64)
+    TSTEP = 1600.0 / NE
+    TT = 1.0 + TSTEP * np.arange(NE)
+    DF = FFREQ[2:] - FFREQ[:(-2)]
+    Eout = np.zeros(NE, np.float64)
+    for i in range(NE):
+        TMP = FABS * planck_safe(FFREQ, TT[i])
+        res = TMP[0] * (FFREQ[1] - FFREQ[0]) + TMP[-1] * (FFREQ[-1] - FFREQ[-2])
+        res += np.sum(TMP[1:(-1)] * DF)
+        Eout[i] = (4.0 * np.pi * FACTOR / (GL * PARSEC)) * 0.5 * res
+    Emin, Emax = Eout[0], Eout[NE - 1] * 0.9999
+    kE = (Emax / Emin) ** (1.0 / (NE - 1.0))
+    TTT = np.asarray(np.interp(Emin * kE ** np.arange(NE), Eout, TT), np.float32)
+    return Emin, kE, TTT
+
+
 def mirror_mask(MIRROR):
     """`mirror xXyYzZ` -> bit mask of reflecting faces (ASOC.py:319-321)"""
     MIRROR = MIRROR or ""

@@ -64,6 +64,9 @@ API = {
     "soc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "soc_timer_start": (C.c_int, [C.c_void_p]),
     "soc_timer_stop": (C.c_int, [C.c_void_p, _F]),
+    "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
+    "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
+    "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
     "soc_a2e_set_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F]),
     "soc_a2e_solve": (C.c_int, [C.c_void_p, C.c_int, _F, _F]),
     "soc_a2e_upload": (C.c_int, [C.c_void_p, C.c_int, _F]),
@@ -248,6 +251,32 @@ class Engine:
         gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count
         self._chk(self.lib.soc_sim_hp(self.h, int(PACKETS), int(BATCH), np.float32(SEED), np.float32(TW), int(GLOBAL),
                                       int(gid_first), int(gid_count)))
+
+    # ---- equilibrium temperature and emission ----
+    def solve_temperature(self, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS):
+        """EABS[CELLS]: integrated absorbed energy; returns TNEW[CELLS] (kept on the device for emission())"""
+        TTT = np.ascontiguousarray(TTT, np.float32)
+        EABS = np.ascontiguousarray(EABS, np.float32)
+        if EABS.size != self.CELLS:
+            raise SocError("solve_temperature: EABS must hold CELLS floats")
+        T = np.zeros(self.CELLS, np.float32)
+        self._chk(self.lib.soc_solve_temperature(self.h, np.float32(adhoc), np.float32(kE), np.float32(Emin), int(TTT.size), _f(TTT),
+                                                 np.float32(FACTOR), np.float32(LENGTH), _f(EABS), _f(T)))
+        return T
+
+    def set_temperature(self, T):
+        T = np.ascontiguousarray(T, np.float32)
+        if T.size != self.CELLS:
+            raise SocError("set_temperature: T must hold CELLS floats")
+        self._chk(self.lib.soc_set_temperature(self.h, _f(T)))
+
+    def emission(self, FREQ, FABS, FACTOR, LENGTH):
+        """EMITTED[CELLS, nfreq] (FACTOR x photons/Hz/cm3) at the device temperatures"""
+        FREQ = np.ascontiguousarray(FREQ, np.float32)
+        FABS = np.ascontiguousarray(FABS, np.float32)
+        out = np.zeros((self.CELLS, FREQ.size), np.float32)
+        self._chk(self.lib.soc_emission(self.h, int(FREQ.size), _f(FREQ), _f(FABS), np.float32(FACTOR), np.float32(LENGTH), _f(out)))
+        return out
 
     # ---- scattered-light images (ASOCS) ----
     @staticmethod

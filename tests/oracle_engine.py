@@ -80,6 +80,18 @@ class OracleEngine:
         _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n
 
+    # ---- temperature and emission ----
+    def solve_temperature(self, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS):
+        job = Job(self.cloud, np.linspace(1, -1, 8))
+        self.Tdust = self.orc.eqtemp(job, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+        return self.Tdust.copy()
+
+    def set_temperature(self, T):
+        self.Tdust = np.asarray(T, np.float32).copy()
+
+    def emission(self, FREQ, FABS, FACTOR, LENGTH):
+        return self.orc.emission(FREQ, FABS, FACTOR, LENGTH, self.Tdust)
+
     # ---- scattered-light images ----
     def sca_set_view(self, ODIR, RA, DE, NPIX, MAP_DX, CENTRE, FFS=1):
         self.view = ScaView(ODIR, RA, DE, NPIX=NPIX, MAP_DX=MAP_DX, CENTRE=CENTRE, FFS=FFS)

@@ -1,0 +1,133 @@
+"""Equilibrium temperature and emission: oracle against the reference's
+EqTemperature / Emission2 (x86 build, bit-exact in libm mode), host E<->T table against an independent
+evaluation, the iteration loop of asoc.py on the oracle-backed engine, and (GPU) the HIP kernels against
+the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import Job, Oracle, Ref
+from soc_amd import files, launch, synth
+from soc_amd.asoc import AbsorptionRun
+from soc_amd.ini import User
+
+FF = np.logspace(np.log10(3e11), np.log10(3e15), 40)
+FABS = 1e-5 * (FF / 1e13) ** 1.6
+GL = 0.01
+
+
+def _absorbed(cloud, Emin, kE, TTT, FACTOR, LENGTH, seed=4):
+    """absorbed energies that put the leaves at temperatures between 5 and 300 K"""
+    NE = len(TTT)
+    T_target = np.random.default_rng(seed).uniform(5, 300, cloud.CELLS)
+    Ein = np.interp(T_target, TTT.astype(float), Emin * kE ** np.arange(NE))
+    lev = np.zeros(cloud.CELLS, int)
+    for l in range(cloud.LEVELS):
+        lev[cloud.OFF[l]:cloud.OFF[l] + cloud.LCELLS[l]] = l
+    scale = 6.62607e-27 * float(FACTOR) / float(LENGTH)
+    return (Ein * np.abs(cloud.DENS) / (scale * 8.0 ** lev)).astype(np.float32), T_target
+
+
+def test_kernel_literals_and_table():
+    FACTOR, LENGTH = launch.kernel_literals(GL)
+    assert FACTOR == np.float32(1.0e20) and LENGTH == np.float32(3.08568e16)     # "%.5e" % (0.01*3.08567758e18)
+    Emin, kE, TTT = launch.temperature_table(FF, FABS, GL, NE=6000)
+    # independent: energy emitted at T, trapezoid over the frequency grid
+    def Eout(T):
+        B = 2.0e-20 * 7.372496678e-28 * FF ** 3 / np.expm1(np.clip(4.79924335e-11 * FF / T, -100, 100))
+        return 4.0 * np.pi * 1.0e20 / (GL * 3.08567758e18) * np.trapezoid(FABS * B, FF)
+    assert abs(Emin / Eout(1.0) - 1) < 1e-9
+    for i in (3000, 4500, 5999):                                                 # T > 20 K: E(T) is smooth on the 0.27 K grid
+        assert abs(Eout(float(TTT[i])) / (Emin * kE ** i) - 1) < 2e-3
+    assert TTT[0] == 1.0 and 1590 < TTT[-1] <= 1601
+
+
+@pytest.mark.skipif(not Ref.available("oct8"), reason="reference builds (oracle/_ref) not present")
+def test_oracle_bit_exact_vs_reference_kernels():
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    job = Job(o8, np.linspace(1, -1, 2500))
+    Emin, kE, TTT = launch.temperature_table(FF, FABS, GL, NE=3000)
+    FACTOR, LENGTH = launch.kernel_literals(GL)
+    EABS, T_target = _absorbed(o8, Emin, kE, TTT, FACTOR, LENGTH)
+    ol = Oracle("libm")
+    T = ol.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+    assert np.array_equal(T.view(np.uint32), Ref("oct8").eqtemp(job, 1.0, kE, Emin, TTT, EABS).view(np.uint32))
+    leaf = o8.DENS > 0
+    assert np.abs(T[leaf] - T_target[leaf]).max() < 0.01 and (T[~leaf] == 10.0).all()
+    E = ol.emission(FF, FABS, FACTOR, LENGTH, T)
+    assert np.array_equal(E.view(np.uint32), Ref("oct8").emission(job, FF, FABS, T).view(np.uint32))
+    # product math: same algorithm, last-bit differences in log10/pown/exp only
+    Ts = Oracle("soc").eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+    assert np.abs(Ts[leaf] / T[leaf] - 1).max() < 2e-5
+
+
+def test_iteration_loop_on_oracle_engine(tmp_path):
+    """constant sources -> T -> emission -> cell-emission packets -> T: files and arithmetic of one cycle"""
+    from oracle_engine import OracleEngine
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    extra = ("noabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
+    ini = _write_model(d, cloud, extra=extra).replace("nosolve\n", "")
+    txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+    eng = OracleEngine("soc")
+    run = AbsorptionRun(User(ini), eng)
+    CTABS, FABS_ = run.run()
+    assert FABS_ is None and run.TNEW is not None
+    # files
+    head = np.fromfile(os.path.join(d, "T.bin"), np.int32, 5)
+    assert list(head) == [6, 6, 6, 2, cloud.CELLS]
+    em = files.mmap_emitted(os.path.join(d, "em.bin"), cloud.CELLS, 3)
+    assert np.array_equal(np.array(em), run.EMITTED)
+    leaf = cloud.DENS > 0
+    assert (run.TNEW[leaf] >= 3.0).all() and (run.TNEW[leaf] <= 1600.0).all() and (run.TNEW[~leaf] == 10.0).all()
+    # the emission is the modified black body of those temperatures (Emission kernel formula)
+    FFREQ, _, AFABS, _ = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    FACTOR, LENGTH = launch.kernel_literals(0.5)
+    want = Oracle("soc").emission(FFREQ, AFABS[0], FACTOR, LENGTH, run.TNEW)
+    assert np.array_equal(run.EMITTED, want)
+    # second iteration used cell emission: temperatures are at least those from the constant sources alone
+    Emin, kE, TTT = launch.temperature_table(FFREQ, AFABS[0], 0.5)
+    T0 = Oracle("soc").eqtemp(Job(cloud, np.linspace(1, -1, 8)), 1.0, kE, Emin, TTT, FACTOR, LENGTH, CTABS)
+    assert (run.TNEW[leaf] >= T0[leaf] - 1e-3).all() and (run.TNEW[leaf] > T0[leaf]).any()
+
+
+@pytest.mark.gpu
+def test_hip_temperature_and_emission_match_oracle(engine):
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    job = Job(o8, np.linspace(1, -1, 2500))
+    Emin, kE, TTT = launch.temperature_table(FF, FABS, GL, NE=3000)
+    FACTOR, LENGTH = launch.kernel_literals(GL)
+    EABS, _ = _absorbed(o8, Emin, kE, TTT, FACTOR, LENGTH)
+    engine.set_cloud(o8)
+    T = engine.solve_temperature(1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+    osoc = Oracle("soc")
+    want = osoc.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+    assert np.array_equal(T.view(np.uint32), want.view(np.uint32))          # same header, same operation order
+    E = engine.emission(FF, FABS, FACTOR, LENGTH)
+    assert np.array_equal(E.view(np.uint32), osoc.emission(FF, FABS, FACTOR, LENGTH, want).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_iteration_loop_end_to_end(engine, tmp_path):
+    from oracle_engine import OracleEngine
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    extra = ("noabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
+    ini = _write_model(d, cloud, extra=extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+    want = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+    want.run()
+    os.remove(os.path.join(d, "em.bin"))          # an existing emitted file is the starting point of the next run
+    got = AbsorptionRun(User(ini), engine, verbose=0)
+    got.run()
+    leaf = cloud.DENS > 0
+    assert np.abs(got.TNEW[leaf] / want.TNEW[leaf] - 1).max() < 2e-5
+    assert np.allclose(got.EMITTED[leaf], want.EMITTED[leaf], rtol=2e-3)
