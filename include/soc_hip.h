@@ -33,6 +33,7 @@ typedef struct soc_ctx soc_ctx;
 /* tallies selectable in soc_zero / soc_read_tally / soc_tally_ptr */
 #define SOC_TALLY_TABS    0   /* absorbed energy integrated over frequency (TABS, kernel arg 15) */
 #define SOC_TALLY_INT     1   /* per-frequency absorptions (INT, kernel arg 20)                  */
+#define SOC_TALLY_XAB     2   /* WITH_ALI: absorptions inside the emitting cell (XAB, kernel arg 19) */
 
 /* replaces ASOC_aux.py:1188-1256 opencl_init(): create a context on GPU `device` */
 int  soc_create(int device, soc_ctx **out);
@@ -53,7 +54,7 @@ int soc_set_grid(soc_ctx *ctx, int NX, int NY, int NZ, int LEVELS, const int32_t
 /* feature switches the reference compiles in with -D (ASOC.py:344-362):
  *   with_int     : SAVE_INTENSITY in (1,2) or NOABSORBED==0 -> INT tally is updated
  *   ps_method    : PS_METHOD 0,1,2,4,5 (3 does not compile in the reference)
- *   use_emweight : USE_EMWEIGHT 0 or 1 (SimRAM_CL)                                         */
+ *   use_emweight : USE_EMWEIGHT 0, 1, or 2 = cells listed by soc_set_emindex (SimRAM_CL)     */
 int soc_set_features(soc_ctx *ctx, int with_int, int ps_method, int use_emweight);
 
 /* replaces -D MIRROR=%d (ASOC.py:319-321,352; ASOCS.py:119-122): reflecting model faces, bits
@@ -81,6 +82,14 @@ int soc_set_scatter_table(soc_ctx *ctx, const float *DSC, const float *CSC, int 
 
 /* replaces the EMIT / EMWEI uploads (ASOC.py:1276, 1291); arrays of CELLS floats */
 int soc_set_emission(soc_ctx *ctx, const float *EMIT, const float *EMWEI);
+
+/* replaces the EMINDEX upload of the USE_EMWEIGHT==2 loop (ASOC.py:1809-1840): EMINDEX[CELLS], the cells to
+ * emit 100 packets from in the next soc_sim_cl launch, terminated by -1 */
+int soc_set_emindex(soc_ctx *ctx, const int32_t *EMINDEX);
+
+/* replaces -D WITH_ALI=1 (ASOC.py:344): what a cell absorbs of its own emission is tallied in XAB
+ * (SOC_TALLY_XAB) instead of TABS (kernel_ASOC.c:1486-1491); soc_zero(ctx, 0) clears both */
+int soc_set_ali(soc_ctx *ctx, int with_ali);
 
 /* replaces ZeroAMC (kernel_ASOC_aux.c:657-683; ASOC.py:1115,1183): tag 0 clears TABS,
  * tag 1 clears INT */

@@ -52,10 +52,10 @@ def build_oracle(force=False):
 
 def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
              USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
-             GL=0.01, HPBG_WEIGHTED=0):
+             GL=0.01, HPBG_WEIGHTED=0, WITH_ALI=0):
     """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
-    d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=0, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
+    d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=WITH_ALI, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
              CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS), WITH_ABU=WITH_ABU, ROI_MAP=0, MAX_SPLIT=4300,
              SELEM=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0,
              AXY="%.5ff" % (NX * NY / AREA), AXZ="%.5ff" % (NX * NZ / AREA), AYZ="%.5ff" % (NY * NZ / AREA),
@@ -220,6 +220,8 @@ def ref_models():
         "c128":    dict(NX=128, NY=128, NZ=128, LEVELS=1, CELLS=128 ** 3),
         "c8mir":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, MIRROR=25),
         "oct8mir": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, MIRROR=6),
+        "oct8emw2": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=2),
+        "oct8ali": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, WITH_ALI=1),
         "c8hpw":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, HPBG_WEIGHTED=1),
         "oct8hpw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, HPBG_WEIGHTED=1, NOABSORBED=0),
     }

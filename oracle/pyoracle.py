@@ -38,6 +38,7 @@ class OrcModel(C.Structure):
         ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
         ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("DSC", _F), ("OUT", _F), ("XPS_AS_FLOAT", C.c_int),
         ("HPBG_WEIGHTED", C.c_int), ("HPBG", _F), ("HPBGP", _F), ("MIRROR", C.c_int),
+        ("WITH_ALI", C.c_int), ("XAB", _F), ("EMINDEX", _I),
     ]
 
 
@@ -63,8 +64,12 @@ class Job:
 
     def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
                  GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
-                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None, MIRROR=0):
+                 EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None, MIRROR=0,
+                 WITH_ALI=0, EMINDEX=None):
         self.cloud = cloud
+        self.WITH_ALI = int(WITH_ALI)
+        self.EMINDEX = None if EMINDEX is None else np.ascontiguousarray(EMINDEX, np.int32)
+        self.XAB = np.zeros(cloud.CELLS, np.float32)
         self.MIRROR = int(MIRROR)
         # Healpix sky (NSIDE 64, RING) in photons per package; HPBGP given = weighted pixel selection
         self.HPBG = None if HPBG is None else np.ascontiguousarray(HPBG, np.float32)
@@ -164,6 +169,7 @@ class Oracle:
         m.XPS_NSIDE, m.XPS_SIDE, m.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         m.EMIT, m.EMWEI = _fp(job.EMIT), _fp(job.EMWEI)
         m.MIRROR = job.MIRROR
+        m.WITH_ALI, m.XAB, m.EMINDEX = job.WITH_ALI, _fp(job.XAB), _ip(job.EMINDEX)
         m.HPBG_WEIGHTED = int(job.HPBGP is not None)
         m.HPBG, m.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
         return m
@@ -286,6 +292,7 @@ class Ref:
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1))
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
         assert job.MIRROR == m.get("MIRROR", 0)
+        assert job.WITH_ALI == m.get("WITH_ALI", 0)
 
     def seed(self, SEED, gid):
         x, c = C.c_uint32(), C.c_uint32()
@@ -373,12 +380,12 @@ class Ref:
         a.ABS, a.SCA, a.PSPOS, a.PS = _fp(ABS), _fp(SCA), _fp(job.PSPOS), _fp(job.PS)
         a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
         a.DENS, a.EMIT, a.TABS = _fp(job.DENS), _fp(job.EMIT), _fp(TABS)
-        a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(job.CSC), _fp(dummy), _fp(job.EMWEI)
+        a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(job.CSC), _fp(job.XAB), _fp(job.EMWEI)
         a.INT, a.INTX, a.INTY, a.INTZ = _fp(INT), _fp(dummy), _fp(dummy), _fp(dummy)
         a.OPT = _fp(job.OPT) if job.OPT is not None else _fp(dummy)
         a.ABU = _fp(dummy)
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
-        a.EMINDEX = _ip(idummy)
+        a.EMINDEX = _ip(job.EMINDEX) if job.EMINDEX is not None else _ip(idummy)
         a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP if job.HPBGP is not None else dummy)
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sim(C.byref(a), kind, gid0, gid1, stride, nthreads)

@@ -114,6 +114,9 @@ typedef struct {
     const float *HPBG;                /* [49152] photons per package                      */
     const float *HPBGP;               /* [49152] cumulative pixel probability (weighted)  */
     int   MIRROR;                     /* bit mask x,X,y,Y,z,Z = 1,2,4,8,16,32 (ASOC.py:319-321) */
+    int   WITH_ALI;                   /* SimRAM_CL: absorptions in the emitting cell go to XAB           */
+    float *XAB;                       /* [CELLS]                                                          */
+    const int *EMINDEX;               /* [CELLS] USE_EMWEIGHT==2: cells to emit from, terminated by -1    */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -368,8 +371,9 @@ static void Mirror(const orc_model *M, f3 *pos, f3 *dir, int *level, int *ind)
     if (MIRROR & 32) { if (pos->z > M->NZ) pos->z = M->NZ - EPS_MIRROR;  dir->z = -dir->z;  IndexG(M, pos, level, ind); }
 }
 
+/* e_index: global index of the emitting cell (WITH_ALI, kernel_ASOC.c:1394-1396) or -1 */
 static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS,
-                        int level, int ind, int cl_order)
+                        int level, int ind, int cl_order, int e_index)
 {
     const float *DENS = M->DENS;
     const int *OFF = M->OFF;
@@ -410,7 +414,8 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
                 break;
             }
             delta = (tauA > TAULIM) ? (PHOTONS * (1.0f - M_EXP(-tauA))) : (PHOTONS * tauA * (1.0f - 0.5f * tauA));
-            tally(M, M->TABS, oind, delta * M->TW * 1.0f);
+            if ((M->WITH_ALI == 1) && (oind == e_index)) tally(M, M->XAB, oind, delta * M->TW);   /* :1486-1491, :1589-1594 */
+            else tally(M, M->TABS, oind, delta * M->TW * 1.0f);
             if (M->WITH_INT) tally(M, M->INT, oind, delta);
             nt++;
             PHOTONS *= M_EXP(-tauA);
@@ -439,7 +444,8 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
             tauA = dx * DENS[oind] * M->ABS;
         }
         delta = (tauA > TAULIM) ? (PHOTONS * (1.0f - M_EXP(-tauA))) : (PHOTONS * tauA * (1.0f - 0.5f * tauA));
-        tally(M, M->TABS, oind, delta * M->TW * 1.0f);
+        if ((M->WITH_ALI == 1) && (oind == e_index)) tally(M, M->XAB, oind, delta * M->TW);   /* :1486-1491, :1589-1594 */
+            else tally(M, M->TABS, oind, delta * M->TW * 1.0f);
         if (M->WITH_INT) tally(M, M->INT, oind, delta);
         nt++;
         dx = M_LDEXP_UP(dx, level0);
@@ -664,10 +670,60 @@ static long sim_pb_workitem(const orc_model *M, int id)
     pb_surface_element(M, id, &E);
     for (int III = 0; III < BATCH; III++) {
         pb_create(M, &E, III, &rng, &POS, &DIR, &PHOTONS, &level, &ind);
-        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0);
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0, -1);
         ind = -1;
     }
     return nt;
+}
+
+/* One work item of the USE_EMWEIGHT==2 SimRAM_CL (kernel_ASOC.c:1693-2105): the host lists the emitting
+ * cells in EMINDEX (a cell index 0 is skipped by the "> 0" test, -1 ends the list) and the packet weight of
+ * each cell in EMWEI; 100 packets (EMWEI2_STEP, ASOC.py:79) per listed cell and launch. */
+static long sim_cl2_workitem(const orc_model *M, int id)
+{
+    const int NX = M->NX, NY = M->NY, CELLS = M->CELLS, GLOBAL = M->GLOBAL, LEVELS = M->LEVELS;
+    const int *LCELLS = M->LCELLS, *OFF = M->OFF;
+    int   level = 0, ind, IND = id - GLOBAL, ICELL = -1;
+    float phi, cos_theta, sin_theta, PHOTONS, X0, Y0, Z0, PWEI = 1.0f;
+    f3    DIR, POS;
+    rng_t rng;
+    long  nt = 0;
+    if (id >= CELLS) return 0;
+    seed_workitem(&rng, M->SEED, (uint64_t)id);
+    while (1) {
+        while (1) {
+            IND += GLOBAL;
+            if (IND >= CELLS) return nt;
+            if (M->EMINDEX[IND] < 0) return nt;
+            if (M->EMINDEX[IND] > 0) {
+                ICELL = M->EMINDEX[IND];
+                PWEI  = M->EMWEI[ICELL];
+                break;
+            }
+        }
+        for (int iter = 0; iter < 100; iter++) {
+            ind = ICELL;
+            for (level = 0; level < LEVELS - 1; level++) {
+                ind -= LCELLS[level];
+                if (ind < 0) { ind += LCELLS[level]; break; }
+            }
+            if (level == 0) {
+                X0 = (ind % NX);  Y0 = ((ind / NX) % NY);  Z0 = (ind / (NX * NY));
+            } else {
+                int sid = ind % 8;
+                X0 = (sid % 2);  Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;  Z0 = (sid / 4);
+            }
+            PHOTONS = M->EMIT[OFF[level] + ind] * PWEI;
+            POS.x = X0 + Rand(&rng);  POS.y = Y0 + Rand(&rng);  POS.z = Z0 + Rand(&rng);
+            phi       = TWOPI * Rand(&rng);
+            cos_theta = 0.999997f - 1.999995f * Rand(&rng);
+            sin_theta = M_SQRT(1.0f - cos_theta * cos_theta);
+            DIR.x = sin_theta * M_COS(phi);
+            DIR.y = sin_theta * M_SIN(phi);
+            DIR.z = cos_theta;
+            nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 1, (M->WITH_ALI > 0) ? (OFF[level] + ind) : -1);
+        }
+    }
 }
 
 /* ================================ SimRAM_HP ============================================ */
@@ -775,7 +831,7 @@ static long sim_hp_workitem(const orc_model *M, int id)
             }
         }
         IndexG(M, &POS, &level, &ind);
-        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 2);
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 2, -1);
         ind = -1;
     }
     return nt;
@@ -850,7 +906,7 @@ static long sim_cl_workitem(const orc_model *M, int id)
         DIR.x = sin_theta * M_COS(phi);
         DIR.y = sin_theta * M_SIN(phi);
         DIR.z = cos_theta;
-        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 1);
+        nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 1, (M->WITH_ALI > 0) ? (OFF[level] + ind) : -1);
     }
 }
 
@@ -1315,14 +1371,14 @@ EXPORT long orc_sim(orc_model *M, int kind, int gid0, int gid1, int stride, int 
     if (nthreads <= 1) {
         M->threaded = 0;
         for (int id = gid0; id < gid1; id += stride)
-            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id));
+            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? ((M->USE_EMWEIGHT == 2) ? sim_cl2_workitem(M, id) : sim_cl_workitem(M, id)) : sim_pb_workitem(M, id));
     } else {
         M->threaded = 1;
         const long n = ((long)gid1 - gid0 + stride - 1) / stride;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : total) num_threads(nthreads)
         for (long k = 0; k < n; k++) {
             int id = (int)(gid0 + k * stride);
-            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? sim_cl_workitem(M, id) : sim_pb_workitem(M, id));
+            total += (kind == 2) ? sim_hp_workitem(M, id) : (kind ? ((M->USE_EMWEIGHT == 2) ? sim_cl2_workitem(M, id) : sim_cl_workitem(M, id)) : sim_pb_workitem(M, id));
         }
     }
     return total;

@@ -36,8 +36,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("several dsc files (WITH_MSF)")
     if USER.DO_SPLIT:
         bad.append("split")
-    if USER.WITH_ALI:
-        bad.append("ali")
     if USER.STEP_WEIGHT[0] > 0:
         bad.append("stepweight")
     if USER.DIR_WEIGHT[0] > 0:
@@ -48,8 +46,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("saveint 2 (intensity vectors)")
     if USER.PS_METHOD == 3:
         bad.append("psmethod 3 (does not compile in the reference either)")
-    if USER.USE_EMWEIGHT > 1:
-        bad.append("emweight 2")
     if USER.OPT_IS_HALF:
         bad.append("optishalf")
     if USER.WITH_REFERENCE:
@@ -137,7 +133,7 @@ class AbsorptionRun:
     def setup_engine(self):
         e, c, U = self.eng, self.cloud, self.U
         e.set_cloud(c)
-        e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(U.USE_EMWEIGHT, 1))
+        e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 2))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
         if self.comm:
             self.comm.attach(e, c.CELLS)
@@ -305,11 +301,17 @@ class AbsorptionRun:
             Emin, kE, TTT = launch.temperature_table(FFREQ, self.AFABS[0], U.GL)
             FACTOR_f, LENGTH_f = launch.kernel_literals(U.GL)
         EMWEI = np.ones(CELLS, np.float32) * np.float32(self.CLPAC / CELLS) if U.USE_EMWEIGHT > 0 else None
+        EMPAC = None
+        ali = bool(U.WITH_ALI)
+        if ali:
+            e.set_ali(1)
+        beta = None
         hostrng = np.random.default_rng(int(U.SEED * 2 ** 31) if U.SEED > 0 else None)
         EMIT = np.zeros(CELLS, np.float32)
         for iteration in range(U.ITERATIONS):
             self.log("ITERATION %d/%d" % (iteration + 1, U.ITERATIONS))
             e.zero(0)
+            XEM = np.full(CELLS, 1.0e-32, np.float64) if ali else None      # ASOC.py:1606
             if self.CLPAC > 0:
                 GLOBAL, BATCH = self.GLOBAL_0, max(1, int(self.CLPAC / CELLS))
                 first, count = self.comm.shard(GLOBAL) if self.comm else (0, GLOBAL)
@@ -332,6 +334,8 @@ class AbsorptionRun:
                         a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
                         EMIT[a:b] *= coeff * c.DENS[a:b]
                     EMIT[c.DENS < 1.0e-10] = 0.0
+                    if ali:
+                        XEM += EMIT * np.float64(FF)               # integral of the emitted energy (ASOC.py:1741)
                     if U.USE_EMWEIGHT > 0:                         # ASOC.py:1745-1771
                         skip += 1
                         if skip % U.EMWEIGHT_SKIP == 0:
@@ -342,6 +346,9 @@ class AbsorptionRun:
                             EMWEI[hostrng.random(CELLS) > EMWEI] = 0.0
                             if U.EMWEIGHT_LIM[2] > 0.0:
                                 EMWEI[EMWEI < U.EMWEIGHT_LIM[2]] = 0.0
+                            if U.USE_EMWEIGHT == 2:                # packets per cell in multiples of 100 (ASOC.py:1773-1780)
+                                EMPAC = np.asarray(100 * np.round(tmp / 100), np.int32)
+                                EMWEI[:] = 1.0 / (EMPAC + 1e-10)
                     e.set_emission(EMIT, EMWEI)
                     if U.SEED > 0:
                         seed = float(np.fmod(U.SEED + IFREQ * launch.SEED1, 1.0))      # ASOC.py:1807 (no SEED0 here)
@@ -351,7 +358,23 @@ class AbsorptionRun:
                             seed = self._bcast_seed(seed)
                     self.timers["Tpush"] += time.time() - t0
                     t0 = time.time()
-                    e.sim_cl(2, self.CLPAC, BATCH, seed, FF, GLOBAL, gid_first=first, gid_count=count)
+                    if U.USE_EMWEIGHT == 2 and EMPAC is not None:
+                        # the host lists the cells that still owe packets, 100 per cell and launch (ASOC.py:1811-1840)
+                        EMDONE = np.zeros(CELLS, np.int32)
+                        EMINDEX = np.zeros(CELLS, np.int32)
+                        f2, c2 = self.comm.shard(8192) if self.comm else (0, 8192)
+                        while True:
+                            mm = np.nonzero(EMDONE < EMPAC)[0]
+                            if len(mm) < 1:
+                                break
+                            EMINDEX[:len(mm)] = mm
+                            EMINDEX[len(mm):] = -1
+                            e.set_emindex(EMINDEX)
+                            e.sim_cl(2, self.CLPAC, BATCH, seed, FF, 8192, gid_first=f2, gid_count=c2)
+                            EMDONE[mm] += 100
+                            self.packets += 100 * len(mm)
+                    else:
+                        e.sim_cl(2, self.CLPAC, BATCH, seed, FF, GLOBAL, gid_first=first, gid_count=count)
                     if self.with_int and self.comm:
                         self.comm.all_reduce_tally(e, 1)
                     e.sync()
@@ -361,12 +384,20 @@ class AbsorptionRun:
                         FABSORBED[:, IFREQ] += e.read_tally(1)
                 if self.comm:
                     self.comm.all_reduce_tally(e, 0)
+                    if ali:
+                        self.comm.all_reduce_tally(e, 2)
                 EABS = e.read_tally(0) + CTABS
+                if ali:
+                    beta = (XEM - e.read_tally(2)) / XEM           # escape probability (ASOC.py:1939-1942)
             else:
                 EABS = np.array(CTABS, np.float32)
             if solve:
                 t0 = time.time()
-                TNEW = e.solve_temperature(launch.ADHOC, kE, Emin, TTT, FACTOR_f, LENGTH_f, EABS)
+                if ali:                                            # only the host solve knows beta (ASOC.py:2024, 2056-2057)
+                    TNEW = launch.solve_temperature_host(EABS, c, Emin, kE, TTT, U.GL, beta)
+                    e.set_temperature(np.where(TNEW > 0, TNEW, np.float32(10.0)))
+                else:
+                    TNEW = e.solve_temperature(launch.ADHOC, kE, Emin, TTT, FACTOR_f, LENGTH_f, EABS)
                 EMITTED[:, :] = e.emission(FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], FACTOR_f, LENGTH_f)
                 self.timers["Tsolve"] = self.timers.get("Tsolve", 0.0) + time.time() - t0
         if self.rank == 0 and solve and U.ITERATIONS > 0:

@@ -35,8 +35,9 @@ struct soc_ctx {
     float  ABS = 0.0f, SCA = 0.0f;
     bool   have_optical = false;
     float2 *dOPT = nullptr;
-    float *dEMIT = nullptr, *dEMWEI = nullptr;
-    bool   have_emit = false;
+    float *dEMIT = nullptr, *dEMWEI = nullptr, *dXAB = nullptr;
+    int   *dEMINDEX = nullptr;
+    bool   have_emit = false, have_emindex = false, with_ali = false;
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
     bool   have_hpbg = false, hpbg_weighted = false;
     // tallies
@@ -181,7 +182,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF,
+    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -269,8 +270,8 @@ int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
     FLUSH(c);
     if (!(ps_method == 0 || ps_method == 1 || ps_method == 2 || ps_method == 4 || ps_method == 5))
         return fail(c, SOC_ERR_ARG, "soc_set_features: PS_METHOD %d not supported (0,1,2,4,5)", ps_method);
-    if (use_emweight < 0 || use_emweight > 1)
-        return fail(c, SOC_ERR_ARG, "soc_set_features: USE_EMWEIGHT %d not supported (0,1)", use_emweight);
+    if (use_emweight < 0 || use_emweight > 2)
+        return fail(c, SOC_ERR_ARG, "soc_set_features: USE_EMWEIGHT %d not supported (0,1,2)", use_emweight);
     c->with_int = with_int ? 1 : 0;
     c->ps_method = ps_method;
     c->use_emweight = use_emweight;
@@ -365,10 +366,40 @@ int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
     return SOC_OK;
 }
 
+int soc_set_emindex(soc_ctx *c, const int32_t *EMINDEX)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid || !EMINDEX) return fail(c, SOC_ERR_STATE, "soc_set_emindex: needs a grid and EMINDEX[CELLS]");
+    for (int i = 0; i < c->G.CELLS; i++)
+        if (EMINDEX[i] >= c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_set_emindex: EMINDEX[%d] = %d is not a cell", i, EMINDEX[i]);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->dEMINDEX) HIPCHK(c, dev_alloc(&c->dEMINDEX, (size_t)c->G.CELLS));
+    HIPCHK(c, hipMemcpyAsync(c->dEMINDEX, EMINDEX, (size_t)c->G.CELLS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_emindex = true;
+    return SOC_OK;
+}
+
+int soc_set_ali(soc_ctx *c, int with_ali)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_ali: call soc_set_grid first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (with_ali && !c->dXAB) {
+        HIPCHK(c, dev_alloc(&c->dXAB, (size_t)c->G.CELLS));
+        HIPCHK(c, hipMemset(c->dXAB, 0, (size_t)c->G.CELLS * 4));
+    }
+    c->with_ali = with_ali != 0;
+    return SOC_OK;
+}
+
 static float *tally_buf(soc_ctx *c, int which)
 {
     if (which == SOC_TALLY_TABS) return c->dTABS;
     if (which == SOC_TALLY_INT) return c->dINT;
+    if (which == SOC_TALLY_XAB) return c->with_ali ? c->dXAB : nullptr;
     return nullptr;
 }
 
@@ -381,6 +412,8 @@ int soc_zero(soc_ctx *c, int tag)
     if (!b) return fail(c, SOC_ERR_ARG, "soc_zero: tag %d", tag);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(b, 0, (size_t)c->G.CELLS * 4, c->stream));
+    if (tag == SOC_TALLY_TABS && c->with_ali && c->dXAB)           // ZeroAMC tag 0 clears TABS and XAB (kernel_ASOC_aux.c:664-668)
+        HIPCHK(c, hipMemsetAsync(c->dXAB, 0, (size_t)c->G.CELLS * 4, c->stream));
     return SOC_OK;
 }
 
@@ -406,6 +439,7 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     S.ABS = c->ABS; S.SCA = c->SCA; S.BG = BG; S.TW = TW;
     S.CSC = c->dCSC; S.OPT = c->dOPT;
     S.EMIT = c->dEMIT; S.EMWEI = c->dEMWEI;
+    S.EMINDEX = c->dEMINDEX; S.XAB = nullptr;
     S.HPBG = c->dHPBG; S.HPBGP = c->dHPBGP; S.HPBG_WEIGHTED = c->hpbg_weighted ? 1 : 0;
     S.TABS = c->dTABS; S.INT = c->dINT;
     S.stats = c->dStats;
@@ -596,6 +630,8 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, 0.0f, TW, GLOBAL, gid_first, gid_count);
     S.NO_PS = 1;
+    if (c->use_emweight == 2 && !c->have_emindex) return fail(c, SOC_ERR_STATE, "soc_sim_cl: USE_EMWEIGHT 2 needs soc_set_emindex");
+    if (c->with_ali) S.XAB = c->dXAB;
     HIPCHK(c, soc_launch_sim_cl(c->G, S, V, c->stream));
     return SOC_OK;
 }

@@ -32,6 +32,8 @@ struct SocSim {
     const int    *XPS_NSIDE, *XPS_SIDE;
     const float  *XPS_AREA;
     const float  *EMIT, *EMWEI;
+    const int    *EMINDEX;     /* USE_EMWEIGHT == 2: cells to emit from, -1 terminated        */
+    float        *XAB;         /* WITH_ALI: absorptions in the emitting cell (else NULL)      */
     int    HPBG_WEIGHTED;      /* SimRAM_HP: pixel chosen by cumulative probability       */
     const float  *HPBG, *HPBGP; /* [49152] sky (photons per package), cumulative probability */
     float *TABS, *INT;

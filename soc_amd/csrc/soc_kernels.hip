@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
     w.dens = 0.0f;  w.photons = 0.0f;  w.tau = 0.0f;  w.free_path = 0.0f;  w.scat = 0;
 
     long long ICELL = (long long)id - S.GLOBAL;            // kernel_ASOC.c:1283-1290
+    long long IND = (long long)id - S.GLOBAL;              // USE_EMWEIGHT == 2: position in EMINDEX (:1759)
     int   IRAY = 0, batch = -1;
     float PWEI = 1.0f;
     unsigned int n_pkt = 0;
@@ -173,7 +174,19 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
         const bool nobody_steps = (__ballot(mode == SOC_M_STEP) == 0ull);
         if (soc_service_now(mode == SOC_M_CREATE, nobody_steps)) {
             if (mode == SOC_M_CREATE) {
-                if (IRAY >= batch) {                       // next emitting cell (kernel_ASOC.c:1318-1355)
+                if ((S.USE_EMWEIGHT == 2) && (IRAY >= batch)) {
+                    // the host's list of emitting cells, 100 packets from each (kernel_ASOC.c:1775-1790);
+                    // a listed cell 0 is skipped by the reference's "> 0" test, -1 ends the list
+                    IRAY = 0;
+                    batch = 100;
+                    while (true) {
+                        IND += S.GLOBAL;
+                        if (IND >= G.CELLS) { mode = SOC_M_DONE; break; }
+                        const int e = S.EMINDEX[IND];
+                        if (e < 0) { mode = SOC_M_DONE; break; }
+                        if (e > 0) { ICELL = e;  PWEI = S.EMWEI[e];  break; }
+                    }
+                } else if (IRAY >= batch) {                // next emitting cell (kernel_ASOC.c:1318-1355)
                     IRAY = 0;
                     PWEI = 1.0f;
                     while (true) {
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
                     }
                     w.level   = level;
                     w.ind     = ind;
+                    w.e_index = sOFF[level] + ind;
                     w.dens    = G.DENS[sOFF[level] + ind];
                     w.photons = S.EMIT[sOFF[level] + ind] * PWEI;
                     w.px = X0 + soc_rand(&w.rng);

@@ -242,8 +242,17 @@ struct SocWalker {
     float px, py, pz, ux, uy, uz;
     float photons, free_path, tau, dens;
     int   level, ind, scat;
+    int   e_index = -1;            // WITH_ALI: global index of the emitting cell (kernel_ASOC.c:1394-1396)
     soc_rng_t rng;
     unsigned int n_tally, n_scat;
+
+    // absorbed energy of one step: TABS, or XAB for what the emitting cell absorbs of its own
+    // emission (WITH_ALI, kernel_ASOC.c:1486-1491)
+    __device__ __forceinline__ void deposit(const SocSim &S, int oind, float delta)
+    {
+        if (S.XAB && (oind == e_index)) soc_tally(S.XAB, oind, delta * S.TW);
+        else                            soc_tally(S.TABS, oind, delta * S.TW);
+    }
 
     // after creation: kernel_ASOC.c:508-519
     __device__ __forceinline__ void begin()
@@ -296,7 +305,7 @@ struct SocWalker {
         }
         float e = soc_expf(-tauA);
         float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-        soc_tally(S.TABS, oind, delta * S.TW);
+        deposit(S, oind, delta);
         if (WINT) soc_tally(S.INT, oind, delta);
         n_tally++;
         photons *= e;
@@ -335,7 +344,7 @@ struct SocWalker {
         float tauA = dx * dens * kabs;
         float e = soc_expf(-tauA);
         float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-        soc_tally(S.TABS, oind, delta * S.TW);
+        deposit(S, oind, delta);
         if (WINT) soc_tally(S.INT, oind, delta);
         n_tally++;
         n_scat++;

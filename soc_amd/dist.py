@@ -58,8 +58,12 @@ class Comm:
         """Sum tally `which` over all ranks (result on every rank)."""
         if self.world == 1:
             return
-        if self.backend == "nccl":
+        if self.backend == "nccl" and which in self._tensors:
             self.dist.all_reduce(self._tensors[which])
+        elif self.backend == "nccl":                       # a tally that is not bound to a tensor (XAB): via the host
+            arr = self.torch.from_numpy(np.ascontiguousarray(engine.read_tally(which))).cuda()
+            self.dist.all_reduce(arr)
+            engine.write_tally(which, arr.cpu().numpy())
         else:
             arr = self.torch.from_numpy(np.ascontiguousarray(engine.read_tally(which)))
             self.dist.all_reduce(arr)

@@ -161,6 +161,33 @@ def temperature_table(FFREQ, FABS, GL, NE=NE_TEMPERATURE):
     return Emin, kE, TTT
 
 
+def solve_temperature_host(EABS, cloud, Emin, kE, TTT, GL, beta=None):
+    """The reference's host temperature solve (ASOC.py:2042-2073), vectorised: the only path that takes
+    the escape probability beta of an ALI run.  Its interpolation weight
+    wi = (Emin kE^(iE+1) - E) / (Emin kE^(iE+1) - kE^iE) is kept as written (the device kernel divides by
+    Emin kE^iE (kE-1) instead); cells with density < 1e-10 (parents, empty cells) get 0."""
+    NE = len(TTT)
+    oplgkE = 1.0 / math.log10(kE)
+    scale = (6.62607e-27 * FACTOR) / (GL * PARSEC)
+    T = np.zeros(cloud.CELLS, np.float32)
+    TT = np.asarray(TTT, np.float64)
+    for level in range(cloud.LEVELS):
+        a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+        dens = np.asarray(cloud.DENS[a:b], np.float64)
+        ok = dens >= 1.0e-10
+        Ein = (scale / ADHOC) * np.asarray(EABS[a:b], np.float64)[ok] * (8.0 ** level) / dens[ok]
+        if beta is not None:
+            Ein = Ein / np.asarray(beta[a:b], np.float64)[ok]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            iE = np.clip(np.floor(oplgkE * np.log10(Ein / Emin)), 0, NE - 2)
+        iE = np.nan_to_num(iE, nan=0.0).astype(np.int64)
+        wi = (Emin * kE ** (iE + 1) - Ein) / (Emin * kE ** (iE + 1) - kE ** iE)
+        t = np.zeros(b - a, np.float64)
+        t[ok] = wi * TT[iE] + (1.0 - wi) * TT[iE + 1]
+        T[a:b] = t
+    return T
+
+
 def mirror_mask(MIRROR):
     """`mirror xXyYzZ` -> bit mask of reflecting faces (ASOC.py:319-321)"""
     MIRROR = MIRROR or ""

@@ -13,6 +13,7 @@ LIBNAME = os.path.join(HERE, "libsoc_hip.so")
 
 TALLY_TABS = 0
 TALLY_INT = 1
+TALLY_XAB = 2
 
 _F = C.POINTER(C.c_float)
 _I = C.POINTER(C.c_int32)
@@ -33,6 +34,8 @@ API = {
     "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
     "soc_set_scatter_table": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
     "soc_set_emission": (C.c_int, [C.c_void_p, _F, _F]),
+    "soc_set_emindex": (C.c_int, [C.c_void_p, _I]),
+    "soc_set_ali": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_zero": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_sim_pb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                              _F, _F, C.c_int, _I, _I, _F, C.c_int, C.c_int, C.c_int]),
@@ -207,6 +210,15 @@ class Engine:
         if EMIT.size != self.CELLS or (EMWEI is not None and EMWEI.size != self.CELLS):
             raise SocError("set_emission: arrays must hold CELLS floats")
         self._chk(self.lib.soc_set_emission(self.h, _f(EMIT), _f(EMWEI)))
+
+    def set_emindex(self, EMINDEX):
+        EMINDEX = np.ascontiguousarray(EMINDEX, np.int32)
+        if EMINDEX.size != self.CELLS:
+            raise SocError("set_emindex: EMINDEX must hold CELLS ints")
+        self._chk(self.lib.soc_set_emindex(self.h, _i(EMINDEX)))
+
+    def set_ali(self, with_ali=1):
+        self._chk(self.lib.soc_set_ali(self.h, int(with_ali)))
 
     # ---- launches ----
     def zero(self, tag):

@@ -67,6 +67,16 @@ def _hpjob(cloud, ref_weighted, **kw):
     return Job(cloud, _CSC, ABS=1e-4, SCA=3e-4, HPBG=bg, HPBGP=P, **kw)
 
 
+def _emindex(cloud, n=300, seed=3):
+    """USE_EMWEIGHT==2 inputs: a list of emitting leaf cells (terminated by -1) and packet weights"""
+    rr = np.random.default_rng(seed)
+    pick = rr.choice(np.flatnonzero(cloud.DENS > 0), n, replace=False)
+    EMINDEX = -np.ones(cloud.CELLS, np.int32)
+    EMINDEX[:n] = pick
+    EMWEI = (1.0 / (100 * rr.integers(1, 4, cloud.CELLS) + 1e-10)).astype(np.float32)
+    return EMINDEX, EMWEI
+
+
 CASES = {
     # name: (ref build, kind, job factory); kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_HP
     "bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=50, SEED=0.6004384)),
@@ -105,6 +115,11 @@ CASES = {
     "cl_oct8_mirror": ("oct8mir", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
                                                   EMIT=_emit(_oct8()), MIRROR=6)),
     "hp_c8_mirror": ("c8mir", 2, lambda: _hpjob(_c8(), False, BATCH=6, SEED=0.3, GLOBAL=3072, MIRROR=25)),
+    "cl_oct8_emw2": ("oct8emw2", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=64,
+                                                  EMIT=_emit(_oct8()), EMWEI=_emindex(_oct8())[1], USE_EMWEIGHT=2,
+                                                  EMINDEX=_emindex(_oct8())[0])),
+    "cl_oct8_ali": ("oct8ali", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                EMIT=_emit(_oct8()), WITH_ALI=1)),
     "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
                                      EMIT=_emit(_c8()))),
 }

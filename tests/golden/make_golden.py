@@ -85,6 +85,8 @@ def main():
         out[name + "_TABS"] = T
         if job.WITH_INT:
             out[name + "_INT"] = I
+        if job.WITH_ALI:
+            out[name + "_XAB"] = job.XAB.copy()
         out[name + "_DENS"] = job.DENS          # pins the synthetic-cloud generator as well
         print("%-14s sum(TABS) = %.9e   nonzero cells %d / %d" % (name, T.sum(dtype=np.float64), (T != 0).sum(), T.size))
     np.savez_compressed(os.path.join(HERE, "sims.npz"), **out)

@@ -17,11 +17,13 @@ class OracleEngine:
         self.EMIT = self.EMWEI = None
         self.T = [None, None]
         self.events = 0
+        self.ali = 0
+        self.EMINDEX = None
 
     def set_cloud(self, cloud):
         self.cloud = cloud
         self.CELLS = cloud.CELLS
-        self.T = [np.zeros(cloud.CELLS, np.float32), np.zeros(cloud.CELLS, np.float32)]
+        self.T = [np.zeros(cloud.CELLS, np.float32), np.zeros(cloud.CELLS, np.float32), np.zeros(cloud.CELLS, np.float32)]
 
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self.feat = dict(with_int=with_int, ps_method=ps_method, use_emweight=use_emweight)
@@ -43,6 +45,14 @@ class OracleEngine:
 
     def zero(self, tag):
         self.T[tag][:] = 0
+        if tag == 0:
+            self.T[2][:] = 0
+
+    def set_ali(self, with_ali=1):
+        self.ali = int(with_ali)
+
+    def set_emindex(self, EMINDEX):
+        self.EMINDEX = np.asarray(EMINDEX, np.int32).copy()
 
     def bind_tally(self, which, ptr):
         raise NotImplementedError
@@ -76,6 +86,7 @@ class OracleEngine:
 
     def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
         job = self._job(SOURCE, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
+        job.WITH_ALI, job.XAB, job.EMINDEX = self.ali, self.T[2], self.EMINDEX
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
         _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n

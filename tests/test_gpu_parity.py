@@ -109,6 +109,8 @@ def test_simulation_vs_oracle(name, engine, oracle_soc):
         assert_tally_close(Ig, I, rtol=1e-5)
     else:
         assert not Ig.any()
+    if job.WITH_ALI:
+        assert_tally_close(job.XAB_gpu, job.XAB, rtol=1e-5)      # job.XAB was filled by the oracle run above
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))

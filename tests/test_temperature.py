@@ -131,3 +131,54 @@ def test_iteration_loop_end_to_end(engine, tmp_path):
     leaf = cloud.DENS > 0
     assert np.abs(got.TNEW[leaf] / want.TNEW[leaf] - 1).max() < 2e-5
     assert np.allclose(got.EMITTED[leaf], want.EMITTED[leaf], rtol=2e-3)
+
+
+def _iter_ini(d, cloud, extra):
+    from test_host import _write_model
+    ini = _write_model(d, cloud, extra="noabsorbed\niterations 2\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (d, d) + extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    return ini
+
+
+def test_emweight2_and_ali_iterations_on_oracle_engine(tmp_path):
+    """host loops of USE_EMWEIGHT==2 (EMINDEX lists, 100 packets per cell and launch, ASOC.py:1811-1840) and of
+    ALI (XEM, escape probability, host temperature solve with beta, ASOC.py:1606,1741,1939-1942,2042-2073)"""
+    from oracle_engine import OracleEngine
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(5, seed=2)
+    os.chdir(d)
+    # EMWEIGHT 2: every cell emits a multiple of 100 packets; energy is conserved against the plain run
+    runs = {}
+    for key, extra in (("plain", "cellpackets %d\n" % (200 * cloud.CELLS)),
+                       ("emw2", "cellpackets %d\nemweight 2\n" % (200 * cloud.CELLS))):
+        if os.path.exists(os.path.join(d, "em.bin")):
+            os.remove(os.path.join(d, "em.bin"))
+        eng = OracleEngine("soc")
+        run = AbsorptionRun(User(_iter_ini(d, cloud, extra)), eng, verbose=0)
+        run.run()
+        runs[key] = run
+    a, b = runs["plain"].TNEW, runs["emw2"].TNEW
+    assert np.abs(b / a - 1).max() < 0.05 and not np.array_equal(a, b)
+    # ALI: same energy budget, temperatures from the host solve with the escape probability
+    os.remove(os.path.join(d, "em.bin"))
+    eng = OracleEngine("soc")
+    run = AbsorptionRun(User(_iter_ini(d, cloud, "cellpackets %d\nali 1\n" % (20 * cloud.CELLS))), eng, verbose=0)
+    run.run()
+    assert eng.ali == 1 and eng.T[2].sum() > 0                      # XAB was tallied
+    # self-absorbed emission is taken out of the budget and the solve divides by the escape probability:
+    # in this opaque toy model the temperatures come out higher than without ALI
+    assert (run.TNEW > a).all() and np.abs(run.TNEW / a - 1).max() < 0.4
+
+
+def test_host_temperature_solve_matches_device_formula_away_from_its_quirk():
+    """launch.solve_temperature_host (the reference's host loop) lands within one table step of the device kernel"""
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    Emin, kE, TTT = launch.temperature_table(FF, FABS, GL, NE=3000)
+    FACTOR, LENGTH = launch.kernel_literals(GL)
+    EABS, _ = _absorbed(o8, Emin, kE, TTT, FACTOR, LENGTH)
+    Th = launch.solve_temperature_host(EABS, o8, Emin, kE, TTT, GL)
+    Td = Oracle("soc").eqtemp(Job(o8, np.linspace(1, -1, 8)), 1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
+    leaf = o8.DENS > 0
+    assert (Th[~leaf] == 0).all()
+    assert np.abs(Th[leaf] - Td[leaf]).max() < 1.2 * np.diff(TTT).max()

@@ -27,9 +27,17 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
         eng.sim_hp(job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
     else:
         eng.set_emission(job.EMIT, job.EMWEI)
+        eng.set_ali(job.WITH_ALI)
+        if job.WITH_ALI:
+            eng.zero(0)                                  # clears XAB together with TABS
+        if job.EMINDEX is not None:
+            eng.set_emindex(job.EMINDEX)
         eng.sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL,
                    gid_first=gid_first, gid_count=gid_count)
     eng.sync()
+    if kind == 1 and job.WITH_ALI:
+        job.XAB_gpu = eng.read_tally(2)
+        eng.set_ali(0)
     return eng.read_tally(0), eng.read_tally(1), eng.stats()
 
 
