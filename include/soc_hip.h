@@ -224,6 +224,19 @@ int soc_set_temperature(soc_ctx *ctx, const float *T);
  * temperatures, for the nfreq frequencies FREQ with absorption cross sections FABS */
 int soc_emission(soc_ctx *ctx, int nfreq, const float *FREQ, const float *FABS, float FACTOR, float LENGTH, float *EMITTED);
 
+/* ---- map making ---- */
+
+/* replaces the kernel_map launch + copies (ASOC.py:3113-3128 -> Mapping / HealpixMapping, kernel_ASOC_map.c:496-516,
+ * 890-910): line-of-sight integral of EMIT[CELLS] (x density, with extinction ABS+SCA or the per-cell OPT of soc_set_opt)
+ * for one map.  healpix = 0: orthographic map of NPIX_X x NPIX_Y pixels of MAP_DX root cells towards DIR with image axes
+ * RA (right), DE (up) through CENTRE -- or, with INTOBS given (INTOBS[0] > -1e10), the longitude x latitude image seen
+ * from that position; healpix = 1: Healpix map of NSIDE = NPIX_X seen from INTOBS.  MAP gets the surface brightness
+ * integral, SAVETAU the optical depth or (save_colden) column density x LENGTH.  MAP_INTERPOLATION, ROI_MAP,
+ * LEVEL_THRESHOLD and polarisation maps are not covered. */
+int soc_map(soc_ctx *ctx, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const float *EMIT, const float *DIR,
+            const float *RA, const float *DE, const float *CENTRE, const float *INTOBS, float ABS, float SCA,
+            int save_colden, float LENGTH, float *MAP, float *SAVETAU);
+
 /* ---- stochastically heated grains: A2E.py / kernel_A2E.c ---- */
 
 /* replaces the per-size uploads of A2E.py:338-371 (AF, Iw, L1, L2, Tdown, EA, Ibeg) and the

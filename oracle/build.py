@@ -171,6 +171,48 @@ def build_ref_sca(tag, force=False, **model):
     return so
 
 
+def build_ref_map(tag, force=False, NSIDE=8, **model):
+    """kernel_ASOC_map.c for one model -> oracle/_ref/refmap_<tag>.so (the -D list of ASOC.py:344-362 plus
+    -D NSIDE=<NPIX.x>, ASOC.py:2934)"""
+    so = os.path.join(REF_DIR, "refmap_%s.so" % tag)
+    ksrc = os.path.join(REFERENCE, "kernel_ASOC_map.c")
+    if not os.path.exists(ksrc):
+        return so if os.path.exists(so) else None
+    os.makedirs(REF_DIR, exist_ok=True)
+    drv = os.path.join(HERE, "ref_map.cpp")
+    defs = [d for d in ref_defs(**model) if not d.startswith("-DNSIDE=")] + ["-DNSIDE=%d" % NSIDE]
+    stamp = so + ".defs"
+    if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
+            and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
+        return so
+    kobj = os.path.join(REF_DIR, "kmap_%s.o" % tag)
+    sobj = os.path.join(REF_DIR, "dmap_%s.o" % tag)
+    common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
+    subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header", "-ftrivial-auto-var-init=zero",
+                           "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
+    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    os.remove(kobj)
+    os.remove(sobj)
+    with open(stamp, "w") as fp:
+        fp.write(" ".join(defs))
+    return so
+
+
+def map_ref_models():
+    sys.path.insert(0, REPO)
+    from soc_amd import synth
+    oct8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    oct104 = synth.octree_cloud(104, levels=3, frac=0.002, seed=11)
+    return {
+        "c8": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512),
+        "c8abu": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ABU=1),
+        "oct8": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
+        "oct104": dict(NX=104, NY=104, NZ=104, LEVELS=oct104.LEVELS, CELLS=oct104.CELLS),
+        "c208": dict(NX=208, NY=208, NZ=208, LEVELS=1, CELLS=208 ** 3),
+    }
+
+
 def sca_ref_models():
     sys.path.insert(0, REPO)
     from soc_amd import synth
@@ -235,6 +277,8 @@ def build_all_refs(force=False):
     out = {}
     for tag, model in ref_models().items():
         out[tag] = build_ref(tag, force=force, **model)
+    for tag, model in map_ref_models().items():
+        out["map_" + tag] = build_ref_map(tag, force=force, **model)
     for tag, model in a2e_ref_models().items():
         out["a2e_" + tag] = build_ref_a2e(tag, force=force, **model)
     for tag, model in sca_ref_models().items():

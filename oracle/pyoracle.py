@@ -573,3 +573,75 @@ class RefSca:
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sca_sim(C.byref(a), kind, gid0, gid1, stride)
         return OUT
+
+
+# ---------------------------------------------------------------------------------------
+# map making (kernel_ASOC_map.c)
+# ---------------------------------------------------------------------------------------
+
+class MArgs(C.Structure):
+    _fields_ = [("NPIX_X", C.c_int), ("NPIX_Y", C.c_int), ("SAVE_COLDEN", C.c_int), ("healpix", C.c_int),
+                ("MAP_DX", C.c_float), ("ABS", C.c_float), ("SCA", C.c_float),
+                ("DIR", C.c_float * 4), ("RA", C.c_float * 4), ("DE", C.c_float * 4), ("CENTRE", C.c_float * 4),
+                ("INTOBS", C.c_float * 4),
+                ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
+                ("DENS", _F), ("EMIT", _F), ("OPT", _F), ("MAP", _F), ("SAVETAU", _F)]
+
+
+NO_INTOBS = (-1.0e12, 0.0, 0.0)
+
+
+def oracle_mapping(orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, INTOBS=NO_INTOBS, save_colden=0, LENGTH=1.0, healpix=0):
+    """Mapping (healpix=0: NPIX = (x, y)) or HealpixMapping (healpix=NSIDE).  Returns (MAP, SAVETAU)."""
+    L = orc.lib
+    L.orc_mapping.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_float, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_float, _F, _F]
+    m = orc._model(job)
+    nx, ny = (healpix, 1) if healpix else (int(NPIX[0]), int(NPIX[1]))
+    n = 12 * healpix * healpix if healpix else nx * ny
+    MAP, TAU = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    v = [np.ascontiguousarray(np.asarray(a, np.float32).ravel()[:3]) for a in (DIR, RA, DE, CENTRE, INTOBS)]
+    EMIT = np.ascontiguousarray(EMIT, np.float32)
+    L.orc_mapping(C.byref(m), int(bool(healpix)), np.float32(MAP_DX), nx, ny, _fp(EMIT), _fp(v[0]), _fp(v[1]), _fp(v[2]), _fp(v[3]),
+                  _fp(v[4]), int(save_colden), np.float32(LENGTH), _fp(MAP), _fp(TAU))
+    return MAP, TAU
+
+
+class RefMap:
+    """x86 build of kernel_ASOC_map.c for one model: oracle/_ref/refmap_<tag>.so"""
+
+    def __init__(self, tag, NSIDE=8):
+        self.model = _build.map_ref_models()[tag]
+        self.tag = tag if NSIDE == 8 else "%s_n%d" % (tag, NSIDE)
+        path = _build.build_ref_map(self.tag, NSIDE=NSIDE, **self.model)
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("reference build map %s not available" % tag)
+        self.lib = C.CDLL(path)
+        self.lib.ref_map.argtypes = [C.POINTER(MArgs), C.c_int]
+        self.NSIDE = NSIDE
+
+    @staticmethod
+    def available(tag):
+        try:
+            RefMap(tag)
+            return True
+        except (FileNotFoundError, OSError, KeyError):
+            return False
+
+    def mapping(self, job, PAR, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, INTOBS=NO_INTOBS, save_colden=0, healpix=0):
+        a = MArgs()
+        nx, ny = (healpix, 1) if healpix else (int(NPIX[0]), int(NPIX[1]))
+        n = 12 * healpix * healpix if healpix else nx * ny
+        assert (not healpix) or healpix == self.NSIDE
+        MAP, TAU = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        EMIT = np.ascontiguousarray(EMIT, np.float32)
+        a.NPIX_X, a.NPIX_Y, a.SAVE_COLDEN, a.healpix = nx, ny, int(save_colden), int(bool(healpix))
+        a.MAP_DX, a.ABS, a.SCA = np.float32(MAP_DX), job.ABS, job.SCA
+        for name, val in (("DIR", DIR), ("RA", RA), ("DE", DE), ("CENTRE", CENTRE), ("INTOBS", INTOBS)):
+            arr = getattr(a, name)
+            for k in range(3):
+                arr[k] = float(np.float32(np.asarray(val).ravel()[k]))
+        a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
+        a.DENS, a.EMIT, a.MAP, a.SAVETAU = _fp(job.DENS), _fp(EMIT), _fp(MAP), _fp(TAU)
+        a.OPT = _fp(job.OPT) if job.OPT is not None else None
+        self.lib.ref_map(C.byref(a), n)
+        return MAP, TAU

@@ -1267,6 +1267,159 @@ static long sim_sca_hp_workitem(const orc_model *M, int id)
     return n;
 }
 
+/* ================================ map making (kernel_ASOC_map.c) ======================== */
+/* The map file carries its own copies of the traversal: PEPS = 5e-4, EPS = 2.5e-4 (:10-11), Index() in
+ * double for NX > 100 whatever LEVELS (:297-301) and with the climb test of :345. */
+#define PEPS_MAP 5.0e-4f
+#define EPS_MAP  2.5e-4f
+
+#define INDEX_MAP_VARIANT
+#define REAL float
+#define RFLOOR(x) M_FLOOR(x)
+#define RFMOD1(x) M_FMOD1(x)
+#define INDEX_NAME IndexMap_f
+#include "soc_oracle_index.inc"
+#undef REAL
+#undef RFLOOR
+#undef RFMOD1
+#undef INDEX_NAME
+#define REAL double
+#define RFLOOR(x) floor(x)
+#define RFMOD1(x) M_FMOD1D(x)
+#define INDEX_NAME IndexMap_d
+#include "soc_oracle_index.inc"
+#undef REAL
+#undef RFLOOR
+#undef RFMOD1
+#undef INDEX_NAME
+#undef INDEX_MAP_VARIANT
+
+static float GetStepMap(const orc_model *M, f3 *POS, const f3 *DIR, int *level, int *ind)
+{
+    float dx, dy, dz;
+    dx = (DIR->x > 0.0f) ? ((1.0f + PEPS_MAP - M_FMOD1(POS->x)) / DIR->x) : ((-PEPS_MAP - M_FMOD1(POS->x)) / DIR->x);
+    dy = (DIR->y > 0.0f) ? ((1.0f + PEPS_MAP - M_FMOD1(POS->y)) / DIR->y) : ((-PEPS_MAP - M_FMOD1(POS->y)) / DIR->y);
+    dz = (DIR->z > 0.0f) ? ((1.0f + PEPS_MAP - M_FMOD1(POS->z)) / DIR->z) : ((-PEPS_MAP - M_FMOD1(POS->z)) / DIR->z);
+    dx = fminf(dx, fminf(dy, dz));
+    POS->x += dx * DIR->x;
+    POS->y += dx * DIR->y;
+    POS->z += dx * DIR->z;
+    dx = M_LDEXP_DN(dx, *level);
+    if (M->NX > 100) IndexMap_d(M, POS, level, ind);
+    else             IndexMap_f(M, POS, level, ind);
+    return dx;
+}
+
+static int map_outside(const orc_model *M, f3 T)
+{
+    return (T.x < 0.0f) || (T.x > M->NX) || (T.y < 0.0f) || (T.y > M->NY) || (T.z < 0.0f) || (T.z > M->NZ);
+}
+
+/* Mapping (kernel_ASOC_map.c:496-888; MAP_INTERPOLATION 0, no ROI_MAP, no LEVEL_THRESHOLD): line-of-sight
+ * integral of the emission with extinction for the pixels of an orthographic map, or of an all-sky
+ * (longitude x latitude) image seen from INTOBS when INTOBS[0] > -1e10.  One call = all pixels.
+ * mode 1: HealpixMapping (:890-970), NSIDE = NPIX_X, seen from INTOBS. */
+__attribute__((visibility("default"))) void orc_mapping(const orc_model *M, int mode, float MAP_DX, int NPIX_X, int NPIX_Y, const float *EMIT, const float *DIRv,
+                        const float *RAv, const float *DEv, const float *CENTREv, const float *INTOBSv, int SAVE_COLDEN,
+                        float LENGTH, float *MAP, float *SAVETAU)
+{
+    const int NX = M->NX, NY = M->NY, NZ = M->NZ;
+    const f3 DIR = { DIRv[0], DIRv[1], DIRv[2] }, RA = { RAv[0], RAv[1], RAv[2] }, DE = { DEv[0], DEv[1], DEv[2] };
+    const f3 CENTRE = { CENTREv[0], CENTREv[1], CENTREv[2] }, INTOBS = { INTOBSv[0], INTOBSv[1], INTOBSv[2] };
+    const int npix = mode ? 12 * NPIX_X * NPIX_X : NPIX_X * NPIX_Y;
+    for (int id = 0; id < npix; id++) {
+        float DTAU, TAU = 0.0f, PHOTONS = 0.0f, colden = 0.0f, sx, sy, sz, dens, emit;
+        f3    POS, TMP;
+        int   ind, level = 0, oind;
+        const int i = mode ? 0 : id % NPIX_X, j = mode ? 0 : id / NPIX_X;
+        if (mode) {
+            float phi, theta;
+            pixel2angles_ring(NPIX_X, id, &phi, &theta);
+            TMP.x = -M_SIN(theta) * M_COS(phi);
+            TMP.y = -M_SIN(theta) * M_SIN(phi);
+            TMP.z = +M_COS(theta);
+            if (fabsf(TMP.x) < 1.0e-5f) TMP.x = 1.0e-5f;
+            if (fabsf(TMP.y) < 1.0e-5f) TMP.y = 1.0e-5f;
+            if (fabsf(TMP.z) < 1.0e-5f) TMP.z = 1.0e-5f;
+            POS = INTOBS;
+            if ((M_FMOD1(POS.x) < 1.0e-5f) || (M_FMOD1(POS.x) < 0.99999f)) POS.x += 2.0e-5f;      /* :923-925, as written */
+            if ((M_FMOD1(POS.y) < 1.0e-5f) || (M_FMOD1(POS.y) < 0.99999f)) POS.y += 2.0e-5f;
+            if ((M_FMOD1(POS.z) < 1.0e-5f) || (M_FMOD1(POS.z) < 0.99999f)) POS.z += 2.0e-5f;
+        } else if (INTOBS.x > -1e10f) {
+            float phi = TWOPI * i / (float)(NPIX_X);
+            phi += PI_F;
+            const float pix = TWOPI / NPIX_X;
+            const float theta = pix * (j - (NPIX_Y - 1) / 2);
+            POS = INTOBS;
+            TMP.x = M_COS(theta) * M_COS(phi);
+            TMP.y = M_COS(theta) * M_SIN(phi);
+            TMP.z = M_SIN(theta);
+            if (fabsf(TMP.x) < 1.0e-5f) TMP.x = 1.0e-5f;
+            if (fabsf(TMP.y) < 1.0e-5f) TMP.y = 1.0e-5f;
+            if (fabsf(TMP.z) < 1.0e-5f) TMP.z = 1.0e-5f;
+            if (M_FMOD1(POS.x) < 1.0e-5f) POS.x += 2.0e-5f;
+            if (M_FMOD1(POS.y) < 1.0e-5f) POS.y += 2.0e-5f;
+            if (M_FMOD1(POS.z) < 1.0e-5f) POS.z += 2.0e-5f;
+        } else {
+            POS.x = CENTRE.x + (i - 0.5f * (NPIX_X - 1)) * MAP_DX * RA.x + (j - 0.5f * (NPIX_Y - 1)) * MAP_DX * DE.x;
+            POS.y = CENTRE.y + (i - 0.5f * (NPIX_X - 1)) * MAP_DX * RA.y + (j - 0.5f * (NPIX_Y - 1)) * MAP_DX * DE.y;
+            POS.z = CENTRE.z + (i - 0.5f * (NPIX_X - 1)) * MAP_DX * RA.z + (j - 0.5f * (NPIX_Y - 1)) * MAP_DX * DE.z;
+            POS.x += (NX + NY + NZ) * DIR.x;  POS.y += (NX + NY + NZ) * DIR.y;  POS.z += (NX + NY + NZ) * DIR.z;
+            if (NX < 200) {
+                if (DIR.x >= 0.0f) sx = (NX - POS.x) / (-DIR.x) + EPS_MAP;  else sx = (0.0f - POS.x) / (-DIR.x) + EPS_MAP;
+                if (DIR.y >= 0.0f) sy = (NY - POS.y) / (-DIR.y) + EPS_MAP;  else sy = (0.0f - POS.y) / (-DIR.y) + EPS_MAP;
+                if (DIR.z >= 0.0f) sz = (NZ - POS.z) / (-DIR.z) + EPS_MAP;  else sz = (0.0f - POS.z) / (-DIR.z) + EPS_MAP;
+                TMP.x = POS.x - sx * DIR.x;  TMP.y = POS.y - sx * DIR.y;  TMP.z = POS.z - sx * DIR.z;
+                if (map_outside(M, TMP)) sx = 1e10f;
+                TMP.x = POS.x - sy * DIR.x;  TMP.y = POS.y - sy * DIR.y;  TMP.z = POS.z - sy * DIR.z;
+                if (map_outside(M, TMP)) sy = 1e10f;
+                TMP.x = POS.x - sz * DIR.x;  TMP.y = POS.y - sz * DIR.y;  TMP.z = POS.z - sz * DIR.z;
+                if (map_outside(M, TMP)) sz = 1e10f;
+                sx = fminf(sx, fminf(sy, sz));
+                POS.x = POS.x - sx * DIR.x;  POS.y = POS.y - sx * DIR.y;  POS.z = POS.z - sx * DIR.z;
+            } else {
+                const float ex = (DIR.x > 0.0f) ? (-EPS_MAP) : (+EPS_MAP), ey = (DIR.y > 0.0f) ? (-EPS_MAP) : (+EPS_MAP),
+                            ez = (DIR.z > 0.0f) ? (-EPS_MAP) : (+EPS_MAP);
+                if (DIR.x >= 0.0f) sx = (NX - POS.x) / (-DIR.x);  else sx = (0.0f - POS.x) / (-DIR.x);
+                if (DIR.y >= 0.0f) sy = (NY - POS.y) / (-DIR.y);  else sy = (0.0f - POS.y) / (-DIR.y);
+                if (DIR.z >= 0.0f) sz = (NZ - POS.z) / (-DIR.z);  else sz = (0.0f - POS.z) / (-DIR.z);
+                TMP.x = POS.x - sx * DIR.x;  TMP.y = POS.y - sx * DIR.y;  TMP.z = POS.z - sx * DIR.z;
+                TMP.x += ex;  TMP.y += ey;  TMP.z += ez;
+                if (map_outside(M, TMP)) sx = 1e10f;
+                TMP.x = POS.x - sy * DIR.x;  TMP.y = POS.y - sy * DIR.y;  TMP.z = POS.z - sy * DIR.z;
+                TMP.x += ex;  TMP.y += ey;  TMP.z += ez;
+                if (map_outside(M, TMP)) sy = 1e10f;
+                TMP.x = POS.x - sz * DIR.x;  TMP.y = POS.y - sz * DIR.y;  TMP.z = POS.z - sz * DIR.z;
+                TMP.x += ex;  TMP.y += ey;  TMP.z += ez;
+                if (map_outside(M, TMP)) sz = 1e10f;
+                sx = fminf(sx, fminf(sy, sz));
+                POS.x = POS.x - sx * DIR.x;  POS.y = POS.y - sx * DIR.y;  POS.z = POS.z - sx * DIR.z;
+                POS.x += ex;  POS.y += ey;  POS.z += ez;
+            }
+            TMP.x = -DIR.x;  TMP.y = -DIR.y;  TMP.z = -DIR.z;
+            if (fabsf(TMP.x) < 1.0e-5f) TMP.x = 1.0e-5f;
+            if (fabsf(TMP.y) < 1.0e-5f) TMP.y = 1.0e-5f;
+            if (fabsf(TMP.z) < 1.0e-5f) TMP.z = 1.0e-5f;
+        }
+        IndexG(M, &POS, &level, &ind);
+        while (ind >= 0) {
+            oind = M->OFF[level] + ind;
+            sx   = GetStepMap(M, &POS, &TMP, &level, &ind);
+            dens = M->DENS[oind];
+            emit = EMIT[oind];
+            if (M->WITH_ABU) DTAU = sx * dens * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
+            else             DTAU = sx * dens * (M->SCA + M->ABS);
+            if (DTAU < 1.0e-3f) PHOTONS += M_EXP(-TAU) * (1.0f - 0.5f * DTAU) * sx * emit * dens;
+            else                PHOTONS += M_EXP(-TAU) * ((1.0f - M_EXP(-DTAU)) / DTAU) * sx * emit * dens;
+            TAU += DTAU;
+            if (mode || (SAVE_COLDEN > 0)) colden += sx * dens;
+        }
+        MAP[id] = PHOTONS;
+        if (SAVE_COLDEN) SAVETAU[id] = colden * LENGTH;
+        else             SAVETAU[id] = TAU;
+    }
+}
+
 /* ================================ exported API ========================================= */
 
 #define EXPORT __attribute__((visibility("default")))

@@ -406,6 +406,58 @@ class AbsorptionRun:
             files.write_emitted(U.file_emitted, EMITTED)
         return TNEW, EMITTED
 
+    # ---------------------------------------------------------------------------------
+    def write_maps(self, EMITTED):
+        """Surface-brightness maps from the emission (ASOC.py:2924-3177, the plain `Mapping` path): for every
+        direction map_dir_XX.bin = int32 NPIX.x, NPIX.y + one float32 [NPIX.y, NPIX.x] image [Jy/sr] per selected
+        frequency.  `perspective` gives the longitude x latitude image seen from that position.  Optical-depth
+        images for `savetau` frequencies are written as <file>_tau_<um>.bin.  FITS containers, Healpix maps
+        (NPIX.y <= 0), map interpolation, ROI maps and polarisation maps are not produced."""
+        U, e, c = self.U, self.eng, self.cloud
+        if U.NPIX[1] <= 0:
+            raise UnsupportedOption("Healpix emission maps (mapping with NPIX.y <= 0)")
+        NFREQ, FFREQ = self.NFREQ, self.FFREQ
+        m = np.nonzero((FFREQ >= U.REMIT_F[0]) & (FFREQ <= U.REMIT_F[1]))[0]
+        I1, I2 = int(m[0]), int(m[-1])
+        NDIR, ODIR, RA, DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+        centre = U.MAPCENTRE if U.MAPCENTRE[0] > -1e7 else (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)   # ASOC_aux.py:791-793
+        KK = (1.0e23 / launch.FACTOR) * PLANCK / (4.0 * np.pi) * (U.GL * PARSEC)                 # ASOC.py:2997-2998
+        _, LENGTH_f = launch.kernel_literals(U.GL)
+        fps = []
+        if self.rank == 0:
+            for idir in range(NDIR):
+                fp = open("map_dir_%02d.bin" % idir, "wb")
+                np.asarray([U.NPIX[0], U.NPIX[1]], np.int32).tofile(fp)
+                fps.append(fp)
+        singles = np.asarray(getattr(U, "SINGLE_MAP_FREQ", []), np.float64)
+        savetau = np.asarray(getattr(U, "savetau_freq", []), np.float64)
+        for IFREQ in range(NFREQ):
+            FREQ = float(FFREQ[IFREQ])
+            save_spe = (IFREQ >= I1) and (IFREQ <= I2)
+            if (FREQ < U.MAP_FREQ[0]) or (FREQ > U.MAP_FREQ[1]):
+                continue
+            save_tau = int(len(savetau) > 0 and np.min(np.abs((savetau - FREQ) / FREQ)) < 0.001)
+            if len(singles) > 0 and np.min(np.abs(FREQ - singles)) / FREQ > 0.005:
+                save_spe = False
+            if not save_spe and not save_tau:
+                continue
+            ABS, SCA = self._optical_for(IFREQ)
+            EMIT = np.asarray(KK * FREQ * EMITTED[:, IFREQ - I1], np.float32) if save_spe else np.zeros(c.CELLS, np.float32)
+            um = launch.C_LIGHT / FREQ * 1.0e4
+            ums = '%.0f' % um if um > 20.0 else ('%.1f' % um if um > 2.0 else '%.2f' % um)
+            for idir in range(NDIR):
+                MAP, TAU = e.map(EMIT, ODIR[idir], RA[idir], DE[idir], U.NPIX, U.MAP_DX, centre, ABS, SCA,
+                                 INTOBS=U.INTOBS, save_colden=0, LENGTH=LENGTH_f)
+                if self.rank != 0:
+                    continue
+                if save_spe:
+                    np.asarray(MAP, np.float32).tofile(fps[idir])
+                if save_tau:
+                    name = '%s_tau_%s.bin' % (U.file_savetau, ums) if NDIR == 1 else '%s_tau_%s_dir%d_%03d.bin' % (U.file_savetau, ums, idir, idir)
+                    np.asarray(TAU, np.float32).tofile(name)
+        for fp in fps:
+            fp.close()
+
     def _bcast_seed(self, seed):
         t = self.comm.torch.tensor([seed], dtype=self.comm.torch.float64,
                                    device="cuda" if self.comm.backend == "nccl" else "cpu")
@@ -422,6 +474,8 @@ class AbsorptionRun:
         self.TNEW, self.EMITTED = None, None
         if U.ITERATIONS > 0 and (self.CLPAC > 0 or ((not U.NOSOLVE) and U.NOABSORBED)) and hasattr(self.eng, "solve_temperature"):
             self.TNEW, self.EMITTED = self.emission_iterations(CTABS, FABSORBED)
+        if (not U.NOMAP) and self.EMITTED is not None and hasattr(self.eng, "map"):
+            self.write_maps(self.EMITTED)
         if self.rank == 0:
             if len(U.file_constant_save) > 0:
                 CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+
 struct soc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -68,6 +69,9 @@ struct soc_ctx {
     int    ttt_cap = 0, ef_cap = 0;
     size_t ebuf_cap = 0;
     bool   have_T = false;
+    // map making (soc_map.hip)
+    float *dMapEmit = nullptr, *dMap = nullptr, *dMapTau = nullptr;
+    size_t map_cap = 0, mapemit_cap = 0;
     // A2E
     int a2e_NE = 0, a2e_NFREQ = 0, a2e_npair = 0, a2e_cap = 0, a2e_noIw = 0;
     float *aIw = nullptr, *aTdown = nullptr, *aEA = nullptr, *aAF = nullptr, *aABS = nullptr, *aEMIT = nullptr;
@@ -182,7 +186,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF,
+    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -256,6 +260,11 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
         if (c->own_INT || !c->dINT) { c->dINT = nullptr; HIPCHK(c, dev_alloc(&c->dINT, (size_t)cells)); c->own_INT = true; HIPCHK(c, hipMemset(c->dINT, 0, (size_t)cells * 4)); }
         if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
         c->have_emit = false;
+        // everything else that is sized by the cell count
+        if (c->dT) { (void)hipFree(c->dT); c->dT = nullptr; }
+        if (c->dXAB) { (void)hipFree(c->dXAB); c->dXAB = nullptr; }
+        if (c->dEMINDEX) { (void)hipFree(c->dEMINDEX); c->dEMINDEX = nullptr; }
+        c->have_T = false;  c->with_ali = false;  c->have_emindex = false;
     }
     c->G = G;
     c->have_grid = true;
@@ -1014,6 +1023,58 @@ int soc_emission(soc_ctx *c, int nfreq, const float *FREQ, const float *FABS, fl
         HIPCHK(c, hipMemcpyAsync(EMITTED + (size_t)a * nfreq, c->dEbuf, (size_t)(b - a) * nfreq * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return SOC_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// map making (ASOC.py:2924-3177 -> kernel_ASOC_map.c Mapping / HealpixMapping)
+// ------------------------------------------------------------------------------------
+
+int soc_map(soc_ctx *c, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const float *EMIT, const float *DIR, const float *RA,
+            const float *DE, const float *CENTRE, const float *INTOBS, float ABS, float SCA, int save_colden, float LENGTH,
+            float *MAP, float *SAVETAU)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_map: call soc_set_grid first");
+    if (!EMIT || !MAP || !SAVETAU) return fail(c, SOC_ERR_ARG, "soc_map: EMIT, MAP and SAVETAU are needed");
+    const bool inside = INTOBS && INTOBS[0] > -1e10f;
+    if (healpix) {
+        if (NPIX_X < 1 || NPIX_X > 8192 || !inside) return fail(c, SOC_ERR_ARG, "soc_map: Healpix maps need NSIDE (NPIX_X) and an observer position");
+    } else {
+        if (NPIX_X < 1 || NPIX_Y < 1 || (int64_t)NPIX_X * NPIX_Y > 2147483647LL) return fail(c, SOC_ERR_ARG, "soc_map: NPIX %d x %d", NPIX_X, NPIX_Y);
+        if (!inside && (!DIR || !RA || !DE || !CENTRE || !(MAP_DX > 0.0f))) return fail(c, SOC_ERR_ARG, "soc_map: DIR, RA, DE, CENTRE and MAP_DX > 0 are needed");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = healpix ? (size_t)12 * NPIX_X * NPIX_X : (size_t)NPIX_X * NPIX_Y;
+    const size_t cells = (size_t)c->G.CELLS;
+    if (c->mapemit_cap < cells) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dMapEmit, cells));
+        c->mapemit_cap = cells;
+    }
+    if (c->map_cap < npix) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dMap, npix));
+        HIPCHK(c, dev_alloc(&c->dMapTau, npix));
+        c->map_cap = npix;
+    }
+    SocMapArgs A;
+    memset(&A, 0, sizeof A);
+    A.mode = healpix ? 1 : 0;
+    A.NPIX_X = NPIX_X;  A.NPIX_Y = healpix ? 1 : NPIX_Y;  A.SAVE_COLDEN = save_colden;
+    A.MAP_DX = MAP_DX;  A.ABS = ABS;  A.SCA = SCA;  A.LENGTH = LENGTH;
+    for (int k = 0; k < 3; k++) {
+        A.DIR[k] = DIR ? DIR[k] : 0.0f;  A.RA[k] = RA ? RA[k] : 0.0f;  A.DE[k] = DE ? DE[k] : 0.0f;
+        A.CENTRE[k] = CENTRE ? CENTRE[k] : 0.0f;
+        A.INTOBS[k] = inside ? INTOBS[k] : (k == 0 ? -1.0e12f : 0.0f);
+    }
+    A.EMIT = c->dMapEmit;  A.OPT = c->dOPT;  A.MAP = c->dMap;  A.SAVETAU = c->dMapTau;
+    HIPCHK(c, hipMemcpyAsync(c->dMapEmit, EMIT, cells * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, soc_launch_map(c->G, A, c->dOPT != nullptr, c->stream));
+    HIPCHK(c, hipMemcpyAsync(MAP, c->dMap, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(SAVETAU, c->dMapTau, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
 }
 

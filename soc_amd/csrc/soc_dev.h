@@ -87,6 +87,18 @@ hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin
 hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
                                const float *T, float *EMIT, hipStream_t st);
 
+// map making (soc_map.hip): one launch of Mapping / HealpixMapping (kernel_ASOC_map.c:496-516, 890-910)
+struct SocMapArgs {
+    int   mode;                    // 0 Mapping, 1 HealpixMapping (NSIDE = NPIX_X)
+    int   NPIX_X, NPIX_Y, SAVE_COLDEN;
+    float MAP_DX, ABS, SCA, LENGTH;
+    float DIR[3], RA[3], DE[3], CENTRE[3], INTOBS[3];
+    const float  *EMIT;
+    const float2 *OPT;
+    float *MAP, *SAVETAU;
+};
+hipError_t soc_launch_map(const SocGrid &G, const SocMapArgs &A, bool abu, hipStream_t st);
+
 // stochastic-heating solver (soc_a2e.hip)
 struct SocA2EArgs {
     int NE, NFREQ, npair, batch;

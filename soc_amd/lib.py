@@ -70,6 +70,8 @@ API = {
     "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
     "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
+    "soc_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int,
+                          C.c_float, _F, _F]),
     "soc_a2e_set_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F]),
     "soc_a2e_solve": (C.c_int, [C.c_void_p, C.c_int, _F, _F]),
     "soc_a2e_upload": (C.c_int, [C.c_void_p, C.c_int, _F]),
@@ -289,6 +291,21 @@ class Engine:
         out = np.zeros((self.CELLS, FREQ.size), np.float32)
         self._chk(self.lib.soc_emission(self.h, int(FREQ.size), _f(FREQ), _f(FABS), np.float32(FACTOR), np.float32(LENGTH), _f(out)))
         return out
+
+    # ---- map making ----
+    def map(self, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, ABS, SCA, INTOBS=None, save_colden=0, LENGTH=1.0, healpix=0):
+        """One map (kernel_ASOC_map.c Mapping / HealpixMapping).  Returns (MAP, SAVETAU): [NPIX.y, NPIX.x] or [12*NSIDE^2]."""
+        EMIT = np.ascontiguousarray(EMIT, np.float32)
+        if EMIT.size != self.CELLS:
+            raise SocError("map: EMIT must hold CELLS floats")
+        v = [None if a is None else np.ascontiguousarray(np.asarray(a, np.float32).ravel()[:3]) for a in (DIR, RA, DE, CENTRE, INTOBS)]
+        nx, ny = (int(healpix), 1) if healpix else (int(NPIX[0]), int(NPIX[1]))
+        shape = (12 * nx * nx,) if healpix else (ny, nx)
+        MAP, TAU = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+        self._chk(self.lib.soc_map(self.h, int(bool(healpix)), nx, ny, np.float32(MAP_DX), _f(EMIT), _f(v[0]), _f(v[1]), _f(v[2]),
+                                   _f(v[3]), _f(v[4]), np.float32(ABS), np.float32(SCA), int(save_colden), np.float32(LENGTH),
+                                   _f(MAP), _f(TAU)))
+        return MAP, TAU
 
     # ---- scattered-light images (ASOCS) ----
     @staticmethod

@@ -138,7 +138,25 @@ def sca_main():
     np.savez_compressed(os.path.join(HERE, "sca.npz"), **out)
 
 
+def maps_main():
+    """Golden maps of tests/test_maps.py:MAP_CASES from the x86 build of kernel_ASOC_map.c."""
+    from oracle.pyoracle import RefMap, Oracle
+    import test_maps
+    out = {}
+    ol = Oracle("libm")
+    for name, (ref, mk, kw) in test_maps.MAP_CASES.items():
+        R = RefMap(ref, NSIDE=kw.get("healpix", 8) or 8)
+        job, m, t = test_maps.run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
+                                       R.mapping(job, ol.parents(job), emit, d, r, e, npix, dx, c, io, cd, hp))
+        out[name + "_map"], out[name + "_tau"] = m, t
+        print("%-20s sum(MAP) = %.6e  nonzero %d / %d" % (name, m.sum(dtype=np.float64), (m > 0).sum(), m.size))
+    np.savez_compressed(os.path.join(HERE, "maps.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--maps" in sys.argv:
+        maps_main()
+        sys.exit(0)
     if "--sca" in sys.argv:
         sca_main()
         sys.exit(0)

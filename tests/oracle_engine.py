@@ -3,7 +3,7 @@ Lives in tests/: it lets the host driver (soc_amd.asoc.AbsorptionRun) and the mu
 sharding logic be exercised without a GPU.  Never imported by the product."""
 import numpy as np
 
-from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca
+from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca, oracle_mapping, NO_INTOBS
 
 
 class OracleEngine:
@@ -102,6 +102,14 @@ class OracleEngine:
 
     def emission(self, FREQ, FABS, FACTOR, LENGTH):
         return self.orc.emission(FREQ, FABS, FACTOR, LENGTH, self.Tdust)
+
+    # ---- map making ----
+    def map(self, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, ABS, SCA, INTOBS=None, save_colden=0, LENGTH=1.0, healpix=0):
+        job = Job(self.cloud, np.linspace(1, -1, 8), ABS=ABS, SCA=SCA, OPT=self.OPT)
+        io = NO_INTOBS if (INTOBS is None or INTOBS[0] < -1e10) else INTOBS
+        m, t = oracle_mapping(self.orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, io, save_colden, LENGTH, healpix)
+        shape = (m.size,) if healpix else (int(NPIX[1]), int(NPIX[0]))
+        return m.reshape(shape), t.reshape(shape)
 
     # ---- scattered-light images ----
     def sca_set_view(self, ODIR, RA, DE, NPIX, MAP_DX, CENTRE, FFS=1):

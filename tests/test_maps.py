@@ -1,0 +1,115 @@
+"""Map making: the oracle's restatement of kernel_ASOC_map.c against the x86 build of
+that file (bit-exact, libm mode) and the golden maps made from it; the HIP kernel against the oracle
+(soc mode; same header, same operation order -> bit-identical); the map files of asoc.py."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import Job, Oracle, RefMap, oracle_mapping, NO_INTOBS
+from soc_amd import launch, synth
+
+_, CSC = synth.hg_scattering_table(0.6)
+N, OD, RA, DE = launch.set_observer_directions([math.radians(30), math.radians(90), 0.0], [math.radians(40), 0.0, 0.0])
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "maps.npz"))
+
+
+def _opt(cells):
+    rr = np.random.default_rng(5)
+    o = np.zeros((cells, 2), np.float32)
+    o[:, 0] = 1e-3 * rr.uniform(0.5, 2, cells)
+    o[:, 1] = 3e-3 * rr.uniform(0.5, 2, cells)
+    return o
+
+
+MAP_CASES = {
+    # name: (ref build, cloud factory, kwargs)
+    "map_c8": ("c8", lambda: synth.cartesian_cloud(8, seed=3), {}),
+    "map_oct8": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), {}),
+    "map_c8_abu": ("c8abu", lambda: synth.cartesian_cloud(8, seed=3), dict(abu=True)),
+    "map_oct8_inside": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(intobs=(4.2, 4.1, 3.9), npix=(16, 9))),
+    "map_oct8_colden": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(colden=1)),
+    "map_oct8_healpix": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(intobs=(4.2, 4.1, 3.9), healpix=8)),
+    "map_oct104_double": ("oct104", lambda: synth.octree_cloud(104, levels=3, frac=0.002, seed=11), dict(npix=(24, 24), dx=4.0)),
+    "map_c208_entry": ("c208", lambda: synth.cartesian_cloud(208, uniform=1.0), dict(npix=(10, 10), dx=20.0)),
+}
+LENGTH = np.float32(3.08568e16)
+
+
+def run_case(name, mapper):
+    ref, mk, kw = MAP_CASES[name]
+    cloud = mk()
+    job = Job(cloud, CSC, ABS=1e-3, SCA=3e-3, OPT=_opt(cloud.CELLS) if kw.get("abu") else None)
+    emit = np.where(cloud.DENS > 0, np.abs(cloud.DENS) * 1e-3 * np.random.default_rng(1).uniform(0.5, 2, cloud.CELLS), 0).astype(np.float32)
+    c = (cloud.NX / 2, cloud.NY / 2, cloud.NZ / 2)
+    out = []
+    for k in range(1 if kw.get("healpix") else N):
+        out.append(mapper(job, emit, OD[k], RA[k], DE[k], kw.get("npix", (12, 10)), kw.get("dx", 0.9), c,
+                          kw.get("intobs", NO_INTOBS), kw.get("colden", 0), kw.get("healpix", 0)))
+    return job, np.concatenate([o[0].ravel() for o in out]), np.concatenate([o[1].ravel() for o in out])
+
+
+@pytest.mark.parametrize("name", sorted(MAP_CASES))
+def test_map_oracle_bit_exact_vs_reference_golden(name, oracle_libm):
+    job, m, t = run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
+                         oracle_mapping(oracle_libm, job, emit, d, r, e, npix, dx, c, io, cd, LENGTH, hp))
+    assert (m > 0).sum() > 30
+    assert np.array_equal(m.view(np.uint32), GOLD[name + "_map"].view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), GOLD[name + "_tau"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["map_c8", "map_oct8_inside", "map_oct8_healpix"])
+def test_map_soc_math_close(name, oracle_soc):
+    job, m, t = run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
+                         oracle_mapping(oracle_soc, job, emit, d, r, e, npix, dx, c, io, cd, LENGTH, hp))
+    assert np.abs(m - GOLD[name + "_map"]).max() < 1e-5 * GOLD[name + "_map"].max()
+
+
+def test_map_files_of_the_driver(tmp_path):
+    """asoc.py writes map_dir_XX.bin (int32 NPIX.x, NPIX.y + one float32 image per emitted frequency, ASOC.py:2992-2996,
+    3134) with the scaling of ASOC.py:2997-2998, 3099"""
+    from oracle_engine import OracleEngine
+    from soc_amd import files
+    from soc_amd.asoc import AbsorptionRun
+    from soc_amd.ini import User
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    extra = ("noabsorbed\niterations 1\ntemperature %s/T.bin\nemitted %s/em.bin\nmapping 12 10 0.8\ndirection 30 40\ndirection 90 0\n" % (d, d))
+    ini = _write_model(d, cloud, extra=extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("nomap\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+    run = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+    run.run()
+    for idir in (0, 1):
+        raw = np.fromfile("map_dir_%02d.bin" % idir, np.int32, 2)
+        assert list(raw) == [12, 10]
+        maps = np.fromfile("map_dir_%02d.bin" % idir, np.float32, offset=8).reshape(3, 10, 12)
+        assert (maps >= 0).all() and maps.sum() > 0
+    # one image re-derived: EMIT = KK*FREQ*EMITTED, KK = 1e23/FACTOR*PLANCK/(4 pi)*GL*PARSEC
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    KK = (1.0e23 / launch.FACTOR) * launch.PLANCK / (4.0 * np.pi) * 0.5 * launch.PARSEC
+    i = 1
+    emit = np.asarray(KK * float(FFREQ[i]) * run.EMITTED[:, i], np.float32)
+    _, OD2, RA2, DE2 = launch.set_observer_directions([math.radians(30), math.radians(90)], [math.radians(40), 0.0])
+    job = Job(cloud, CSC, ABS=AFABS[0][i], SCA=AFSCA[0][i])
+    want, _ = oracle_mapping(Oracle("soc"), job, emit, OD2[0], RA2[0], DE2[0], (12, 10), 0.8, (3.0, 3.0, 3.0))
+    maps = np.fromfile("map_dir_00.bin", np.float32, offset=8).reshape(3, 10, 12)
+    assert np.array_equal(maps[i].ravel(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MAP_CASES))
+def test_map_hip_bit_identical_to_oracle(name, engine, oracle_soc):
+    def gpu(job, emit, d, r, e, npix, dx, c, io, cd, hp):
+        engine.set_cloud(job.cloud)
+        engine.set_opt(job.OPT)
+        return engine.map(emit, d, r, e, npix, dx, c, job.ABS, job.SCA, INTOBS=io, save_colden=cd, LENGTH=LENGTH, healpix=hp)
+    job, m, t = run_case(name, gpu)
+    _, mo, to = run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
+                         oracle_mapping(oracle_soc, job, emit, d, r, e, npix, dx, c, io, cd, LENGTH, hp))
+    assert np.array_equal(m.view(np.uint32), mo.view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), to.view(np.uint32))
+    engine.set_opt(None)
