@@ -32,21 +32,58 @@
 #include "soc_walk.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define SOC_BRICK_T 256          // threads per workgroup (scatter kernel; step kernel uses A.T)
+
+// wave-level counters of the walk loop for experiments (-DSOC_BRICK_PROF): iterations, lanes stepping, arm executions
+#if defined(SOC_BRICK_PROF)
+__device__ unsigned long long g_soc_prof[16];
+#define SOC_PROF_DECL unsigned int prof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  unsigned long long tprof_[5] = { 0, 0, 0, 0, 0 }, tlast_ = __builtin_readcyclecounter()
+#define SOC_PROF_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter();  tprof_[i] += t_ - tlast_;  tlast_ = t_; } while (0)
+#define SOC_PROF(i, n) do { prof_[i] += (unsigned int)(n); } while (0)           /* n is wave-uniform */
+#define SOC_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) if (i_ != 6) atomicAdd(&g_soc_prof[i_], (unsigned long long)prof_[i_]); \
+                            if (prof_[6]) atomicAdd(&g_soc_prof[6], (unsigned long long)prof_[6]); \
+                            if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_soc_prof[8 + i_], tprof_[i_]); } while (0)   /* [6] is counted per lane */
+extern "C" __attribute__((visibility("default"))) void soc_prof_read(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_soc_prof), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = { 0 };  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_soc_prof), z, sizeof(z)); }
+}
+#else
+#define SOC_PROF_DECL
+#define SOC_PROF_T(i) do { } while (0)
+#define SOC_PROF(i, n) do { } while (0)
+#define SOC_PROF_FLUSH do { } while (0)
+#endif
 #define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk
 
-enum { SOC_BM_STEP = 0, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
+enum { SOC_BM_STEP = 0, SOC_BM_CLIMB = 1, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
 
 struct __align__(16) SocPk2 { float4 A, B, C; uint4 D; };   // 64-B packet record, see soc_brick_walk
 
 struct SocDesc { int brick, start, count, pad; };
 
+// Packet records and queue entries are touched once per pass.  Streaming them past the caches (-DSOC_BRICK_NT:
+// nontemporal) was measured: no change on a 256^3 hierarchy, -23 % on C2 (whose packets fit the last-level cache).
+#if defined(SOC_BRICK_NT)
+#define SOC_NT_LOAD(p)      __builtin_nontemporal_load(p)
+#define SOC_NT_STORE(v, p)  __builtin_nontemporal_store((v), (p))
+#else
+#define SOC_NT_LOAD(p)      (*(p))
+#define SOC_NT_STORE(v, p)  (*(p) = (v))
+#endif
+typedef float soc_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 soc_ld4(const float4 *p) { const soc_f4v v = SOC_NT_LOAD((const soc_f4v *)p);  return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void soc_st4(float4 *p, float4 a) { soc_f4v v = { a.x, a.y, a.z, a.w };  SOC_NT_STORE(v, (soc_f4v *)p); }
+
 struct SocBrickArgs {
     int LB, NBX, NBY, NBZ, NB;   // brick edge = 1 << LB root cells; NB bricks
     int T, P, KCAP, FTH;         // step-kernel threads, packets per chunk, max steps per packet per pass, fetch threshold
+    int TAIL;                    // a wave with this many lanes out of work sends its last packets back to the queue (0: never)
     SocPk2 *pk;
     const uint32_t *idq;         // current queue (ids sorted by brick)
     uint32_t *idq_next;
@@ -60,7 +97,55 @@ struct SocBrickArgs {
     int *ndesc_next;
     int *total;                  // packets still in flight after this pass
     int ev_brick;                // scan: first event queue (descriptors from here on belong to soc_brick_events)
+    int HS;                      // arrivals per destination, per workgroup: 0 = LDS table indexed by queue, else hash table of HS entries
+    // hierarchical grids: bricks are sets of <= CAP leaf cells (soc_oct_build)
+    int CAP;
+    const float2 *DS;            // [CELLS] density or link as in DENS | brick << 14 + tally slot of a leaf (bits)
+    float sib_thr;               // coordinates from here up climb to the parent exactly in double (see the walk)
+    const int *bcell;            // cells of every brick in slot order
+    const int *bbase;            // [NB+1] first entry of a brick in bcell
 };
+
+#define SOC_SLOT_BITS 14
+#define SOC_SLOT_MASK ((1u << SOC_SLOT_BITS) - 1u)
+#define SOC_LVL_SHIFT 16         // packet word C.z: tally slot | level << 16 | launch << 20
+#define SOC_LCH_SHIFT 20
+
+// Arrivals per destination queue, counted per workgroup in LDS and added to the global histogram once.
+// Small models: a table with one entry per queue.  Large ones (thousands of bricks): a workgroup's packets go to
+// its neighbours and the event queues only, so an open-addressing table of HS entries; a key that finds no
+// place within 32 probes is counted in global memory directly.
+__device__ __forceinline__ void soc_qh_init(int *sH, int HS, int NQ)
+{
+    if (HS == 0) { for (int i = threadIdx.x; i < NQ; i += blockDim.x) sH[i] = 0; }
+    else         { for (int i = threadIdx.x; i < HS; i += blockDim.x) { sH[i] = -1;  sH[HS + i] = 0; } }
+}
+// returns the table entry (for soc_brick_scatter's ranks), -1 when counted globally
+__device__ __forceinline__ int soc_qh_find(int *sH, int HS, int key)
+{
+    uint32_t h = (((uint32_t)key * 0x9E3779B1u) >> 12) & (uint32_t)(HS - 1);
+    for (int t = 0; t < 32; t++) {
+        const int old = atomicCAS(&sH[h], -1, key);
+        if (old == -1 || old == key) return (int)h;
+        h = (h + 1) & (uint32_t)(HS - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ void soc_qh_add(int *sH, int HS, int key, int *ghist)
+{
+    if (HS == 0) { atomicAdd(&sH[key], 1);  return; }
+    const int h = soc_qh_find(sH, HS, key);
+    if (h >= 0) atomicAdd(&sH[HS + h], 1);
+    else        atomicAdd(&ghist[key], 1);
+}
+__device__ __forceinline__ void soc_qh_flush(const int *sH, int HS, int NQ, int *ghist)
+{
+    if (HS == 0) {
+        for (int i = threadIdx.x; i < NQ; i += blockDim.x) { const int c = sH[i];  if (c) atomicAdd(&ghist[i], c); }
+    } else {
+        for (int i = threadIdx.x; i < HS; i += blockDim.x) { const int k = sH[i], c = sH[HS + i];  if (k >= 0 && c) atomicAdd(&ghist[k], c); }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 
@@ -121,7 +206,7 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
         SocPk2 p;
         p.A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         p.B = p.A;
-        p.C = make_float4(0.0f, 0.0f, __int_as_float(l << 16), __int_as_float(-1));
+        p.C = make_float4(0.0f, 0.0f, __int_as_float(l << SOC_LCH_SHIFT), __int_as_float(-1));
         p.D = make_uint4(r.x, r.c, 0u, 0u);
         pk[t] = p;
         idq0[t] = t;
@@ -146,13 +231,13 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
     if (t <= (uint32_t)(A.NB + 2 * K.n)) hist[t] = 0;
 }
 
-template <bool ABU, bool WINT>
+template <bool OCT, bool DBL, bool ABU, bool WINT>
 __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
     if (bid >= *A.ndesc) return;
     const SocDesc D = A.desc[bid];
     if (D.brick >= A.NB) return;                           // an event queue: soc_brick_events
-    const int BV = 1 << (3 * A.LB);
+    const int BV = OCT ? A.CAP : (1 << (3 * A.LB));        // tally slots in LDS
     const int nthr = (int)blockDim.x;
     SocPk2 *pk = A.pk;
 
@@ -160,15 +245,18 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + BV;                                 // [BV] INT (WINT)
     const int NQ = A.NB + 2 * K.n + 1;                     // bricks, (creation, scattering) per launch, finished
-    int   *sH   = (int *)(sI + (WINT ? BV : 0));           // [NQ] arrivals per queue, next pass
-    int   *sCtl = sH + NQ;                                 // [0] next packet, [1] tally events
-    float *sL   = (float *)(sCtl + 2);                     // [3 * n] ABS, SCA, TW of every launch
+    int   *sH   = (int *)(sI + (WINT ? BV : 0));           // arrivals per queue, next pass
+    int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0] next packet, [1] tally events
+    float *sL   = (float *)(sCtl + 2);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
+    int   *sOFF = (int *)(sL + 3 * SOC_MAXLAUNCH);         // [SOC_MAXL] first cell of every level
     const SocSim &S = K.S[0];                              // what the launches share: tallies, stats, OPT (n == 1)
     if ((int)threadIdx.x < K.n) {
         sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
     }
-    for (int i = threadIdx.x; i < BV; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
-    for (int i = threadIdx.x; i < NQ; i += nthr) sH[i] = 0;
+    if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
+    const int nslot = OCT ? (A.bbase[D.brick + 1] - A.bbase[D.brick]) : BV;
+    for (int i = threadIdx.x; i < nslot; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
+    soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
     __syncthreads();
 
@@ -179,48 +267,160 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
     float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;             // of the packet's launch
-    int   lsh = 0;                                         // launch index << 16
-    int   ind = -1, lid = 0, nvisit = 0, key = 0, slot = 0;
+    int   lsh = 0;                                         // launch index << SOC_LCH_SHIFT
+    int   ind = -1, level = 0, lid = 0, nvisit = 0, key = 0, slot = 0;
+    int   ind0 = -1, level0 = 0;                           // cell at the start of the step (hierarchies)
     int   mode = SOC_BM_SWAP;
     bool  have = false;
     uint32_t wid = 0;
     unsigned int n_tally = 0;
+    SOC_PROF_DECL;
 
     while (true) {
         {
+            SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
+            // the chunk has run out and most of the wave idles behind its longest walks: those continue in the next
+            // pass, from this brick's queue, among a full wave again (between steps the packet state is complete)
+            if (A.TAIL > 0 && __popcll(__ballot(mode == SOC_BM_IDLE)) >= A.TAIL && mode == SOC_BM_STEP) { mode = SOC_BM_SWAP;  key = mybrick; }
             const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
             const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
             if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
+                SOC_PROF(4, 1);  SOC_PROF(5, __popcll(m));
                 if (mode == SOC_BM_SWAP) {
                     if (have) {
                         SocPk2 *q = pk + wid;
-                        q->A = make_float4(px, py, pz, photons);
-                        q->C = make_float4(tau, dens, __int_as_float(lid | lsh), __int_as_float(ind));
-                        if (key >= A.NB) q->D.w = (uint32_t)mybrick;                 // scattering: the brick to come back to
-                        A.keyq[D.start + slot] = (uint32_t)key;
-                        atomicAdd(&sH[key], 1);
+                        soc_st4(&q->A, make_float4(px, py, pz, photons));
+                        soc_st4(&q->C, make_float4(tau, dens, __int_as_float(lid | (level << SOC_LVL_SHIFT) | lsh), __int_as_float(ind)));
+                        if (key >= A.NB) SOC_NT_STORE((uint32_t)mybrick, &q->D.w);   // scattering: the brick to come back to
+                        SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + slot]);
+                        soc_qh_add(sH, A.HS, key, A.hist);
                     }
                     slot = atomicAdd(&sCtl[0], 1);
                     have = slot < D.count;
                     if (!have) {
                         mode = SOC_BM_IDLE;
                     } else {
-                        wid = A.idq[D.start + slot];
+                        wid = SOC_NT_LOAD(&A.idq[D.start + slot]);
                         const SocPk2 *q = pk + wid;
-                        const float4 a = q->A, b = q->B, c = q->C;
+                        const float4 a = soc_ld4(&q->A), b = soc_ld4(&q->B), c = soc_ld4(&q->C);
                         px = a.x;  py = a.y;  pz = a.z;  photons = a.w;
                         ux = b.x;  uy = b.y;  uz = b.z;  free_path = b.w;
                         rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
                         tau = c.x;  dens = c.y;  ind = __float_as_int(c.w);
-                        lid = __float_as_int(c.z) & 0xffff;  lsh = __float_as_int(c.z) & ~0xffff;
-                        { const int l3 = 3 * (lsh >> 16);  kabs = sL[l3];  ksca = sL[l3 + 1];  tw = sL[l3 + 2]; }
+                        const int cz = __float_as_int(c.z);
+                        lid = cz & 0xffff;  level = (cz >> SOC_LVL_SHIFT) & 15;  lsh = cz & ~((1 << SOC_LCH_SHIFT) - 1);
+                        { const int l3 = 3 * (lsh >> SOC_LCH_SHIFT);  kabs = sL[l3];  ksca = sL[l3 + 1];  tw = sL[l3 + 2]; }
                         nvisit = 0;
                         mode = SOC_BM_STEP;
                     }
                 }
             }
         }
+        SOC_PROF_T(0);                                     // swap
         if (__ballot(mode != SOC_BM_IDLE) == 0ull) break;
+        if (OCT) {
+            // ---- one cell step on the hierarchy (kernel_ASOC.c:565-683) ----
+            // GetStep as on Cartesian grids (local coordinates: the arithmetic does not depend on the level).
+            // Index (kernel_ASOC_aux.c:198-278) by case, each with the reference's results:
+            //  * from a root cell: the root-grid lookup, then the descent through refined cells -- positions are
+            //    floats >= 0, for which 2*fmod(p,1) is exact in float and in double alike;
+            //  * to a sibling of the same octet (DBL, all coordinates in [sib_thr, 2)): the reference climbs to the
+            //    parent (P = 0.5*p + octant, exact in double above sib_thr), finds the position inside the parent cell
+            //    and descends again to 2*fmod(P,1) == p: same position, cell = octet base + octant of p, no reads;
+            //  * anything else: soc_index() itself, for several lanes at a time (mode SOC_BM_CLIMB).
+            bool finish = false;
+            uint32_t sl = 0;
+            if (mode == SOC_BM_STEP) {
+                ind0 = ind;  level0 = level;
+                const int   lid0 = lid;
+                const float p0x = px, p0y = py, p0z = pz, d0 = dens;
+                if (ABU) { float2 o = S.OPT[sOFF[level] + ind];  kabs = o.x;  ksca = o.y; }
+                float fx, fy, fz;
+                if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
+                    fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
+                } else {
+                    fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
+                }
+                const float ax = soc_div_by_rcp(((ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fx, ux, rux);
+                const float ay = soc_div_by_rcp(((uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fy, uy, ruy);
+                const float az = soc_div_by_rcp(((uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fz, uz, ruz);
+                float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
+                px += ds * ux;
+                py += ds * uy;
+                pz += ds * uz;
+                ds = soc_scale_down(ds, level);
+                const float tauA = ds * d0 * kabs;
+                const float dtau = ds * d0 * ksca;
+                if (free_path < (tau + dtau)) {
+                    px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
+                    mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT) + 1;
+                } else {
+                    const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
+                    const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+                    atomicAdd(&sT[lid0], delta * tw);
+                    if (WINT) atomicAdd(&sI[lid0], delta);
+                    n_tally++;
+                    photons *= e;
+                    tau += dtau;
+                    int cell = -1;                                               // global index of the cell to look at next
+                    if (level == 0) {
+                        const bool inside = (px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ);
+                        ind = inside ? ((int)pz * NX * NY + (int)py * NX + (int)px) : -1;
+                        cell = ind;
+                        finish = true;
+                    } else if (DBL && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)
+                                   && (__builtin_fmaxf(px, __builtin_fmaxf(py, pz)) < 2.0f)) {
+                        ind = (ind & ~7) + 4 * (int)pz + 2 * (int)py + (int)px;
+                        cell = sOFF[level] + ind;
+                        finish = true;
+                    } else {
+                        mode = SOC_BM_CLIMB;
+                    }
+                    if (cell >= 0) {
+                        float2 rec = A.DS[cell];
+                        while (!(rec.x > 0.0f)) {                                 // descend to the leaf
+                            SOC_PROF(6, 1);                                      /* per lane */
+                            px = 2.0f * __builtin_amdgcn_fractf(px);
+                            py = 2.0f * __builtin_amdgcn_fractf(py);
+                            pz = 2.0f * __builtin_amdgcn_fractf(pz);
+                            level++;
+                            ind = soc_link_index(rec.x) + 4 * (int)pz + 2 * (int)py + (int)px;
+                            rec = A.DS[sOFF[level] + ind];
+                        }
+                        dens = rec.x;
+                        sl = __float_as_uint(rec.y);
+                    }
+                }
+            }
+            SOC_PROF_T(1);                                 // step
+            {
+                const unsigned long long mc = __ballot(mode == SOC_BM_CLIMB);
+                if (mc != 0ull && (__popcll(mc) >= A.FTH || __ballot(mode == SOC_BM_STEP) == 0ull)) {
+                    SOC_PROF(2, 1);  SOC_PROF(3, __popcll(mc));
+                    if (mode == SOC_BM_CLIMB) {
+                        if (DBL) soc_index<true, double>(G, sOFF, px, py, pz, level, ind, dens);
+                        else     soc_index<true, float>(G, sOFF, px, py, pz, level, ind, dens);
+                        if (ind >= 0) sl = __float_as_uint(A.DS[sOFF[level] + ind].y);
+                        mode = SOC_BM_STEP;
+                        finish = true;
+                    }
+                }
+            }
+            SOC_PROF_T(2);                                 // climb
+            if (finish) {
+                if ((level == level0) && (ind == ind0)) {                         // failed step: nudge
+                    px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
+                }
+                nvisit++;
+                if (ind < 0) {
+                    mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT);                          // -> creation queue
+                } else {
+                    const int nb = (int)(sl >> SOC_SLOT_BITS);
+                    lid = (int)(sl & SOC_SLOT_MASK);
+                    if (nb != mybrick || nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = nb; }
+                }
+            }
+        } else
         // ---- one cell step (kernel_ASOC.c:565-683, LEVELS == 1) ----
         if (mode == SOC_BM_STEP) {
             const int   oind = ind, lid0 = lid;
@@ -258,7 +458,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             const float dtau = ds * d0 * ksca;
             if (free_path < (tau + dtau)) {
                 px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> 16) + 1;          // -> scattering queue of its launch
+                mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT) + 1;   // -> scattering queue of its launch
             } else {
                 // every lane of the wave in the interval where soc_expf_small == soc_expf (the common case)
                 const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
@@ -276,15 +476,27 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 py += failed ? (SOC_PEPS * uy) : 0.0f;
                 pz += failed ? (SOC_PEPS * uz) : 0.0f;
                 nvisit++;
-                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> 16); }   // -> creation queue
+                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT); }   // -> creation queue
                 else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = nb; }
             }
         }
     }
 
+    SOC_PROF_FLUSH;
     atomicAdd(&sCtl[1], (int)n_tally);
     __syncthreads();
-    {
+    if (OCT) {
+        const int *cells = A.bcell + A.bbase[mybrick];                        // consecutive slots: row neighbours, octet siblings
+        for (int i = threadIdx.x; i < nslot; i += nthr) {
+            const float v = sT[i];
+            const float vi = WINT ? sI[i] : 0.0f;
+            if (v != 0.0f || vi != 0.0f) {
+                const int cell = cells[i];
+                soc_tally(S.TABS, cell, v);
+                if (WINT) soc_tally(S.INT, cell, vi);
+            }
+        }
+    } else {
         const int B = 1 << A.LB;
         const int bx = mybrick % A.NBX, by = (mybrick / A.NBX) % A.NBY, bz = mybrick / (A.NBX * A.NBY);
         for (int i = threadIdx.x; i < BV; i += nthr) {
@@ -298,15 +510,12 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             }
         }
     }
-    for (int i = threadIdx.x; i < NQ; i += nthr) {
-        const int c = sH[i];
-        if (c) atomicAdd(&A.hist[i], c);
-    }
+    soc_qh_flush(sH, A.HS, NQ, A.hist);
     if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
 }
 
 // creation and scattering, one lane per queued packet
-template <bool ABU, bool WINT>
+template <bool OCT, bool ABU, bool WINT>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
     // ebid counts from the first event descriptor (event queues sort last);
@@ -326,23 +535,24 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
     const int lq = (D.brick - A.NB) >> 1;                  // the launch this queue belongs to (workgroup-uniform)
     const SocSim &S = K.S[lq];
     extern __shared__ float lds[];
-    int   *sH   = (int *)lds;                              // [NQ]
-    int   *sCtl = sH + NQ;                                 // [0..2] stats, [4] = 0 (OFF[0])
-    for (int i = threadIdx.x; i < NQ; i += blockDim.x) sH[i] = 0;
-    if (threadIdx.x < 8) sCtl[threadIdx.x] = 0;
+    int   *sH   = (int *)lds;                              // arrivals per queue
+    int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0..2] stats
+    int   *sOFF = sCtl + 4;                                // [SOC_MAXL]
+    soc_qh_init(sH, A.HS, NQ);
+    if (threadIdx.x < 4) sCtl[threadIdx.x] = 0;
+    if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
     __syncthreads();
-    const int *sOFF0 = sCtl + 4;
     unsigned int n_tally = 0, n_pkt = 0, n_scat = 0;
 
     for (int j = threadIdx.x; j < D.count; j += blockDim.x) {
         const uint32_t wid = A.idq[D.start + j];
         SocPk2 p = pk[wid];
         SocBrickLane w;
-        w.level = 0;
         w.px = p.A.x;  w.py = p.A.y;  w.pz = p.A.z;  w.photons = p.A.w;
         w.ux = p.B.x;  w.uy = p.B.y;  w.uz = p.B.z;  w.free_path = p.B.w;
         w.tau = p.C.x;  w.dens = p.C.y;
         int lid = __float_as_int(p.C.z) & 0xffff;
+        w.level = OCT ? ((__float_as_int(p.C.z) >> SOC_LVL_SHIFT) & 15) : 0;
         w.ind = __float_as_int(p.C.w);
         w.rng.x = p.D.x;  w.rng.c = p.D.y;
         int III = (int)(p.D.z & 0xffffffu);
@@ -351,7 +561,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         bool create = (((D.brick - A.NB) & 1) == 0);
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
-            const int oind = w.ind;
+            const int oind = (OCT ? sOFF[w.level] : 0) + w.ind;
             float kabs, ksca;
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
             else     { kabs = S.ABS;  ksca = S.SCA; }
@@ -365,7 +575,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             if (WINT) soc_tally(S.INT, oind, delta);
             n_tally++;
             n_scat++;
-            dx = soc_scale_up(dx, 0);
+            dx = soc_scale_up(dx, w.level);
             dx = __builtin_fmaxf(0.0f, dx - 2.0f * SOC_PEPS);
             w.px = w.px + dx * w.ux;
             w.py = w.py + dx * w.uy;
@@ -381,29 +591,34 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             const SocSurfElem E = soc_surface_element(G, S, id);
             while (true) {
                 if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
-                soc_pb_create<false>(G, S, sOFF0, E, III, w);
+                soc_pb_create<OCT>(G, S, sOFF, E, III, w);
                 III++;
                 n_pkt++;
                 w.begin();
-                if (w.ind >= 0) { soc_cell_brick(A, w.px, w.py, w.pz, key, lid);  break; }
+                if (w.ind >= 0) {
+                    if (OCT) {
+                        const uint32_t si = __float_as_uint(A.DS[sOFF[w.level] + w.ind].y);
+                        key = (int)(si >> SOC_SLOT_BITS);  lid = (int)(si & SOC_SLOT_MASK);
+                    } else {
+                        soc_cell_brick(A, w.px, w.py, w.pz, key, lid);
+                    }
+                    break;
+                }
             }
         }
         p.A = make_float4(w.px, w.py, w.pz, w.photons);
         p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
-        p.C = make_float4(w.tau, w.dens, __int_as_float(lid | (lq << 16)), __int_as_float(w.ind));
+        p.C = make_float4(w.tau, w.dens, __int_as_float(lid | ((OCT ? w.level : 0) << SOC_LVL_SHIFT) | (lq << SOC_LCH_SHIFT)), __int_as_float(w.ind));
         p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), (uint32_t)key);
         pk[wid] = p;
         A.keyq[D.start + j] = (uint32_t)key;
-        atomicAdd(&sH[key], 1);
+        soc_qh_add(sH, A.HS, key, A.hist);
     }
     atomicAdd(&sCtl[0], (int)n_tally);
     atomicAdd(&sCtl[1], (int)n_pkt);
     atomicAdd(&sCtl[2], (int)n_scat);
     __syncthreads();
-    for (int i = threadIdx.x; i < NQ; i += blockDim.x) {
-        const int c = sH[i];
-        if (c) atomicAdd(&A.hist[i], c);
-    }
+    soc_qh_flush(sH, A.HS, NQ, A.hist);
     if (threadIdx.x == 0 && S.stats) {
         atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[0]);
         atomicAdd(S.stats + 1, (unsigned long long)(unsigned int)sCtl[1]);
@@ -414,15 +629,15 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
 // One launch per pass for both: blocks [0, nwalk) walk the descriptor of their index (and leave at
 // once if it belongs to an event queue), the blocks after them are the event workgroups.  The short,
 // latency-bound event work runs beside the walk instead of after it.
-template <bool ABU, bool WINT>
+template <bool OCT, bool DBL, bool ABU, bool WINT>
 __global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSimPack K, const SocBrickArgs A, const int nwalk, const int slices)
 {
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
-        soc_brick_walk<ABU, WINT>(G, K, A, b);
+        soc_brick_walk<OCT, DBL, ABU, WINT>(G, K, A, b);
     } else {
         const int e = b - nwalk;
-        soc_brick_events<ABU, WINT>(G, K, A, e / slices, e % slices);
+        soc_brick_events<OCT, ABU, WINT>(G, K, A, e / slices, e % slices);
     }
 }
 
@@ -482,11 +697,12 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A)
 {
     if ((int)blockIdx.x >= *A.ndesc) return;
     const SocDesc D = A.desc[blockIdx.x];
-    extern __shared__ int sB[];                          // [NB]
-    for (int i = threadIdx.x; i < A.NB; i += SOC_BRICK_T) sB[i] = 0;
+    extern __shared__ int sB[];                          // [NB], or keys[HS] + counts[HS]
+    const int HS = A.HS;
+    soc_qh_init(sB, HS, A.NB);
     __syncthreads();
     uint32_t key[SOC_BRICK_PMAX / SOC_BRICK_T];
-    int      rank[SOC_BRICK_PMAX / SOC_BRICK_T];
+    int      rank[SOC_BRICK_PMAX / SOC_BRICK_T];         // rank within (workgroup, destination); hash mode: | entry << 16
 #pragma unroll
     for (int k = 0; k < SOC_BRICK_PMAX / SOC_BRICK_T; k++) {
         const int j = k * SOC_BRICK_T + threadIdx.x;
@@ -494,19 +710,41 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A)
         rank[k] = 0;
         if (j < D.count) {
             key[k] = A.keyq[D.start + j];
-            if (key[k] < (uint32_t)A.NB) rank[k] = atomicAdd(&sB[key[k]], 1);
+            if (key[k] < (uint32_t)A.NB) {
+                if (HS == 0) {
+                    rank[k] = atomicAdd(&sB[key[k]], 1);
+                } else {
+                    const int h = soc_qh_find(sB, HS, (int)key[k]);
+                    if (h >= 0) {
+                        rank[k] = atomicAdd(&sB[HS + h], 1) | (h << 16);
+                    } else {                             // table full around this key: place it now
+                        A.idq_next[A.off[key[k]] + atomicAdd(&A.cursor[key[k]], 1)] = A.idq[D.start + j];
+                        key[k] = (uint32_t)A.NB;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < A.NB; i += SOC_BRICK_T) {
-        const int c = sB[i];
-        if (c) sB[i] = A.off[i] + atomicAdd(&A.cursor[i], c);
+    if (HS == 0) {
+        for (int i = threadIdx.x; i < A.NB; i += SOC_BRICK_T) {
+            const int c = sB[i];
+            if (c) sB[i] = A.off[i] + atomicAdd(&A.cursor[i], c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HS; i += SOC_BRICK_T) {
+            const int q = sB[i], c = sB[HS + i];
+            if (q >= 0 && c) sB[HS + i] = A.off[q] + atomicAdd(&A.cursor[q], c);
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SOC_BRICK_PMAX / SOC_BRICK_T; k++) {
         const int j = k * SOC_BRICK_T + threadIdx.x;
-        if (j < D.count && key[k] < (uint32_t)A.NB) A.idq_next[sB[key[k]] + rank[k]] = A.idq[D.start + j];
+        if (j < D.count && key[k] < (uint32_t)A.NB) {
+            const int base = (HS == 0) ? sB[key[k]] : sB[HS + (rank[k] >> 16)];
+            A.idq_next[base + (rank[k] & 0xffff)] = A.idq[D.start + j];
+        }
     }
 }
 
@@ -538,6 +776,8 @@ static hipError_t brick_alloc(T **p, size_t n)
     return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
 }
 
+static void soc_oct_release(int device);
+
 void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
@@ -545,34 +785,229 @@ void soc_brick_release(int device)
     void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     b = SocBrickBuffers();
+    soc_oct_release(device);
 }
 
-// LB: log2 of the brick edge.  nlaunch launches (same geometry, same tallies; scalar opacities and no
-// INT tally when nlaunch > 1) share one sweep: more packets in flight per pass, and the passes in which
-// one launch's last work items finish are filled by the others.  Returns hipErrorNotSupported when the
-// launches cannot use bricks.
+// ---------------------------------------------------------------------------------------
+// Bricks of a hierarchical grid.  A brick is a set of <= CAP leaf cells that are close in space, each with a
+// tally slot; refined cells hold no tally and belong to no brick.  Built on the host once per grid:
+//   1. leaves in every subtree, bottom-up over the levels;
+//   2. the root grid is visited in cubes of 16^3 cells; a cube (and below that: an octant of it, a root cell's
+//      subtree, a child's subtree) that holds more than CAP leaves is split into its eight parts; a part that
+//      fits goes to the open brick, or starts a new one when the open brick has no room for it;
+//   3. slots are given in visiting order (x fastest, octet siblings together), so that the end-of-pass flush
+//      touches neighbouring cells with neighbouring lanes.
+// The reference layout of DENS/OFF/PAR is untouched; the walk reads density and slot together from DS[cell].
+// ---------------------------------------------------------------------------------------
+struct SocOctBricks {
+    bool valid = false;
+    int  NB = 0, CAP = 0;
+    size_t cells = 0, leaves = 0;
+    const float *dens_key = nullptr;           // the hierarchy the bricks were built for
+    float2 *DS = nullptr;
+    int *bcell = nullptr, *bbase = nullptr;
+};
+static SocOctBricks g_ob[16];
+
+void soc_brick_invalidate(int device)
+{
+    if (device >= 0 && device < 16) g_ob[device].valid = false;
+}
+
+static void soc_oct_release(int device)
+{
+    SocOctBricks &o = g_ob[device];
+    if (o.DS) (void)hipFree(o.DS);
+    if (o.bcell) (void)hipFree(o.bcell);
+    if (o.bbase) (void)hipFree(o.bbase);
+    o = SocOctBricks();
+}
+
+namespace {
+struct OctBuilder {
+    const SocGrid &G;
+    const std::vector<float> &D;
+    std::vector<uint32_t> sub;                 // leaves in the subtree of every cell
+    std::vector<uint32_t> slotmap;
+    std::vector<int> bcell, bbase;
+    int CAP, fill = 0;
+
+    OctBuilder(const SocGrid &g, const std::vector<float> &d, int cap) : G(g), D(d), CAP(cap) {}
+
+    static int link(float d) { float m = -d;  int i;  memcpy(&i, &m, 4);  return i; }
+
+    void count()
+    {
+        sub.assign((size_t)G.CELLS, 0u);
+        for (int l = G.LEVELS - 1; l >= 0; l--) {
+            const size_t o = (size_t)G.OFF[l];
+            for (int i = 0; i < G.LCELLS[l]; i++) {
+                const float d = D[o + i];
+                if (d > 0.0f) { sub[o + i] = 1;  continue; }
+                uint32_t n = 0;
+                if (l + 1 < G.LEVELS) {
+                    const size_t c = (size_t)G.OFF[l + 1] + link(d);
+                    for (int k = 0; k < 8; k++) n += sub[c + k];
+                }
+                sub[o + i] = n;
+            }
+        }
+    }
+    void open(uint32_t need)
+    {
+        if (fill > 0 && fill + (long long)need > CAP) { bbase.push_back((int)bcell.size());  fill = 0; }
+    }
+    void place_subtree(int l, int i)            // all leaves below (l, i) into the open brick
+    {
+        const size_t a = (size_t)G.OFF[l] + i;
+        if (D[a] > 0.0f) {
+            slotmap[a] = ((uint32_t)(bbase.size() - 1) << SOC_SLOT_BITS) | (uint32_t)fill;
+            bcell.push_back((int)a);
+            fill++;
+            return;
+        }
+        if (l + 1 >= G.LEVELS) return;
+        const int c = link(D[a]);
+        for (int k = 0; k < 8; k++) place_subtree(l + 1, c + k);
+    }
+    void assign_subtree(int l, int i)
+    {
+        const uint32_t n = sub[(size_t)G.OFF[l] + i];
+        if (n == 0) return;
+        if (n <= (uint32_t)CAP) { open(n);  place_subtree(l, i);  return; }
+        const int c = link(D[(size_t)G.OFF[l] + i]);
+        for (int k = 0; k < 8; k++) assign_subtree(l + 1, c + k);
+    }
+    unsigned long long count_cube(int x0, int y0, int z0, int s) const
+    {
+        unsigned long long n = 0;
+        for (int z = z0; z < std::min(z0 + s, G.NZ); z++)
+            for (int y = y0; y < std::min(y0 + s, G.NY); y++)
+                for (int x = x0; x < std::min(x0 + s, G.NX); x++) n += sub[((size_t)z * G.NY + y) * G.NX + x];
+        return n;
+    }
+    void assign_cube(int x0, int y0, int z0, int s)
+    {
+        if (x0 >= G.NX || y0 >= G.NY || z0 >= G.NZ) return;
+        const unsigned long long n = count_cube(x0, y0, z0, s);
+        if (n == 0) return;
+        if (n <= (unsigned long long)CAP) {
+            open((uint32_t)n);
+            for (int z = z0; z < std::min(z0 + s, G.NZ); z++)
+                for (int y = y0; y < std::min(y0 + s, G.NY); y++)
+                    for (int x = x0; x < std::min(x0 + s, G.NX); x++) place_subtree(0, (z * G.NY + y) * G.NX + x);
+            return;
+        }
+        if (s == 1) { assign_subtree(0, (z0 * G.NY + y0) * G.NX + x0);  return; }
+        const int h = s / 2;
+        for (int k = 0; k < 8; k++) assign_cube(x0 + (k & 1) * h, y0 + ((k >> 1) & 1) * h, z0 + (k >> 2) * h, h);
+    }
+    void build()
+    {
+        count();
+        slotmap.assign((size_t)G.CELLS, 0xffffffffu);
+        bcell.clear();
+        bbase.assign(1, 0);
+        fill = 0;
+        for (int z = 0; z < G.NZ; z += 16)
+            for (int y = 0; y < G.NY; y += 16)
+                for (int x = 0; x < G.NX; x += 16) assign_cube(x, y, z, 16);
+        if (fill > 0) bbase.push_back((int)bcell.size());
+    }
+};
+}  // namespace
+
+static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream_t st)
+{
+    SocOctBricks &ob = g_ob[device];
+    if (ob.valid && ob.CAP == CAP && ob.cells == (size_t)G.CELLS && ob.dens_key == G.DENS) return hipSuccess;
+    std::vector<float> D((size_t)G.CELLS);
+    BCHK(hipStreamSynchronize(st));
+    BCHK(hipMemcpy(D.data(), G.DENS, (size_t)G.CELLS * 4, hipMemcpyDeviceToHost));
+    OctBuilder B(G, D, CAP);
+    B.build();
+    const int NB = (int)B.bbase.size() - 1;
+    if (NB < 1 || NB >= (1 << (32 - SOC_SLOT_BITS))) return hipErrorNotSupported;
+    std::vector<float2> DS((size_t)G.CELLS);
+    for (size_t i = 0; i < (size_t)G.CELLS; i++) { float y;  memcpy(&y, &B.slotmap[i], 4);  DS[i] = make_float2(D[i], y); }
+    BCHK(brick_alloc(&ob.DS, (size_t)G.CELLS));
+    BCHK(brick_alloc(&ob.bcell, B.bcell.size()));
+    BCHK(brick_alloc(&ob.bbase, B.bbase.size()));
+    BCHK(hipMemcpy(ob.DS, DS.data(), (size_t)G.CELLS * 8, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(ob.bcell, B.bcell.data(), B.bcell.size() * 4, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(ob.bbase, B.bbase.data(), B.bbase.size() * 4, hipMemcpyHostToDevice));
+    ob.NB = NB;  ob.CAP = CAP;  ob.cells = (size_t)G.CELLS;  ob.leaves = B.bcell.size();  ob.dens_key = G.DENS;
+    ob.valid = true;
+    if (getenv("SOC_BRICK_VERBOSE"))
+        fprintf(stderr, "soc_brick: hierarchy of %d cells, %zu leaves -> %d bricks of <= %d leaves (mean %.0f)\n",
+                G.CELLS, ob.leaves, NB, CAP, (double)ob.leaves / NB);
+    return hipSuccess;
+}
+
+// LB: log2 of the brick edge (Cartesian grids; hierarchies use bricks of <= CAP leaves).  nlaunch launches
+// (same geometry, same tallies; scalar opacities and no INT tally when nlaunch > 1) share one sweep: more
+// packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
+// others.  Returns hipErrorNotSupported when the launches cannot use bricks.
+template <bool OCT, bool DBL>
+static void soc_brick_launch_pass(int vkey, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+                                  const SocBrickArgs &A, int nwalk, int slices)
+{
+    if (lds > 64 * 1024) {                         // more dynamic LDS than the default limit: once per kernel
+        static bool raised[4] = { false, false, false, false };
+        if (!raised[vkey]) {
+            const void *f = vkey == 0 ? (const void *)soc_brick_pass<OCT, DBL, false, false> : vkey == 1 ? (const void *)soc_brick_pass<OCT, DBL, false, true>
+                          : vkey == 2 ? (const void *)soc_brick_pass<OCT, DBL, true, false> : (const void *)soc_brick_pass<OCT, DBL, true, true>;
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised[vkey] = true;
+        }
+    }
+    switch (vkey) {
+    case 0:  soc_brick_pass<OCT, DBL, false, false><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
+    case 1:  soc_brick_pass<OCT, DBL, false, true><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
+    case 2:  soc_brick_pass<OCT, DBL, true, false><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
+    default: soc_brick_pass<OCT, DBL, true, true><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
+    }
+}
+
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
                             hipStream_t st, int *passes_out)
 {
-    if (V.octree || device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
+    if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     if (nlaunch > 1 && (V.abu || V.wint)) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
     A.ev_brick = -1;
-    A.NBX = (G.NX + B - 1) / B;  A.NBY = (G.NY + B - 1) / B;  A.NBZ = (G.NZ + B - 1) / B;
-    A.NB = A.NBX * A.NBY * A.NBZ;
-    if (A.NB > 8192) return hipErrorNotSupported;
     // workgroup shape; overridable for experiments (measured on C2)
     A.T = 512;
-    A.P = 4 * A.T;
+    A.P = (V.octree ? 8 : 4) * A.T;                  // hierarchies: one chunk per brick queue (measured)
     A.KCAP = 32;
     A.FTH = 16;
+    A.CAP = 8192;
+    A.TAIL = 0;
+    if (const char *e = getenv("SOC_BRICK_TAIL")) A.TAIL = atoi(e);
     if (const char *e = getenv("SOC_BRICK_T")) A.T = atoi(e);
     if (const char *e = getenv("SOC_BRICK_P")) A.P = atoi(e);
     if (const char *e = getenv("SOC_BRICK_KCAP")) A.KCAP = atoi(e);
     if (const char *e = getenv("SOC_BRICK_FTH")) A.FTH = atoi(e);
+    if (const char *e = getenv("SOC_BRICK_CAP")) A.CAP = atoi(e);
     if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
+    if (A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS)) return hipErrorInvalidValue;
+    if (V.octree) {
+        if (G.LEVELS > 15) return hipErrorNotSupported;                  // the level shares a packet word with slot and launch
+        BCHK(soc_oct_build(device, G, A.CAP, st));
+        const SocOctBricks &ob = g_ob[device];
+        A.NBX = A.NBY = A.NBZ = 0;
+        A.NB = ob.NB;
+        A.DS = ob.DS;  A.bcell = ob.bcell;  A.bbase = ob.bbase;
+        int k = 1;
+        while ((1 << k) <= std::max(G.NX, std::max(G.NY, G.NZ))) k++;
+        A.sib_thr = ldexpf(1.0f, k - 29);
+    } else {
+        A.NBX = (G.NX + B - 1) / B;  A.NBY = (G.NY + B - 1) / B;  A.NBZ = (G.NZ + B - 1) / B;
+        A.NB = A.NBX * A.NBY * A.NBZ;
+        if (A.NB > (1 << 18)) return hipErrorNotSupported;
+    }
 
     SocSimPack K{};
     uint32_t count = 0;
@@ -598,6 +1033,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     for (int l = K.n; l <= SOC_MAXLAUNCH; l++) K.first[l] = count;
     const int NQ = A.NB + 2 * K.n + 1;
     const int maxdesc = (int)((count + A.P - 1) / A.P) + NQ + K.n;
+    A.HS = (NQ > 4096) ? 1024 : 0;
+    if (const char *e = getenv("SOC_BRICK_HS")) A.HS = atoi(e);
+    if (A.HS & (A.HS - 1)) return hipErrorInvalidValue;
 
     SocBrickBuffers &bb = g_bb[device];
     if (bb.cap_items < count) {
@@ -624,11 +1062,13 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1)); }
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
 
-    const int BV = 1 << (3 * LB);
-    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + NQ + 2 + 3 * SOC_MAXLAUNCH) * 4;
-    const size_t lds_ev = (size_t)(NQ + 8) * 4;
+    const int BV = V.octree ? A.CAP : (1 << (3 * LB));
+    const int nh = A.HS ? 2 * A.HS : NQ;
+    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL) * 4;
+    const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
-    const size_t lds_scat = (size_t)(NQ - 1) * 4;
+    const size_t lds_scat = (size_t)nh * 4;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
     const int vkey = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((count + A.P - 1) / A.P) + 3 * K.n) * slices;
@@ -642,12 +1082,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            switch (vkey) {
-            case 0:  soc_brick_pass<false, false><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
-            case 1:  soc_brick_pass<false, true><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
-            case 2:  soc_brick_pass<true, false><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
-            default: soc_brick_pass<true, true><<<maxdesc + nev, A.T, lds, st>>>(G, K, A, maxdesc, slices); break;
-            }
+            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            else             soc_brick_launch_pass<true, true>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
             Q.NB = NQ - 1;
             Q.ev_brick = A.NB;

@@ -121,8 +121,15 @@ static int flush_pending(soc_ctx *c)
     std::vector<SocSim> todo;
     todo.swap(c->pending);
     SocVariant V;
-    V.octree = 0;  V.dbl = 0;  V.abu = 0;  V.wint = 0;      // what makes a launch deferrable (see soc_sim_pb)
+    V.octree = c->G.LEVELS > 1;  V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
+    V.abu = 0;  V.wint = 0;                                  // what makes a launch deferrable (see soc_sim_pb)
     HIPCHK(c, hipSetDevice(c->device));
+    if (V.octree && todo.size() == 1 && c->exec_mode < 0) {
+        // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
+        c->last_passes = 0;
+        HIPCHK(c, soc_launch_sim_pb(c->G, todo[0], V, c->stream));
+        return SOC_OK;
+    }
     hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, c->stream, &c->last_passes);
     if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
     return SOC_OK;
@@ -268,6 +275,7 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
     }
     c->G = G;
     c->have_grid = true;
+    soc_brick_invalidate(c->device);
     HIPCHK(c, soc_launch_parents(c->G, c->dPAR, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
@@ -521,13 +529,15 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     SocSim S;
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
-    // brick sweep: Cartesian grids with enough work items to fill the chip
+    // brick sweep: enough work items to fill the chip.  Hierarchies: it pays from two launches per sweep on
+    // (256^3 roots, 4 levels: 1.9e10 steps/s with one launch, 2.8e10 with two, 4.4e10 with eight; direct kernel
+    // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && !V.octree && nb <= 8192 && c->device < 16 && c->mirror == 0;
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.abu && !V.wint));
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (octree, mirror or > 8192 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
     const bool defer = c->batching && bricks && !V.abu && !V.wint;
@@ -568,7 +578,8 @@ int soc_batch_begin(soc_ctx *c, int max_launches)
         return fail(c, SOC_ERR_ARG, "soc_batch_begin: max_launches %d (1..%d, 0 = default)", max_launches, SOC_MAXLAUNCH);
     FLUSH(c);
     c->batching = true;
-    c->batch_max = max_launches ? max_launches : 4;
+    // default: what was measured best -- 4 launches per sweep on Cartesian grids (C2), all 8 on hierarchies
+    c->batch_max = max_launches ? max_launches : ((c->have_grid && c->G.LEVELS > 1) ? SOC_MAXLAUNCH : 4);
     return SOC_OK;
 }
 

@@ -44,11 +44,49 @@ def test_brick_sweep_c32_and_sharding(lb, engine, oracle_soc):
     assert_tally_close(Tb, T, rtol=1e-5)
 
 
-def test_brick_sweep_rejects_octree(engine):
-    from soc_amd.lib import SocError
-    ref, kind, mk = cases.CASES["bg_oct8"]
-    with pytest.raises(SocError, match="not applicable"):
-        run_engine(engine, mk(), kind, exec_mode=1, brick_log2=2)
+@pytest.mark.parametrize("name", ["bg_oct8", "bg_oct4"])
+@pytest.mark.parametrize("cap,hs", [(8, 0), (100, 0), (8192, 0), (100, 64), (8, 8)])
+def test_brick_sweep_octree_matches_oracle(name, cap, hs, engine, oracle_soc, monkeypatch):
+    """hierarchies: bricks of <= cap leaves (cap 8 splits the subtree of a refined root cell of the
+    known-answer tree), tally slots from the cell -> slot map; hs: hash-table form of the arrival counts
+    (8 entries: overflows into the direct global count)"""
+    monkeypatch.setenv("SOC_BRICK_CAP", str(cap))
+    monkeypatch.setenv("SOC_BRICK_HS", str(hs))
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    Tg, Ig, st = run_engine(engine, job, kind, exec_mode=1)
+    assert engine.last_passes() > 0
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_brick_sweep_octree_abu_int_point_sources(engine, oracle_soc, monkeypatch):
+    """per-cell opacities, INT tally and point sources (inside and outside) on a hierarchy"""
+    monkeypatch.setenv("SOC_BRICK_CAP", "200")
+    oct8 = cases._oct8()
+    job = Job(oct8, cases._CSC, SOURCE=0, BATCH=25, SEED=0.2, GLOBAL=512, PSPOS=cases._PS_EXT, PS=[1.0, 2.0], PS_METHOD=0,
+              XPS=cases._XPS2, OPT=cases._opt(oct8.CELLS), WITH_INT=1, TW=1.5)
+    T, I, n = oracle_soc.sim(job, 0)
+    Tg, Ig, st = run_engine(engine, job, 0, exec_mode=1)
+    assert engine.last_passes() > 0 and st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    assert_tally_close(Ig, I, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_brick_sweep_octree_double_index(engine, oracle_soc):
+    """NX > 100 with >= 3 levels: Index() in double (DIMLIM), a range of the work items"""
+    cl = synth.octree_cloud(104, levels=3, frac=0.03, seed=5)
+    job = Job(cl, cases._CSC, ABS=2e-6, SCA=2e-5, SOURCE=1, BATCH=3, SEED=0.37)
+    g0, g1 = 40000, 44000
+    T, _, n = oracle_soc.sim(job, 0, gid0=g0, gid1=g1, nthreads=8)
+    Tg, _, st = run_engine(engine, job, 0, gid_first=g0, gid_count=g1 - g0, exec_mode=1)
+    assert engine.last_passes() > 0 and st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    Td, _, sd = run_engine(engine, job, 0, gid_first=g0, gid_count=g1 - g0, exec_mode=0)
+    assert sd["tally_events"] == n
     engine.set_exec(-1, 4)
 
 
@@ -134,3 +172,48 @@ def test_deferred_launches_flush_on_state_access(engine):
     i = engine.read_tally(1)
     assert b.sum() > 2.5 * a.sum() and i.sum() > 0
     engine.set_features(0, 0, 0)
+
+
+def test_deferred_launches_on_hierarchy(engine, oracle_soc):
+    """automatic mode on a hierarchy: launches deferred inside soc_batch_begin/end share one brick sweep
+    (a single one goes to the direct kernel); tallies = the oracle's sum of the launches"""
+    cl = synth.octree_cloud(40, levels=3, frac=0.1, seed=3)       # 8*6*40^2 work items: above the automatic threshold
+    d6, csc6 = synth.hg_scattering_table(0.6)
+    d0, csc0 = synth.hg_scattering_table(0.1)
+    jobs = [Job(cl, csc6, ABS=2e-5, SCA=6e-5, SOURCE=1, BATCH=2, SEED=0.3711, BG=1.0, TW=1.0),
+            Job(cl, csc0, ABS=5e-5, SCA=2e-5, SOURCE=1, BATCH=1, SEED=0.11, BG=2.5, TW=0.5),
+            Job(cl, csc6, ABS=1e-5, SCA=9e-5, SOURCE=1, BATCH=2, SEED=0.77, BG=0.7, TW=2.0)]
+    T = np.zeros(cl.CELLS, np.float32)
+    n = 0
+    for j in jobs:
+        _, _, k = oracle_soc.sim(j, 0, TABS=T, nthreads=8)
+        n += k
+
+    def run(njobs, batch):
+        engine.set_cloud(cl)
+        engine.set_features(0, 0, 0)
+        engine.set_opt(None)
+        engine.set_mirror(0)
+        engine.set_exec(-1, 4)
+        engine.zero(0)
+        engine.stats(reset=True)
+        if batch:
+            engine.batch_begin(0)
+        for j in jobs[:njobs]:
+            engine.set_scatter_table(j.DSC, j.CSC)
+            engine.set_optical(j.ABS, j.SCA)
+            engine.sim_pb(1, j.PACKETS, j.BATCH, j.SEED, j.BG, j.TW, GLOBAL=j.GLOBAL)
+        if batch:
+            engine.batch_end()
+        engine.sync()
+        return engine.read_tally(0), engine.stats(), engine.last_passes()
+
+    Tb, sb, pb = run(3, True)
+    assert pb > 0, "deferred launches on a hierarchy did not use the brick sweep"
+    assert sb["tally_events"] == n
+    assert_tally_close(Tb, T, rtol=1e-5)
+    _, s1, p1 = run(1, True)
+    assert p1 == 0, "a single deferred launch on a hierarchy goes to the direct kernel"
+    Td, sd, pd = run(3, False)
+    assert pd == 0 and sd["tally_events"] == n
+    assert_tally_close(Td, T, rtol=1e-5)
