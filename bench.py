@@ -51,6 +51,19 @@ def c2_workload():
                 cloud=cloud, DSC=dsc, CSC=csc, ABS=C2_ABS, SCA=C2_SCA, launch=L, SEED=0.7853981634)
 
 
+def c3_workload():
+    """BASELINE.json configs[2], the background part: 256^3-root octree with 3 refinement levels (the densest
+    10 % of the cells of every level refined: 4.95e7 cells, 4.54e7 leaves), `bgpackets 1e9` -> 3 145 728 work
+    items x BATCH 318, same dust row at GL = 0.005 pc (same optical depth across the model as C2)."""
+    cloud = synth.octree_cloud(256, levels=4, frac=0.10, seed=1234)
+    dsc, csc = synth.hg_scattering_table(0.6, 2500)
+    L = launch.bg_launch(1000000000, cloud.AREA)
+    return dict(name="C3 (background part): 256^3-root octree, 4 levels (49.5e6 cells), 1 frequency per step, bgpackets 1e9 "
+                     "(%d work items x BATCH %d = %d packets), isotropic background, HG g=0.6 2500-bin scattering table, "
+                     "noabsorbed" % (L["GLOBAL"], L["BATCH"], L["GLOBAL"] * L["BATCH"]),
+                cloud=cloud, DSC=dsc, CSC=csc, ABS=0.5 * C2_ABS, SCA=0.5 * C2_SCA, launch=L, SEED=0.7853981634)
+
+
 def host_cores():
     """CPU threads this process may really use: scheduler affinity capped by the cgroup quota
     (the GPU box exposes 256 hardware threads but grants a 16-CPU share)."""
@@ -78,6 +91,8 @@ def cpu_baseline(work, budget_s=15.0):
               SEED=launch.launch_seed(work["SEED"], 0), BG=1.0, TW=1.0, GLOBAL=L["GLOBAL"], DSC=work["DSC"])
     kind = "reference"
     try:
+        if work["cloud"].LEVELS > 1:
+            raise RuntimeError("reference builds bake the geometry in; only the C2 one is kept")
         runner = Ref("c128")
         run = lambda stride: runner.sim(job, 0, 0, L["GLOBAL"], nthreads=ncores, stride=stride)      # noqa: E731
     except Exception:
@@ -124,8 +139,11 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
+                         "0 = the engine's default (4 on Cartesian grids, 8 on hierarchies)")
+    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
+                    help="C2 = BASELINE.json configs[1] (the headline); C3 = the background part of configs[2]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +163,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    work = c2_workload()
+    work = c3_workload() if args.workload == "C3" else c2_workload()
+    if args.in_flight == 0:
+        args.in_flight = 8 if work["cloud"].LEVELS > 1 else 4
     cloud, L = work["cloud"], work["launch"]
     eng = Engine(local_rank)
     eng.set_cloud(cloud)
@@ -244,7 +264,7 @@ def main():
                            "replicas with per-rank seeds + 1 RCCL all-reduce of TABS after the K steps (TABS integrates over frequency on the device)" if args.scaling == "weak"
                            else "work-item ranges of one launch + 1 RCCL all-reduce of TABS after the K steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic() if args.workload == "C2" else None,
                          "kernel": kernel_name,
                          "kernel_ms": kavg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
