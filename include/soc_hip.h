@@ -121,6 +121,25 @@ int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
 int soc_batch_begin(soc_ctx *ctx, int max_launches);
 int soc_batch_end(soc_ctx *ctx);
 
+/* ---- region of interest of nested runs (ini keys roi, roisave, roiload, roipac, roinside) ---- */
+
+/* replaces -D WITH_ROI_SAVE -D ROI_STEP -D ROI_NSIDE and ROI_buf / ROI_SAVE_buf (ASOC.py:346,927-944): from now on
+ * soc_sim_pb and soc_sim_cl add every packet that steps into ROI = [x0,x1,y0,y1,z0,z1] (root cells, inclusive) to a
+ * record [surface element, Healpix pixel of its direction] (kernel_ASOC.c:547-562,615-642, 1436-1535; InRoi
+ * kernel_ASOC_aux.c:1031-1048), ROI_STEP elements per root-cell edge, NSIDE = ROI_NSIDE, RING order.
+ * The record is zeroed here; ROI = NULL turns recording off.  Direct kernel only (the brick sweep stands aside). */
+int soc_set_roi_save(soc_ctx *ctx, const int32_t *ROI, int ROI_STEP, int ROI_NSIDE);
+/* replaces enqueue_copy(ROI_SAVE_buf, zeros) per frequency (ASOC.py:1301-1302) */
+int soc_roi_zero(soc_ctx *ctx);
+/* replaces enqueue_copy(tmp, ROI_SAVE_buf) (ASOC.py:1468-1471); n = (nx*ny + ny*nz + nz*nx) * 12 * ROI_NSIDE^2 with
+ * n? = (ROI[2?+1] - ROI[2?] + 1) * ROI_STEP */
+int soc_roi_read(soc_ctx *ctx, float *out, long n);
+/* replaces -D WITH_ROI_LOAD and ROI_DIM_buf / ROI_LOAD_buf (ASOC.py:909-925,1419-1421): the record of one frequency,
+ * LOAD[nelem, 12*ROI_NSIDE^2] photons (already scaled by the host) with nelem = DIM[0]*DIM[1] + DIM[1]*DIM[2] +
+ * DIM[2]*DIM[0] surface elements, sent by soc_sim_pb(SOURCE = 3, PACKETS = nelem, BATCH = k * 12*ROI_NSIDE^2,
+ * GLOBAL >= 100 * nelem) (kernel_ASOC.c:97-105,141-179,469-501).  LOAD = NULL turns it off. */
+int soc_set_roi_load(soc_ctx *ctx, const int32_t *DIM, int ROI_NSIDE, const float *LOAD);
+
 /* replaces the HPBG_buf / HPBGP_buf uploads (ASOC.py:1196-1214): the Healpix sky of the current
  * frequency in photons per package, 49152 floats (NSIDE 64, RING order); HPBGP = cumulative
  * pixel probability for `hpbg ... weighted` runs (-D HPBG_WEIGHTED=1) or NULL */

@@ -52,12 +52,12 @@ def build_oracle(force=False):
 
 def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
              USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
-             GL=0.01, HPBG_WEIGHTED=0, WITH_ALI=0):
+             GL=0.01, HPBG_WEIGHTED=0, WITH_ALI=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0):
     """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
     d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=WITH_ALI, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
              CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS), WITH_ABU=WITH_ABU, ROI_MAP=0, MAX_SPLIT=4300,
-             SELEM=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0,
+             SELEM=0, ROI_STEP=ROI_STEP, ROI_NSIDE=ROI_NSIDE, WITH_ROI_LOAD=WITH_ROI_LOAD, WITH_ROI_SAVE=WITH_ROI_SAVE,
              AXY="%.5ff" % (NX * NY / AREA), AXZ="%.5ff" % (NX * NZ / AREA), AYZ="%.5ff" % (NY * NZ / AREA),
              LEVELS=LEVELS, LENGTH="%.5ef" % (GL * 3.08567758e18), DO_SPLIT=0, POLSTAT=0,
              SW_A="0.000e+00f", SW_B="0.000e+00f", STEP_WEIGHT=-1, DIR_WEIGHT=-1, DW_A="0.000e+00f",
@@ -89,7 +89,8 @@ def build_ref(tag, force=False, **model):
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
                            "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
-    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", shim, "-o", sobj])
+    sdefs = ["-DREF_ROI_LOAD=%d" % int(model.get("WITH_ROI_LOAD", 0)), "-DREF_ROI_SAVE=%d" % int(model.get("WITH_ROI_SAVE", 0))]
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + sdefs + ["-c", shim, "-o", sobj])
     subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
     os.remove(kobj)
     os.remove(sobj)
@@ -267,6 +268,12 @@ def ref_models():
         "c8hpw":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, HPBG_WEIGHTED=1),
         "oct8hpw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, HPBG_WEIGHTED=1, NOABSORBED=0),
     }
+    # region of interest: packets entering ROI saved / loaded at the surface (ROI_STEP and ROI_NSIDE are -D constants)
+    m["c8roi"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ROI_SAVE=1, ROI_STEP=2, ROI_NSIDE=2)
+    m["oct8roi"] = dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, WITH_ROI_SAVE=1, ROI_STEP=1, ROI_NSIDE=4)
+    m["c8roil"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ROI_LOAD=1, ROI_NSIDE=2)
+    m["oct8roils"] = dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, WITH_ROI_LOAD=1, WITH_ROI_SAVE=1,
+                          ROI_STEP=2, ROI_NSIDE=2, NOABSORBED=0)
     for k in (1, 2, 4, 5):
         m["c8ps%d" % k] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=k, NO_PS=2)
     m["c8ps0"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=0, NO_PS=2)

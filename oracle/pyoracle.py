@@ -39,6 +39,8 @@ class OrcModel(C.Structure):
         ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("DSC", _F), ("OUT", _F), ("XPS_AS_FLOAT", C.c_int),
         ("HPBG_WEIGHTED", C.c_int), ("HPBG", _F), ("HPBGP", _F), ("MIRROR", C.c_int),
         ("WITH_ALI", C.c_int), ("XAB", _F), ("EMINDEX", _I),
+        ("WITH_ROI_SAVE", C.c_int), ("ROI", C.c_int * 6), ("ROI_STEP", C.c_int), ("ROI_NSIDE", C.c_int), ("ROI_SAVE", _F),
+        ("WITH_ROI_LOAD", C.c_int), ("ROI_DIM", C.c_int * 3), ("ROI_LOAD", _F),
     ]
 
 
@@ -51,6 +53,7 @@ class RefArgs(C.Structure):
         ("DENS", _F), ("EMIT", _F), ("TABS", _F), ("DSC", _F), ("CSC", _F), ("XAB", _F), ("EMWEI", _F),
         ("INT", _F), ("INTX", _F), ("INTY", _F), ("INTZ", _F), ("OPT", _F), ("ABU", _F),
         ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("EMINDEX", _I), ("HPBG", _F), ("HPBGP", _F),
+        ("ROI_DIM", _I), ("ROI_LOAD", _F), ("ROI", _I), ("ROI_SAVE", _F),
     ]
 
 
@@ -65,8 +68,18 @@ class Job:
     def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
                  GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
                  EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None, MIRROR=0,
-                 WITH_ALI=0, EMINDEX=None):
+                 WITH_ALI=0, EMINDEX=None, ROI=None, ROI_STEP=1, ROI_NSIDE=2, ROI_LOAD=None, ROI_DIM=None):
         self.cloud = cloud
+        # region of interest: ROI = [x0,x1,y0,y1,z0,z1] turns on WITH_ROI_SAVE; ROI_LOAD [elements, 12*NSIDE^2]
+        # with ROI_DIM = (nx, ny, nz) of its surface discretisation is the SOURCE == 3 input (WITH_ROI_LOAD)
+        self.ROI = None if ROI is None else np.ascontiguousarray(ROI, np.int32)
+        self.ROI_STEP, self.ROI_NSIDE = int(ROI_STEP), int(ROI_NSIDE)
+        self.ROI_LOAD = None if ROI_LOAD is None else np.ascontiguousarray(ROI_LOAD, np.float32)
+        self.ROI_DIM = None if ROI_DIM is None else np.ascontiguousarray(ROI_DIM, np.int32)
+        self.ROI_SAVE = None
+        if self.ROI is not None:
+            n = [(self.ROI[2 * i + 1] - self.ROI[2 * i] + 1) * self.ROI_STEP for i in range(3)]
+            self.ROI_SAVE = np.zeros((n[0] * n[1] + n[1] * n[2] + n[2] * n[0]) * 12 * self.ROI_NSIDE ** 2, np.float32)
         self.WITH_ALI = int(WITH_ALI)
         self.EMINDEX = None if EMINDEX is None else np.ascontiguousarray(EMINDEX, np.int32)
         self.XAB = np.zeros(cloud.CELLS, np.float32)
@@ -172,6 +185,15 @@ class Oracle:
         m.WITH_ALI, m.XAB, m.EMINDEX = job.WITH_ALI, _fp(job.XAB), _ip(job.EMINDEX)
         m.HPBG_WEIGHTED = int(job.HPBGP is not None)
         m.HPBG, m.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
+        m.ROI_STEP, m.ROI_NSIDE = job.ROI_STEP, job.ROI_NSIDE
+        m.WITH_ROI_SAVE = int(job.ROI is not None)
+        if job.ROI is not None:
+            m.ROI = (C.c_int * 6)(*[int(v) for v in job.ROI])
+            m.ROI_SAVE = _fp(job.ROI_SAVE)
+        m.WITH_ROI_LOAD = int(job.ROI_LOAD is not None)
+        if job.ROI_LOAD is not None:
+            m.ROI_DIM = (C.c_int * 3)(*[int(v) for v in job.ROI_DIM])
+            m.ROI_LOAD = _fp(job.ROI_LOAD)
         return m
 
     def parents(self, job):
@@ -293,6 +315,11 @@ class Ref:
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
         assert job.MIRROR == m.get("MIRROR", 0)
         assert job.WITH_ALI == m.get("WITH_ALI", 0)
+        assert int(job.ROI is not None) == m.get("WITH_ROI_SAVE", 0) and int(job.ROI_LOAD is not None) == m.get("WITH_ROI_LOAD", 0)
+        if job.ROI is not None:
+            assert job.ROI_STEP == m.get("ROI_STEP", 0)
+        if job.ROI is not None or job.ROI_LOAD is not None:
+            assert job.ROI_NSIDE == m.get("ROI_NSIDE", 16)
 
     def seed(self, SEED, gid):
         x, c = C.c_uint32(), C.c_uint32()
@@ -387,6 +414,8 @@ class Ref:
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         a.EMINDEX = _ip(job.EMINDEX) if job.EMINDEX is not None else _ip(idummy)
         a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP if job.HPBGP is not None else dummy)
+        a.ROI_DIM, a.ROI_LOAD = _ip(job.ROI_DIM), _fp(job.ROI_LOAD)
+        a.ROI, a.ROI_SAVE = _ip(job.ROI), _fp(job.ROI_SAVE)
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sim(C.byref(a), kind, gid0, gid1, stride, nthreads)
         return TABS, INT

@@ -31,7 +31,14 @@ void SimRAM_PB(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float
                float3 *PSPOS, float *PS, float TW, int *LCELLS, int *OFF, int *PAR, float *DENS,
                float *EMIT, float *TABS, float *DSC, float *CSC, float *XAB, float *EMWEI,
                float *INT, float *INTX, float *INTY, float *INTZ, float *OPT, float *ABU,
-               int *XPS_NSIDE, int *XPS_SIDE, float *XPS_AREA);
+               int *XPS_NSIDE, int *XPS_SIDE, float *XPS_AREA
+#if REF_ROI_LOAD
+               , int *ROI_DIM, float *ROI_LOAD
+#endif
+#if REF_ROI_SAVE
+               , int *ROI, float *ROI_SAVE
+#endif
+               );
 void EqTemperature(int level, float adhoc, float kE, float Emin, int NE, int *OFF, int *LCELLS, float *TTT, float *DENS,
                    float *EMIT, float *TNEW);
 void Emission2(int c0, int c1, int nfreq, float *FREQ, float *FABS, float *DENS, float *T, float *EMIT);
@@ -41,7 +48,11 @@ void SimRAM_HP(int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float
 void SimRAM_CL(int SOURCE, int PACKETS, int BATCH, float SEED, float *ABS, float *SCA, float TW,
                int *LCELLS, int *OFF, int *PAR, float *DENS, float *EMIT, float *TABS, float *DSC,
                float *CSC, float *XAB, float *EMWEI, float *INT, float *INTX, float *INTY,
-               float *INTZ, int *EMINDEX, float *OPT, float *ABU);
+               float *INTZ, int *EMINDEX, float *OPT, float *ABU
+#if REF_ROI_SAVE
+               , int *ROI, float *ROI_SAVE
+#endif
+               );
 }
 
 struct ref_args {
@@ -56,6 +67,8 @@ struct ref_args {
     float *XPS_AREA;
     int   *EMINDEX;
     float *HPBG, *HPBGP;     // Healpix sky of the current frequency, cumulative pixel probability
+    int   *ROI_DIM;  float *ROI_LOAD;   // WITH_ROI_LOAD builds
+    int   *ROI;      float *ROI_SAVE;   // WITH_ROI_SAVE builds
 };
 
 static void run_range(const ref_args *a, int kind, int gid0, int gid1, int stride = 1)
@@ -67,14 +80,25 @@ static void run_range(const ref_args *a, int kind, int gid0, int gid1, int strid
             SimRAM_PB(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->BG,
                       (float3 *)a->PSPOS, a->PS, a->TW, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
                       a->TABS, a->DSC, a->CSC, a->XAB, a->EMWEI, a->INT, a->INTX, a->INTY, a->INTZ,
-                      a->OPT, a->ABU, a->XPS_NSIDE, a->XPS_SIDE, a->XPS_AREA);
+                      a->OPT, a->ABU, a->XPS_NSIDE, a->XPS_SIDE, a->XPS_AREA
+#if REF_ROI_LOAD
+                      , a->ROI_DIM, a->ROI_LOAD
+#endif
+#if REF_ROI_SAVE
+                      , a->ROI, a->ROI_SAVE
+#endif
+                      );
         else if (kind == 2)
             SimRAM_HP(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->TW, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
                       a->TABS, a->DSC, a->CSC, a->XAB, a->INT, a->INTX, a->INTY, a->INTZ, a->OPT, a->HPBG, a->HPBGP, a->ABU);
         else
             SimRAM_CL(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->TW, a->LCELLS,
                       a->OFF, a->PAR, a->DENS, a->EMIT, a->TABS, a->DSC, a->CSC, a->XAB, a->EMWEI,
-                      a->INT, a->INTX, a->INTY, a->INTZ, a->EMINDEX, a->OPT, a->ABU);
+                      a->INT, a->INTX, a->INTY, a->INTZ, a->EMINDEX, a->OPT, a->ABU
+#if REF_ROI_SAVE
+                      , a->ROI, a->ROI_SAVE
+#endif
+                      );
     }
 }
 

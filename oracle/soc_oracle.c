@@ -117,6 +117,13 @@ typedef struct {
     int   WITH_ALI;                   /* SimRAM_CL: absorptions in the emitting cell go to XAB           */
     float *XAB;                       /* [CELLS]                                                          */
     const int *EMINDEX;               /* [CELLS] USE_EMWEIGHT==2: cells to emit from, terminated by -1    */
+    /* region of interest (nested runs): packets entering ROI = [x0,x1,y0,y1,z0,z1] (root cells, inclusive) are
+     * recorded per surface element and Healpix direction (WITH_ROI_SAVE); SOURCE == 3 emits such a record from
+     * the model surface (WITH_ROI_LOAD) */
+    int   WITH_ROI_SAVE, ROI[6], ROI_STEP, ROI_NSIDE;
+    float *ROI_SAVE;                  /* [elements * 12*ROI_NSIDE^2]                                      */
+    int   WITH_ROI_LOAD, ROI_DIM[3];
+    const float *ROI_LOAD;            /* [elements * 12*ROI_NSIDE^2] photons, already scaled by the host  */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -372,6 +379,61 @@ static void Mirror(const orc_model *M, f3 *pos, f3 *dir, int *level, int *ind)
 }
 
 /* e_index: global index of the emitting cell (WITH_ALI, kernel_ASOC.c:1394-1396) or -1 */
+static void RootPos(const orc_model *M, f3 *POS, const int ilevel, const int iind);
+static int  angles2pixel_ring(const int nside, float phi, float theta);
+static void pixel2angles_ring(const int nside, const int ipix, float *phi, float *theta);
+
+/* InRoi (kernel_ASOC_aux.c:1031-1048): root-grid index of the root cell above (level, ind) if that cell lies in
+ * ROI, else -1.  A packet that has left the model (ind < 0, level 0) is outside: the reference's arithmetic on
+ * i = -1 gives i % NX = -1 < ROI[0]. */
+static int InRoi(const orc_model *M, int level, int ind)
+{
+    const int NX = M->NX, NY = M->NY;
+    int i = ind, j, k = level;
+    if (ind < 0) return -1;
+    while (k > 0) { i = M->PAR[M->OFF[k] + i - NX * NY * M->NZ];  k--; }
+    k = i / (NX * NY);
+    j = (i / NX) % NY;
+    if (((i % NX) >= M->ROI[0]) && ((i % NX) <= M->ROI[1]) && (j >= M->ROI[2]) && (j <= M->ROI[3]) && (k >= M->ROI[4]) && (k <= M->ROI[5]))
+        return i;
+    return -1;
+}
+
+/* a packet has stepped into ROI: kernel_ASOC.c:618-642 (SimRAM_PB), :1510-1535 (SimRAM_CL).  The element index
+ * `ii` is uninitialised in the reference when no border test matches (the position after the step is within PEPS
+ * of the face it came through, so one always does); 0 here, as in the zero-initialised reference builds. */
+static void roi_save(const orc_model *M, f3 POS, f3 DIR, int level, int ind, float PHOTONS)
+{
+    const int *ROI = M->ROI, ROI_STEP = M->ROI_STEP, ROI_NSIDE = M->ROI_NSIDE;
+    const int ROI_NX = (ROI[1] - ROI[0] + 1) * ROI_STEP, ROI_NY = (ROI[3] - ROI[2] + 1) * ROI_STEP, ROI_NZ = (ROI[5] - ROI[4] + 1) * ROI_STEP;
+    int ii = 0, jj;
+    f3  RPOS = POS;
+    RootPos(M, &RPOS, level, ind);
+    if ((RPOS.x < (ROI[0] + 1.0e-3f)) || (RPOS.x > (ROI[1] + 0.999f))) {
+        ii = clampi((int)M_FLOOR((RPOS.y - ROI[2]) * ROI_STEP), 0, ROI_NY - 1);
+        jj = clampi((int)M_FLOOR((RPOS.z - ROI[4]) * ROI_STEP), 0, ROI_NZ - 1);
+        ii = ii + ROI_NY * jj;
+    }
+    if ((RPOS.y < (ROI[2] + 1.0e-3f)) || (RPOS.y > (ROI[3] + 0.999f))) {
+        ii = clampi((int)M_FLOOR((RPOS.x - ROI[0]) * ROI_STEP), 0, ROI_NX - 1);
+        jj = clampi((int)M_FLOOR((RPOS.z - ROI[4]) * ROI_STEP), 0, ROI_NZ - 1);
+        ii = ROI_NY * ROI_NZ + ii + ROI_NX * jj;
+    }
+    if ((RPOS.z < (ROI[4] + 1.0e-3f)) || (RPOS.z > (ROI[5] + 0.999f))) {
+        ii = clampi((int)M_FLOOR((RPOS.x - ROI[0]) * ROI_STEP), 0, ROI_NX - 1);
+        jj = clampi((int)M_FLOOR((RPOS.y - ROI[2]) * ROI_STEP), 0, ROI_NY - 1);
+        ii = ROI_NY * ROI_NZ + ROI_NX * ROI_NZ + ii + ROI_NX * jj;
+    }
+    {
+        const float theta = M_ACOS(DIR.z);
+        const float phi   = M_ATAN2(DIR.y, DIR.x);
+        jj = angles2pixel_ring(ROI_NSIDE, phi, theta);
+    }
+    ii = clampi(ii, 0, ROI_NX * ROI_NY + ROI_NY * ROI_NZ + ROI_NZ * ROI_NX - 1);
+    jj = clampi(jj, 0, 12 * ROI_NSIDE * ROI_NSIDE - 1);
+    tally(M, M->ROI_SAVE, ii * 12 * ROI_NSIDE * ROI_NSIDE + jj, PHOTONS);
+}
+
 static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PHOTONS,
                         int level, int ind, int cl_order, int e_index)
 {
@@ -393,10 +455,13 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
     tau = 0.0f;
     free_path = -M_LOG(Rand(rng));
     steps = 0;
+    int roi = -1, oroi = -1;
+    if (M->WITH_ROI_SAVE) roi = oroi = InRoi(M, level, ind);            /* kernel_ASOC.c:550, :1439 */
 
     while (ind >= 0) {
         tau = 0.0f;
         while (ind >= 0) {
+            oroi   = roi;
             oind   = OFF[level] + ind;
             ind0   = ind;
             level0 = level;
@@ -420,6 +485,10 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
             nt++;
             PHOTONS *= M_EXP(-tauA);
             tau += dtau;
+            if (M->WITH_ROI_SAVE) {                                      /* only at the end of a full step */
+                roi = InRoi(M, level, ind);
+                if ((roi >= 0) && (oroi < 0)) roi_save(M, POS, DIR, level, ind, PHOTONS);
+            }
             if (!cl_order) {
                 /* failed-step guard exists only in SimRAM_PB (kernel_ASOC.c:649-683) */
                 if ((level == level0) && (ind == ind0)) {
@@ -666,7 +735,60 @@ static long sim_pb_workitem(const orc_model *M, int id)
 
     seed_workitem(&rng, M->SEED, (uint64_t)id);
     if ((SOURCE == 1) && (id >= (8 * AREA))) return 0;
-    if (SOURCE == 3) return 0;
+    if (SOURCE == 3) {
+        /* packets recorded by an enclosing run, sent in from the model surface (kernel_ASOC.c:97-105,141-179,
+         * 469-501): 100 work items per surface element of the file's discretisation (PACKETS = number of
+         * elements), BATCH = a multiple of the Healpix pixel count, a pixel per packet in turn */
+        if (!M->WITH_ROI_LOAD) return 0;
+        if (id >= (100 * M->PACKETS)) return 0;
+        const int *RD = M->ROI_DIM, NS = M->ROI_NSIDE;
+        const int ielem = id % M->PACKETS;
+        int   iside = ielem;
+        float DX = 0.0f, DY = 0.0f;
+        const float rd = NX / ((float)RD[0]);
+        if (iside < (RD[1] * RD[2])) {
+            DX = ((iside % RD[1]) + 0.5f) * rd;  DY = ((iside / RD[1]) + 0.5f) * rd;  iside = 0;
+        } else {
+            iside -= (RD[1] * RD[2]);
+            if (iside < (RD[0] * RD[2])) {
+                DX = ((iside % RD[0]) + 0.5f) * rd;  DY = ((iside / RD[0]) + 0.5f) * rd;  iside = 1;
+            } else {
+                iside -= (RD[0] * RD[2]);
+                if (iside < (RD[0] * RD[1])) {
+                    DX = ((iside % RD[0]) + 0.5f) * rd;  DY = ((iside / RD[0]) + 0.5f) * rd;  iside = 2;
+                }
+            }
+        }
+        const float X0 = (float)(NS * NS * 12.0 / (100.0 * BATCH));
+        for (int III = 0; III < BATCH; III++) {
+            float v1, v2;
+            ind = III % (12 * NS * NS);
+            PHOTONS = X0 * M->ROI_LOAD[(long)ielem * 12 * NS * NS + ind];
+            if (PHOTONS <= 0.0f) continue;
+            pixel2angles_ring(NS, ind, &v1, &v2);
+            v1 += (Rand(&rng) - 0.5f) * 0.05f;
+            v2 += (Rand(&rng) - 0.5f) * 0.05f;
+            DIR.x = M_SIN(v2) * M_COS(v1);
+            DIR.y = M_SIN(v2) * M_SIN(v1);
+            DIR.z = M_COS(v2);
+            if (iside == 0) {
+                POS.y = DX + (-0.49f + 0.98f * Rand(&rng)) * rd;  POS.z = DY + (-0.49f + 0.98f * Rand(&rng)) * rd;
+                POS.x = (DIR.x > 0.0f) ? (PEPS) : (NX - PEPS);
+            }
+            if (iside == 1) {
+                POS.x = DX + (-0.49f + 0.98f * Rand(&rng)) * rd;  POS.z = DY + (-0.49f + 0.98f * Rand(&rng)) * rd;
+                POS.y = (DIR.y > 0.0f) ? (PEPS) : (NY - PEPS);
+            }
+            if (iside == 2) {
+                POS.x = DX + (-0.49f + 0.98f * Rand(&rng)) * rd;  POS.y = DY + (-0.49f + 0.98f * Rand(&rng)) * rd;
+                POS.z = (DIR.z > 0.0f) ? (PEPS) : (NZ - PEPS);
+            }
+            IndexG(M, &POS, &level, &ind);
+            nt += walk_packet(M, &rng, POS, DIR, PHOTONS, level, ind, 0, -1);
+            ind = -1;
+        }
+        return nt;
+    }
     pb_surface_element(M, id, &E);
     for (int III = 0; III < BATCH; III++) {
         pb_create(M, &E, III, &rng, &POS, &DIR, &PHOTONS, &level, &ind);

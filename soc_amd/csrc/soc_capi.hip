@@ -40,6 +40,10 @@ struct soc_ctx {
     int   *dEMINDEX = nullptr;
     bool   have_emit = false, have_emindex = false, with_ali = false;
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
+    SocRoi roi{};                                 // region of interest (host copy of *dRoi)
+    SocRoi *dRoi = nullptr;
+    float *dRoiSave = nullptr, *dRoiLoad = nullptr;
+    size_t roi_save_n = 0, roi_load_cap = 0;
     bool   have_hpbg = false, hpbg_weighted = false;
     // tallies
     float *dTABS = nullptr, *dINT = nullptr;
@@ -173,7 +177,8 @@ int soc_create(int device, soc_ctx **out)
     if ((e = hipMalloc((void **)&c->dSeedTab, 1024 * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMemcpy(c->dSeedTab, tab.data(), 1024 * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc((void **)&c->dStats, 3 * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(c->dStats, 0, 3 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemsetAsync(c->dStats, 0, 3 * sizeof(unsigned long long), c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         int r = fail(nullptr, SOC_ERR_HIP, "soc_create: %s", hipGetErrorString(e));
         soc_destroy(c);
         return r;
@@ -193,7 +198,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -258,13 +263,13 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
     HIPCHK(c, hipMemcpy(c->dDENS, DENS, (size_t)cells * 4, hipMemcpyHostToDevice));
     c->npar = cells - nxyz;
     HIPCHK(c, dev_alloc(&c->dPAR, (size_t)c->npar));
-    HIPCHK(c, hipMemset(c->dPAR, 0, (size_t)(c->npar ? c->npar : 1) * 4));
+    HIPCHK(c, hipMemsetAsync(c->dPAR, 0, (size_t)(c->npar ? c->npar : 1) * 4, c->stream));
     G.DENS = c->dDENS;
     G.PAR = c->dPAR;
     if ((int64_t)G.CELLS != c->G.CELLS || !c->have_grid) {
         // tallies follow the cell count (unless the caller bound its own memory)
-        if (c->own_TABS || !c->dTABS) { c->dTABS = nullptr; HIPCHK(c, dev_alloc(&c->dTABS, (size_t)cells)); c->own_TABS = true; HIPCHK(c, hipMemset(c->dTABS, 0, (size_t)cells * 4)); }
-        if (c->own_INT || !c->dINT) { c->dINT = nullptr; HIPCHK(c, dev_alloc(&c->dINT, (size_t)cells)); c->own_INT = true; HIPCHK(c, hipMemset(c->dINT, 0, (size_t)cells * 4)); }
+        if (c->own_TABS || !c->dTABS) { c->dTABS = nullptr; HIPCHK(c, dev_alloc(&c->dTABS, (size_t)cells)); c->own_TABS = true; HIPCHK(c, hipMemsetAsync(c->dTABS, 0, (size_t)cells * 4, c->stream)); }
+        if (c->own_INT || !c->dINT) { c->dINT = nullptr; HIPCHK(c, dev_alloc(&c->dINT, (size_t)cells)); c->own_INT = true; HIPCHK(c, hipMemsetAsync(c->dINT, 0, (size_t)cells * 4, c->stream)); }
         if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
         c->have_emit = false;
         // everything else that is sized by the cell count
@@ -374,7 +379,7 @@ int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
     if (!c->have_emit) {
         HIPCHK(c, dev_alloc(&c->dEMIT, n));
         HIPCHK(c, dev_alloc(&c->dEMWEI, n));
-        HIPCHK(c, hipMemset(c->dEMWEI, 0, n * 4));
+        HIPCHK(c, hipMemsetAsync(c->dEMWEI, 0, n * 4, c->stream));
         c->have_emit = true;
     }
     HIPCHK(c, hipMemcpyAsync(c->dEMIT, EMIT, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -406,7 +411,7 @@ int soc_set_ali(soc_ctx *c, int with_ali)
     HIPCHK(c, hipSetDevice(c->device));
     if (with_ali && !c->dXAB) {
         HIPCHK(c, dev_alloc(&c->dXAB, (size_t)c->G.CELLS));
-        HIPCHK(c, hipMemset(c->dXAB, 0, (size_t)c->G.CELLS * 4));
+        HIPCHK(c, hipMemsetAsync(c->dXAB, 0, (size_t)c->G.CELLS * 4, c->stream));
     }
     c->with_ali = with_ali != 0;
     return SOC_OK;
@@ -524,20 +529,29 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     if (!c) return SOC_ERR_ARG;
     int r = check_launch(c, "soc_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
-    if (SOURCE != 0 && SOURCE != 1) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE=%d (0 point sources, 1 background)", SOURCE);
+    if (SOURCE != 0 && SOURCE != 1 && SOURCE != 3)
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE=%d (0 point sources, 1 background, 3 packets of soc_set_roi_load)", SOURCE);
+    if (SOURCE == 3) {
+        if (!c->roi.load) return fail(c, SOC_ERR_STATE, "soc_sim_pb: SOURCE 3 needs soc_set_roi_load");
+        const int npix = 12 * c->roi.NSIDE * c->roi.NSIDE;
+        if (PACKETS != c->roi.NELEM) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE 3 takes PACKETS = %d surface elements, got %d", c->roi.NELEM, PACKETS);
+        if (BATCH % npix) return fail(c, SOC_ERR_ARG, "soc_sim_pb: SOURCE 3 takes BATCH = a multiple of the %d Healpix pixels, got %d", npix, BATCH);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     SocSim S;
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
+    S.ROI = (c->roi.save || c->roi.load) ? c->dRoi : nullptr;
     // brick sweep: enough work items to fill the chip.  Hierarchies: it pays from two launches per sweep on
     // (256^3 roots, 4 levels: 1.9e10 steps/s with one launch, 2.8e10 with two, 4.4e10 with eight; direct kernel
     // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
+                  && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.abu && !V.wint));
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
     const bool defer = c->batching && bricks && !V.abu && !V.wint;
@@ -618,6 +632,99 @@ int soc_set_hpbg(soc_ctx *c, const float *BG, const float *HPBGP)
     return SOC_OK;
 }
 
+// ---- region of interest (roi / roisave / roiload keys) ----
+
+static int roi_upload(soc_ctx *c)
+{
+    if (!c->dRoi) HIPCHK(c, hipMalloc((void **)&c->dRoi, sizeof(SocRoi)));
+    c->roi.SAVE = c->dRoiSave;
+    c->roi.LOAD = c->dRoiLoad;
+    HIPCHK(c, hipMemcpyAsync(c->dRoi, &c->roi, sizeof(SocRoi), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_roi_save(soc_ctx *c, const int32_t *ROI, int ROI_STEP, int ROI_NSIDE)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!ROI) {                                             // off
+        c->roi.save = 0;
+        c->roi_save_n = 0;
+        return roi_upload(c);
+    }
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_roi_save: call soc_set_grid first");
+    const int lim[3] = { c->G.NX, c->G.NY, c->G.NZ };
+    for (int a = 0; a < 3; a++)
+        if (ROI[2 * a] < 0 || ROI[2 * a + 1] < ROI[2 * a] || ROI[2 * a + 1] >= lim[a])
+            return fail(c, SOC_ERR_ARG, "soc_set_roi_save: ROI[%d..%d] = %d..%d outside the %d root cells of that axis", 2 * a, 2 * a + 1, ROI[2 * a], ROI[2 * a + 1], lim[a]);
+    if (ROI_STEP < 1 || ROI_NSIDE < 1 || ROI_NSIDE > 1024) return fail(c, SOC_ERR_ARG, "soc_set_roi_save: ROI_STEP %d, ROI_NSIDE %d", ROI_STEP, ROI_NSIDE);
+    if (c->roi.load && c->roi.NSIDE != ROI_NSIDE)
+        return fail(c, SOC_ERR_ARG, "soc_set_roi_save: ROI_NSIDE %d differs from the loaded record's %d (one -D ROI_NSIDE in the reference)", ROI_NSIDE, c->roi.NSIDE);
+    const int64_t n[3] = { (int64_t)(ROI[1] - ROI[0] + 1) * ROI_STEP, (int64_t)(ROI[3] - ROI[2] + 1) * ROI_STEP, (int64_t)(ROI[5] - ROI[4] + 1) * ROI_STEP };
+    const int64_t total = (n[0] * n[1] + n[1] * n[2] + n[2] * n[0]) * 12 * ROI_NSIDE * ROI_NSIDE;
+    if (total > 2147483647LL) return fail(c, SOC_ERR_ARG, "soc_set_roi_save: %lld record entries (int32 indices in the kernel)", (long long)total);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, dev_alloc(&c->dRoiSave, (size_t)total));
+    HIPCHK(c, hipMemsetAsync(c->dRoiSave, 0, (size_t)total * 4, c->stream));
+    for (int i = 0; i < 6; i++) c->roi.ROI[i] = ROI[i];
+    c->roi.STEP = ROI_STEP;  c->roi.NSIDE = ROI_NSIDE;  c->roi.save = 1;
+    c->roi_save_n = (size_t)total;
+    return roi_upload(c);
+}
+
+int soc_roi_zero(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->roi.save) return fail(c, SOC_ERR_STATE, "soc_roi_zero: call soc_set_roi_save first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->dRoiSave, 0, c->roi_save_n * 4, c->stream));
+    return SOC_OK;
+}
+
+int soc_roi_read(soc_ctx *c, float *out, long n)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->roi.save) return fail(c, SOC_ERR_STATE, "soc_roi_read: call soc_set_roi_save first");
+    if (!out || n != (long)c->roi_save_n) return fail(c, SOC_ERR_ARG, "soc_roi_read: the record has %zu entries, buffer %ld", c->roi_save_n, n);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->dRoiSave, c->roi_save_n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_roi_load(soc_ctx *c, const int32_t *DIM, int ROI_NSIDE, const float *LOAD)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!LOAD) {                                            // off
+        c->roi.load = 0;
+        return roi_upload(c);
+    }
+    if (!DIM || DIM[0] < 1 || DIM[1] < 1 || DIM[2] < 1 || ROI_NSIDE < 1 || ROI_NSIDE > 1024)
+        return fail(c, SOC_ERR_ARG, "soc_set_roi_load: DIM / ROI_NSIDE");
+    if (c->roi.save && c->roi.NSIDE != ROI_NSIDE)
+        return fail(c, SOC_ERR_ARG, "soc_set_roi_load: ROI_NSIDE %d differs from the saved record's %d (one -D ROI_NSIDE in the reference)", ROI_NSIDE, c->roi.NSIDE);
+    const int64_t nelem = (int64_t)DIM[0] * DIM[1] + (int64_t)DIM[1] * DIM[2] + (int64_t)DIM[2] * DIM[0];
+    const int64_t total = nelem * 12 * ROI_NSIDE * ROI_NSIDE;
+    if (nelem > 21474836LL || total > 2147483647LL) return fail(c, SOC_ERR_ARG, "soc_set_roi_load: %lld surface elements", (long long)nelem);
+    for (int64_t i = 0; i < total; i++)
+        if (!std::isfinite(LOAD[i])) return fail(c, SOC_ERR_ARG, "soc_set_roi_load: LOAD[%lld] is not finite", (long long)i);
+    if (c->roi_load_cap < (size_t)total) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dRoiLoad, (size_t)total));
+        c->roi_load_cap = (size_t)total;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dRoiLoad, LOAD, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 3; i++) c->roi.DIM[i] = DIM[i];
+    c->roi.NELEM = (int)nelem;  c->roi.NSIDE = ROI_NSIDE;  c->roi.load = 1;
+    return roi_upload(c);
+}
+
 int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLOBAL, int gid_first, int gid_count)
 {
     (void)PACKETS;
@@ -652,6 +759,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     S.NO_PS = 1;
     if (c->use_emweight == 2 && !c->have_emindex) return fail(c, SOC_ERR_STATE, "soc_sim_cl: USE_EMWEIGHT 2 needs soc_set_emindex");
     if (c->with_ali) S.XAB = c->dXAB;
+    S.ROI = c->roi.save ? c->dRoi : nullptr;                // SimRAM_CL records too (kernel_ASOC.c:1250-1254)
     HIPCHK(c, soc_launch_sim_cl(c->G, S, V, c->stream));
     return SOC_OK;
 }
@@ -694,9 +802,10 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
             c->dOUT = nullptr;
             HIPCHK(c, dev_alloc(&c->dOUT, npix));
             c->own_OUT = true;
-            HIPCHK(c, hipMemset(c->dOUT, 0, npix * 4));
+            HIPCHK(c, hipMemsetAsync(c->dOUT, 0, npix * 4, c->stream));
         }
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // launches in flight still read the previous view
     HIPCHK(c, hipMemcpy(c->dODIR, ODIR, (size_t)NDIR * 16, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dORA, RA, (size_t)NDIR * 16, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dODE, DE, (size_t)NDIR * 16, hipMemcpyHostToDevice));
@@ -730,10 +839,11 @@ int soc_sca_set_healpix(soc_ctx *c, int NSIDE, const float *OBSERVER, int FFS)
             c->dOUT = nullptr;
             HIPCHK(c, dev_alloc(&c->dOUT, npix));
             c->own_OUT = true;
-            HIPCHK(c, hipMemset(c->dOUT, 0, npix * 4));
+            HIPCHK(c, hipMemsetAsync(c->dOUT, 0, npix * 4, c->stream));
         }
     }
     const float obs[4] = { OBSERVER[0], OBSERVER[1], OBSERVER[2], 0.0f };
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->dODIR, obs, 16, hipMemcpyHostToDevice));
     c->view.NDIR = -NSIDE;  c->view.NPIX_X = 1;  c->view.NPIX_Y = 1;  c->view.FFS = FFS ? 1 : 0;
     c->view.MAP_DX = 1.0f;  c->view.CX = c->view.CY = c->view.CZ = 0.0f;
@@ -930,6 +1040,7 @@ int soc_read_par(soc_ctx *c, int32_t *out, int64_t n)
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_read_par: call soc_set_grid first");
     if (!out || n < 0 || n > c->npar) return fail(c, SOC_ERR_ARG, "soc_read_par: n=%lld (have %lld)", (long long)n, (long long)c->npar);
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (n) HIPCHK(c, hipMemcpy(out, c->dPAR, (size_t)n * 4, hipMemcpyDeviceToHost));
     return SOC_OK;
 }
@@ -943,7 +1054,7 @@ int soc_stats(soc_ctx *c, uint64_t out[3], int reset)
     unsigned long long h[3];
     HIPCHK(c, hipMemcpy(h, c->dStats, sizeof h, hipMemcpyDeviceToHost));
     if (out) for (int i = 0; i < 3; i++) out[i] = h[i];
-    if (reset) HIPCHK(c, hipMemset(c->dStats, 0, sizeof h));
+    if (reset) HIPCHK(c, hipMemsetAsync(c->dStats, 0, sizeof h, c->stream));
     return SOC_OK;
 }
 
@@ -1212,7 +1323,7 @@ int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int N
     if (e == hipSuccess) e = hipMemcpy(dK, KABS, (size_t)NFREQ * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dT3, TTT, (size_t)NIP * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dA, ABS, (size_t)batch * NFREQ * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dE, 0, ((size_t)batch * NFREQ + batch) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(dE, 0, ((size_t)batch * NFREQ + batch) * 4, c->stream);
     SocEqTArgs A{};
     A.batch = batch;  A.icell = icell;  A.CELLS = CELLS;  A.NFREQ = NFREQ;  A.NIP = NIP;
     A.FACTOR = FACTOR;  A.kE = kE;  A.oplgkE = oplgkE;  A.Emin = Emin;

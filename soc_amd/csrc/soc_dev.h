@@ -17,6 +17,18 @@ struct SocGrid {
     const int   *PAR;          /* [CELLS-NXYZ] parent cell index within its level        */
 };
 
+// Region of interest of nested runs (kernel_ASOC.c:44-51, 1250-1254; -D ROI_STEP, ROI_NSIDE, WITH_ROI_SAVE,
+// WITH_ROI_LOAD): packets entering ROI are recorded per surface element and Healpix direction; SOURCE == 3 sends
+// such a record in from the model surface.  Lives in device memory, SocSim points at it.
+struct SocRoi {
+    int   save, load;          /* WITH_ROI_SAVE, WITH_ROI_LOAD                                          */
+    int   ROI[6];              /* x0, x1, y0, y1, z0, z1: root cells, inclusive                         */
+    int   STEP, NSIDE;         /* surface elements per root-cell edge (save); Healpix NSIDE of the records */
+    int   DIM[3], NELEM;       /* discretisation of the record to load; its number of surface elements  */
+    float *SAVE;               /* [elements * 12 * NSIDE^2]                                             */
+    const float *LOAD;         /* [NELEM * 12 * NSIDE^2] photons                                        */
+};
+
 // One launch of SimRAM_PB / SimRAM_CL (argument lists: kernel_ASOC.c:15-52, 1223-1256).
 struct SocSim {
     int   SOURCE, BATCH, GLOBAL, PS_METHOD, NO_PS, BINS, USE_EMWEIGHT;
@@ -38,6 +50,7 @@ struct SocSim {
     const float  *HPBG, *HPBGP; /* [49152] sky (photons per package), cumulative probability */
     float *TABS, *INT;
     unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
+    const SocRoi *ROI;         /* NULL without roisave / roiload                          */
 };
 
 // Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the

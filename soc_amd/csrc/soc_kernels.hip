@@ -41,14 +41,42 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
     const int id = (int)(S.gid0 + t);                      // logical get_global_id(0)
     const int AREA = 2 * (G.NX * G.NY + G.NY * G.NZ + G.NZ * G.NX);
     if ((S.SOURCE == 1) && (id >= 8 * AREA)) return;
+    if ((S.SOURCE == 3) && (!S.ROI || !S.ROI->load || (id >= 100 * S.ROI->NELEM))) return;     // kernel_ASOC.c:97-105
 
     SocWalker<OCT, DBL, ABU, WINT> w;
     w.rng = soc_seed_stream(S.seed_mul, S.seed_tab, (uint32_t)id);
     w.ind = -1;  w.level = 0;  w.n_tally = 0;  w.n_scat = 0;
     w.ux = w.uy = w.uz = 0.0f;  w.px = w.py = w.pz = 0.0f;
     w.dens = 0.0f;  w.photons = 0.0f;  w.tau = 0.0f;  w.free_path = 0.0f;  w.scat = 0;
+    w.roi_on = (S.ROI != nullptr) && (S.ROI->save != 0);
 
     const SocSurfElem E = soc_surface_element(G, S, id);
+
+    // SOURCE == 3 (kernel_ASOC.c:141-179): 100 work items per surface element of the loaded record, each sends
+    // BATCH packets, the Healpix pixels of the element in turn; patch centre (RDX, RDY) on side pair `rside`
+    int   relem = 0, rside = 0;
+    float RDX = 0.0f, RDY = 0.0f, rd = 1.0f, RX0 = 0.0f;
+    if (S.SOURCE == 3) {
+        const SocRoi &R = *S.ROI;
+        relem = id % R.NELEM;
+        int iside = relem;
+        rd = (float)G.NX / ((float)R.DIM[0]);
+        if (iside < (R.DIM[1] * R.DIM[2])) {
+            RDX = ((float)(iside % R.DIM[1]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[1]) + 0.5f) * rd;  rside = 0;
+        } else {
+            iside -= R.DIM[1] * R.DIM[2];
+            if (iside < (R.DIM[0] * R.DIM[2])) {
+                RDX = ((float)(iside % R.DIM[0]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[0]) + 0.5f) * rd;  rside = 1;
+            } else {
+                iside -= R.DIM[0] * R.DIM[2];
+                rside = 3;
+                if (iside < (R.DIM[0] * R.DIM[1])) {
+                    RDX = ((float)(iside % R.DIM[0]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[0]) + 0.5f) * rd;  rside = 2;
+                }
+            }
+        }
+        RX0 = (float)((double)(R.NSIDE * R.NSIDE) * 12.0 / (100.0 * (double)S.BATCH));
+    }
 
     int III = 0;
     int mode = SOC_M_CREATE;
@@ -56,12 +84,48 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
         const bool nobody_steps = (__ballot(mode == SOC_M_STEP) == 0ull);
         if (soc_service_now(mode == SOC_M_CREATE, nobody_steps)) {
             if (mode == SOC_M_CREATE) {
-                if (III >= S.BATCH) {
+                if (S.SOURCE == 3) {
+                    // kernel_ASOC.c:469-501; an empty pixel is skipped without a draw
+                    const SocRoi &R = *S.ROI;
+                    const int npix = 12 * R.NSIDE * R.NSIDE;
+                    mode = SOC_M_DONE;
+                    while (III < S.BATCH) {
+                        const int pix = III % npix;
+                        III++;
+                        w.photons = RX0 * R.LOAD[(size_t)relem * npix + pix];
+                        if (w.photons <= 0.0f) continue;
+                        float v1, v2, s1, c1, s2, c2;
+                        soc_pixel2angles_ring(R.NSIDE, pix, v1, v2);
+                        v1 += (soc_rand(&w.rng) - 0.5f) * 0.05f;
+                        v2 += (soc_rand(&w.rng) - 0.5f) * 0.05f;
+                        soc_sincosf(v1, &s1, &c1);
+                        soc_sincosf(v2, &s2, &c2);
+                        w.ux = s2 * c1;  w.uy = s2 * s1;  w.uz = c2;
+                        if (rside == 0) {
+                            w.py = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.pz = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+                            w.px = (w.ux > 0.0f) ? SOC_PEPS : ((float)G.NX - SOC_PEPS);
+                        }
+                        if (rside == 1) {
+                            w.px = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.pz = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+                            w.py = (w.uy > 0.0f) ? SOC_PEPS : ((float)G.NY - SOC_PEPS);
+                        }
+                        if (rside == 2) {
+                            w.px = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.py = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+                            w.pz = (w.uz > 0.0f) ? SOC_PEPS : ((float)G.NZ - SOC_PEPS);
+                        }
+                        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                        w.begin();
+                        if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);
+                        mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
+                        break;
+                    }
+                } else if (III >= S.BATCH) {
                     mode = SOC_M_DONE;
                 } else {
                     soc_pb_create<OCT>(G, S, sOFF, E, III, w);
                     III++;
                     w.begin();
+                    if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);       // kernel_ASOC.c:550
                     mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
                 }
             }
@@ -162,6 +226,7 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
     w.ind = -1;  w.level = 0;  w.n_tally = 0;  w.n_scat = 0;
     w.ux = w.uy = w.uz = 0.0f;  w.px = w.py = w.pz = 0.0f;
     w.dens = 0.0f;  w.photons = 0.0f;  w.tau = 0.0f;  w.free_path = 0.0f;  w.scat = 0;
+    w.roi_on = (S.ROI != nullptr) && (S.ROI->save != 0);
 
     long long ICELL = (long long)id - S.GLOBAL;            // kernel_ASOC.c:1283-1290
     long long IND = (long long)id - S.GLOBAL;              // USE_EMWEIGHT == 2: position in EMINDEX (:1759)
@@ -249,6 +314,7 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
                     w.uz = cos_theta;
                     n_pkt++;
                     w.begin();
+                    if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);       // kernel_ASOC.c:1439
                     mode = SOC_M_STEP;
                 }
             }

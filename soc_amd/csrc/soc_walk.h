@@ -237,12 +237,58 @@ __device__ __forceinline__ void soc_mirror(const SocGrid &G, const int *sOFF, in
     if (MIRROR & 32) { if (pz > G.NZ) pz = G.NZ - SOC_EPS_MIRROR;  uz = -uz;  soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens); }
 }
 
+__device__ __forceinline__ void soc_rootpos(const SocGrid &G, const int *sOFF, float &px, float &py, float &pz, int level, int ind);
+__device__ __forceinline__ int  soc_angles2pixel_ring(const int nside, float phi, const float theta);
+
+// InRoi (kernel_ASOC_aux.c:1031-1048): root index of the root cell above (level, ind) if it lies in ROI, else -1.
+// A packet that has left the model is outside (the reference's arithmetic on ind = -1 gives -1 % NX < ROI[0]).
+__device__ __forceinline__ int soc_inroi(const SocGrid &G, const int *sOFF, const SocRoi &R, int level, int ind)
+{
+    if (ind < 0) return -1;
+    while (level > 0) { ind = G.PAR[sOFF[level] + ind - G.NXYZ];  level--; }
+    const int i = ind % G.NX, j = (ind / G.NX) % G.NY, k = ind / (G.NX * G.NY);
+    return ((i >= R.ROI[0]) && (i <= R.ROI[1]) && (j >= R.ROI[2]) && (j <= R.ROI[3]) && (k >= R.ROI[4]) && (k <= R.ROI[5])) ? ind : -1;
+}
+
+// A packet has stepped into ROI (kernel_ASOC.c:618-642, :1510-1535): surface element from the root position,
+// Healpix pixel from the direction, PHOTONS added to the record.  `ii` is uninitialised in the reference when
+// no border test matches (one always does: the packet is within PEPS of the face it came through); 0 here.
+__device__ __forceinline__ void soc_roi_save(const SocGrid &G, const int *sOFF, const SocRoi &R, float px, float py, float pz,
+                                             float ux, float uy, float uz, int level, int ind, float photons)
+{
+    const int NX = (R.ROI[1] - R.ROI[0] + 1) * R.STEP, NY = (R.ROI[3] - R.ROI[2] + 1) * R.STEP, NZ = (R.ROI[5] - R.ROI[4] + 1) * R.STEP;
+    soc_rootpos(G, sOFF, px, py, pz, level, ind);
+    int ii = 0, jj;
+    auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    if ((px < ((float)R.ROI[0] + 1.0e-3f)) || (px > ((float)R.ROI[1] + 0.999f))) {
+        ii = cl((int)soc_floorf((py - (float)R.ROI[2]) * (float)R.STEP), 0, NY - 1);
+        jj = cl((int)soc_floorf((pz - (float)R.ROI[4]) * (float)R.STEP), 0, NZ - 1);
+        ii = ii + NY * jj;
+    }
+    if ((py < ((float)R.ROI[2] + 1.0e-3f)) || (py > ((float)R.ROI[3] + 0.999f))) {
+        ii = cl((int)soc_floorf((px - (float)R.ROI[0]) * (float)R.STEP), 0, NX - 1);
+        jj = cl((int)soc_floorf((pz - (float)R.ROI[4]) * (float)R.STEP), 0, NZ - 1);
+        ii = NY * NZ + ii + NX * jj;
+    }
+    if ((pz < ((float)R.ROI[4] + 1.0e-3f)) || (pz > ((float)R.ROI[5] + 0.999f))) {
+        ii = cl((int)soc_floorf((px - (float)R.ROI[0]) * (float)R.STEP), 0, NX - 1);
+        jj = cl((int)soc_floorf((py - (float)R.ROI[2]) * (float)R.STEP), 0, NY - 1);
+        ii = NY * NZ + NX * NZ + ii + NX * jj;
+    }
+    jj = soc_angles2pixel_ring(R.NSIDE, soc_atan2f(uy, ux), soc_acosf(uz));
+    ii = cl(ii, 0, NX * NY + NY * NZ + NZ * NX - 1);
+    jj = cl(jj, 0, 12 * R.NSIDE * R.NSIDE - 1);
+    soc_tally(R.SAVE, ii * 12 * R.NSIDE * R.NSIDE + jj, photons);
+}
+
 template <bool OCT, bool DBL, bool ABU, bool WINT>
 struct SocWalker {
     float px, py, pz, ux, uy, uz;
     float photons, free_path, tau, dens;
     int   level, ind, scat;
     int   e_index = -1;            // WITH_ALI: global index of the emitting cell (kernel_ASOC.c:1394-1396)
+    bool  roi_on = false;          // SimRAM_PB / SimRAM_CL with WITH_ROI_SAVE (set by those kernels only)
+    int   roi = -1;                // root index of the current cell if inside ROI (kernel_ASOC.c:550,562,617)
     soc_rng_t rng;
     unsigned int n_tally, n_scat;
 
@@ -286,6 +332,7 @@ struct SocWalker {
         const int   ind0 = ind, level0 = level;
         const float p0x = px, p0y = py, p0z = pz;
         const float d0 = dens;
+        const int   oroi = roi;
         float kabs, ksca;
         if (ABU) {
             float2 o = S.OPT[oind];
@@ -310,6 +357,10 @@ struct SocWalker {
         n_tally++;
         photons *= e;
         tau += dtau;
+        if (roi_on) {                                        // only at the end of a full step (kernel_ASOC.c:615-642)
+            roi = soc_inroi(G, sOFF, *S.ROI, level, ind);
+            if ((roi >= 0) && (oroi < 0)) soc_roi_save(G, sOFF, *S.ROI, px, py, pz, ux, uy, uz, level, ind, photons);
+        }
         if (!CL_ORDER) {
             if ((level == level0) && (ind == ind0)) {       // failed step: nudge (kernel_ASOC.c:649-653)
                 px += SOC_PEPS * ux;

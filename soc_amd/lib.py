@@ -45,6 +45,10 @@ API = {
     "soc_batch_end": (C.c_int, [C.c_void_p]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
+    "soc_set_roi_save": (C.c_int, [C.c_void_p, _I, C.c_int, C.c_int]),
+    "soc_roi_zero": (C.c_int, [C.c_void_p]),
+    "soc_roi_read": (C.c_int, [C.c_void_p, _F, C.c_long]),
+    "soc_set_roi_load": (C.c_int, [C.c_void_p, _I, C.c_int, _F]),
     "soc_sim_hp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_set_view": (C.c_int, [C.c_void_p, C.c_int, _F, _F, _F, C.c_int, C.c_int, C.c_float, _F, C.c_int]),
     "soc_sca_set_healpix": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int]),
@@ -260,6 +264,43 @@ class Engine:
         if BG.size != 49152 or (HPBGP is not None and HPBGP.size != 49152):
             raise SocError("set_hpbg: the sky map must hold 49152 pixels (NSIDE 64)")
         self._chk(self.lib.soc_set_hpbg(self.h, _f(BG), _f(HPBGP)))
+
+    # ---- region of interest (nested runs) ----
+    def set_roi_save(self, ROI, ROI_STEP=1, ROI_NSIDE=16):
+        """record the packets that step into ROI = [x0,x1,y0,y1,z0,z1] (root cells, inclusive) during sim_pb / sim_cl;
+        ROI=None turns recording off.  Returns the number of record entries."""
+        if ROI is None:
+            self._chk(self.lib.soc_set_roi_save(self.h, None, 0, 0))
+            self._roi_n = 0
+            return 0
+        ROI = np.ascontiguousarray(ROI, np.int32)
+        if ROI.size != 6:
+            raise SocError("set_roi_save: ROI = [x0, x1, y0, y1, z0, z1]")
+        self._chk(self.lib.soc_set_roi_save(self.h, ROI.ctypes.data_as(_I), int(ROI_STEP), int(ROI_NSIDE)))
+        n = [(int(ROI[2 * i + 1]) - int(ROI[2 * i]) + 1) * int(ROI_STEP) for i in range(3)]
+        self._roi_n = (n[0] * n[1] + n[1] * n[2] + n[2] * n[0]) * 12 * int(ROI_NSIDE) ** 2
+        return self._roi_n
+
+    def roi_zero(self):
+        self._chk(self.lib.soc_roi_zero(self.h))
+
+    def roi_read(self):
+        out = np.zeros(getattr(self, "_roi_n", 0), np.float32)
+        self._chk(self.lib.soc_roi_read(self.h, _f(out), out.size))
+        return out
+
+    def set_roi_load(self, DIM, ROI_NSIDE, LOAD):
+        """the record of one frequency to send in with sim_pb(SOURCE=3): LOAD[nelem, 12*NSIDE^2] photons on the
+        (nx, ny, nz) = DIM surface discretisation; LOAD=None turns it off"""
+        if LOAD is None:
+            self._chk(self.lib.soc_set_roi_load(self.h, None, 0, None))
+            return
+        DIM = np.ascontiguousarray(DIM, np.int32)
+        LOAD = np.ascontiguousarray(LOAD, np.float32)
+        nelem = int(DIM[0]) * int(DIM[1]) + int(DIM[1]) * int(DIM[2]) + int(DIM[2]) * int(DIM[0])
+        if DIM.size != 3 or LOAD.size != nelem * 12 * int(ROI_NSIDE) ** 2:
+            raise SocError("set_roi_load: LOAD must hold %d x %d values" % (nelem, 12 * int(ROI_NSIDE) ** 2))
+        self._chk(self.lib.soc_set_roi_load(self.h, DIM.ctypes.data_as(_I), int(ROI_NSIDE), _f(LOAD)))
 
     def sim_hp(self, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
         gid_count = (GLOBAL - gid_first) if gid_count is None else gid_count

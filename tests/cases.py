@@ -77,6 +77,22 @@ def _emindex(cloud, n=300, seed=3):
     return EMINDEX, EMWEI
 
 
+def roi_load(dim, nside, seed=9):
+    """SOURCE == 3 input: photons per surface element of the (nx, ny, nz) discretisation and Healpix pixel; a third
+    of the entries are empty (those packets are skipped without a draw)"""
+    rr = np.random.default_rng(seed)
+    nelem = dim[0] * dim[1] + dim[1] * dim[2] + dim[2] * dim[0]
+    a = rr.uniform(0.5, 2.0, (nelem, 12 * nside * nside)).astype(np.float32)
+    a[rr.uniform(size=a.shape) < 0.33] = 0.0
+    return a
+
+
+def _roil(cloud, dim, nside, nbatch, **kw):
+    a = roi_load(dim, nside)
+    return Job(cloud, _CSC, ABS=1e-4, SCA=3e-4, SOURCE=3, PACKETS=a.shape[0], GLOBAL=100 * a.shape[0],
+               BATCH=nbatch * 12 * nside * nside, ROI_LOAD=a, ROI_DIM=dim, ROI_NSIDE=nside, **kw)
+
+
 CASES = {
     # name: (ref build, kind, job factory); kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_HP
     "bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=50, SEED=0.6004384)),
@@ -86,6 +102,14 @@ CASES = {
     "bg_c8_abu": ("c8abu", 0, lambda: Job(_c8(), _CSC, SOURCE=1, BATCH=20, SEED=0.3, OPT=_opt(512))),
     "bg_r654": ("r654", 0, lambda: Job(synth.cartesian_cloud(6, seed=4, NY=5, NZ=4), _CSC, ABS=1e-4, SCA=3e-4,
                                          SOURCE=1, BATCH=30, SEED=0.77)),
+    # region of interest (nested runs): save what enters ROI, load such a record as SOURCE 3
+    "bg_c8_roisave": ("c8roi", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=30, SEED=0.6004384,
+                                                ROI=[2, 5, 2, 4, 3, 6], ROI_STEP=2, ROI_NSIDE=2)),
+    "cl_oct8_roisave": ("oct8roi", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                    EMIT=_emit(_oct8()), ROI=[1, 3, 2, 5, 0, 4], ROI_STEP=1, ROI_NSIDE=4)),
+    "roi_c8_load": ("c8roil", 0, lambda: _roil(_c8(), (4, 4, 4), 2, 1, SEED=0.33, TW=1.2)),
+    "roi_oct8_load_save": ("oct8roils", 0, lambda: _roil(_oct8(), (2, 2, 2), 2, 2, SEED=0.71, WITH_INT=1,
+                                                          ROI=[3, 4, 3, 5, 2, 5], ROI_STEP=2)),
     "bg_oct8": ("oct8", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=30, SEED=0.41)),
     "bg_oct4": ("oct4", 0, lambda: Job(synth.kat_octree(), _CSC, ABS=2e-3, SCA=4e-3, SOURCE=1, BATCH=40, SEED=0.51)),
     "ps_in_c8": ("c8ps0", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,

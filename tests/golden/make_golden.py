@@ -87,6 +87,8 @@ def main():
             out[name + "_INT"] = I
         if job.WITH_ALI:
             out[name + "_XAB"] = job.XAB.copy()
+        if job.ROI is not None:
+            out[name + "_ROISAVE"] = job.ROI_SAVE.copy()
         out[name + "_DENS"] = job.DENS          # pins the synthetic-cloud generator as well
         print("%-14s sum(TABS) = %.9e   nonzero cells %d / %d" % (name, T.sum(dtype=np.float64), (T != 0).sum(), T.size))
     np.savez_compressed(os.path.join(HERE, "sims.npz"), **out)

@@ -10,7 +10,7 @@ from util import run_engine, assert_tally_close
 
 pytestmark = pytest.mark.gpu
 
-CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n and "mirror" not in n]
+CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n and "mirror" not in n and "roi" not in n]
 
 
 @pytest.mark.parametrize("name", CART)

@@ -111,6 +111,10 @@ def test_simulation_vs_oracle(name, engine, oracle_soc):
         assert not Ig.any()
     if job.WITH_ALI:
         assert_tally_close(job.XAB_gpu, job.XAB, rtol=1e-5)      # job.XAB was filled by the oracle run above
+    if job.ROI is not None:
+        # the record of packets entering ROI: same entries touched, same sums up to the order of the fp32 adds
+        assert np.array_equal(job.ROI_SAVE_gpu != 0, job.ROI_SAVE != 0)
+        assert_tally_close(job.ROI_SAVE_gpu, job.ROI_SAVE, rtol=1e-5)
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))

@@ -82,6 +82,9 @@ def test_simulation_libm_bit_exact(name, oracle_libm):
         assert np.array_equal(I.view(np.uint32), SIMS[name + "_INT"].view(np.uint32))
     if job.WITH_ALI:
         assert job.XAB.sum() > 0 and np.array_equal(job.XAB.view(np.uint32), SIMS[name + "_XAB"].view(np.uint32))
+    if job.ROI is not None:
+        assert (job.ROI_SAVE > 0).sum() > 20, "no packets recorded at the ROI surface"
+        assert np.array_equal(job.ROI_SAVE.view(np.uint32), SIMS[name + "_ROISAVE"].view(np.uint32))
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))

@@ -12,6 +12,10 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
     eng.set_opt(job.OPT)
     eng.set_mirror(getattr(job, "MIRROR", 0))
     eng.set_exec(exec_mode, brick_log2)
+    if job.ROI is not None:
+        eng.set_roi_save(job.ROI, job.ROI_STEP, job.ROI_NSIDE)
+    if job.ROI_LOAD is not None:
+        eng.set_roi_load(job.ROI_DIM, job.ROI_NSIDE, job.ROI_LOAD)
     if zero:
         eng.zero(0)
         eng.zero(1)
@@ -35,6 +39,11 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
         eng.sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL,
                    gid_first=gid_first, gid_count=gid_count)
     eng.sync()
+    if job.ROI is not None:
+        job.ROI_SAVE_gpu = eng.roi_read()
+        eng.set_roi_save(None)
+    if job.ROI_LOAD is not None:
+        eng.set_roi_load(None, 0, None)
     if kind == 1 and job.WITH_ALI:
         job.XAB_gpu = eng.read_tally(2)
         eng.set_ali(0)
