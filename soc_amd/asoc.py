@@ -40,8 +40,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("stepweight")
     if USER.DIR_WEIGHT[0] > 0:
         bad.append("direweight")
-    if USER.WITH_ROI_SAVE or USER.WITH_ROI_LOAD:
-        bad.append("roisave/roiload")
+    if USER.ROI_MAP:
+        bad.append("roimap")
     if USER.SAVE_INTENSITY == 2:
         bad.append("saveint 2 (intensity vectors)")
     if USER.PS_METHOD == 3:
@@ -174,7 +174,15 @@ class AbsorptionRun:
             return np.fromfile(U.file_constant_load, np.float32, CELLS), FABSORBED
         rng = np.random.default_rng()
         DEVICES, ID, KDEV = 1, 0, 1.0                 # sharded launches reproduce ONE device (ASOC.py:179-181)
-        for II in range(3):
+        # region of interest (ASOC.py:909-944): record what enters ROI / send in what an enclosing run recorded
+        self.ROI_SAVE = self.ROI_LOAD = None
+        if U.WITH_ROI_LOAD:
+            self.ROI_DIM, self.ROI_LOAD = files.open_roi_load(U.FILE_ROI_LOAD, U.ROI_NSIDE, NFREQ)
+        if U.WITH_ROI_SAVE:
+            n = e.set_roi_save(U.ROI, U.ROI_STEP, U.ROI_NSIDE)
+            self.ROI_SAVE = files.create_roi_save(U.FILE_ROI_SAVE, U.ROI, U.ROI_STEP, U.ROI_NSIDE, NFREQ) if self.rank == 0 \
+                else np.zeros((NFREQ, n), np.float32)
+        for II in range(4):
             if U.ITERATIONS < 1:
                 continue
             WPS = WBG = 0.0
@@ -191,16 +199,21 @@ class AbsorptionRun:
                     launch.bg_launch(self.BGPAC, int(U.AREA))
                 WBG = L["WBG"]
                 self.log("=== BG: BGPAC %d, BATCH %d, GLOBAL %d" % (L["PACKETS"], L["BATCH"], L["GLOBAL"]))
-            else:
+            elif II == 2:
                 if len(self.DIFFUSERAD) < 1 or self.DFPAC < 1:
                     continue
                 L = launch.cl_launch(self.DFPAC, CELLS, self.GLOBAL_0)
                 self.log("=== DFPAC %d, GLOBAL %d, BATCH %d" % (self.DFPAC, L["GLOBAL"], L["BATCH"]))
+            else:
+                if U.ROIPAC < 1 or self.ROI_LOAD is None:
+                    continue
+                L = launch.roi_launch(U.ROIPAC, files.roi_elements(self.ROI_DIM), U.ROI_NSIDE)
+                self.log("=== ROI: GLOBAL %d, BATCH %d, elements %d" % (L["GLOBAL"], L["BATCH"], L["PACKETS"]))
             first, count = self.comm.shard(L["GLOBAL"]) if self.comm else (0, L["GLOBAL"])
             e.zero(0)
             # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
             # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
-            deferred = (not self.with_int) and II != 2 and hasattr(e, "batch_begin")
+            deferred = (not self.with_int) and II < 2 and self.ROI_SAVE is None and hasattr(e, "batch_begin")
             if deferred:
                 e.batch_begin(0)
             for IFREQ in range(NFREQ):
@@ -231,6 +244,12 @@ class AbsorptionRun:
                         a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
                         EMIT[a:b] = self.DIFFUSERAD[a:b, dr_ind] * coeff
                     e.set_emission(EMIT, None)
+                if II == 3:
+                    # scale in again the dependence on the grid length (ASOC.py:1419-1421)
+                    e.set_roi_load(self.ROI_DIM, U.ROI_NSIDE,
+                                   np.asarray(self.ROI_LOAD[IFREQ, :] * U.ROI_LOAD_SCALE / (U.GL * U.GL), np.float32))
+                if self.ROI_SAVE is not None:
+                    e.roi_zero()                                   # per frequency (ASOC.py:1301-1302)
                 hp = (II == 1) and len(self.HPBG) > 0
                 if hp:
                     sky = files.hpbg_for_frequency(self.HPBG[IFREQ], WBG / FREQ, U.HPBG_WEIGHTED)
@@ -256,6 +275,13 @@ class AbsorptionRun:
                 t0 = time.time()
                 if FABSORBED is not None:
                     FABSORBED[:, IFREQ] += e.read_tally(1)
+                if self.ROI_SAVE is not None:
+                    # += : point sources, background and a loaded record all pass here; GL^2 scales away the
+                    # dependence on the current grid length (ASOC.py:1466-1475)
+                    rec = e.roi_read()
+                    if self.comm:
+                        rec = self.comm.all_reduce_host(rec)
+                    self.ROI_SAVE[IFREQ, :] += rec * np.float32(U.GL * U.GL)
                 self.timers["Tpull"] += time.time() - t0
                 if self.verbose and self.rank == 0:
                     print("  FREQ %3d/%3d  %10.3e   BG %12.4e  PS %12.4e   TW %10.3e" % (
@@ -270,7 +296,11 @@ class AbsorptionRun:
             t0 = time.time()
             CTABS += e.read_tally(0)
             self.timers["Tpull"] += time.time() - t0
-            self.log("******  CONSTANT   %10s   CTABS -> %12.4e" % (['PS', 'BG', 'DE'][II], float(np.mean(CTABS))))
+            self.log("******  CONSTANT   %10s   CTABS -> %12.4e" % (['PS', 'BG', 'DE', 'ROI'][II], float(np.mean(CTABS))))
+        if self.ROI_LOAD is not None:
+            e.set_roi_load(None, 0, None)
+        if isinstance(self.ROI_SAVE, np.memmap):
+            self.ROI_SAVE.flush()
         return CTABS, FABSORBED
 
     # ---------------------------------------------------------------------------------

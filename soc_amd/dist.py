@@ -69,6 +69,16 @@ class Comm:
             self.dist.all_reduce(arr)
             engine.write_tally(which, arr.numpy())
 
+    def all_reduce_host(self, arr):
+        """Sum a host array over all ranks (small per-frequency records: the ROI record)."""
+        if self.world == 1:
+            return arr
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        if self.backend == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
     def attach_image(self, engine, npix):
         """Same for the scattered-light image OUT[NDIR*NPIX_Y*NPIX_X]."""
         if self.world > 1 and self.backend == "nccl":

@@ -297,3 +297,37 @@ def write_temperature(filename, cloud, TNEW):
             a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
             np.asarray([cloud.LCELLS[level]], np.int32).tofile(fp)
             TNEW[a:b].tofile(fp)
+
+
+# ---------------------------------------------------------------------------------------
+# region-of-interest records (roisave / roiload): int32 (nx, ny, nz, nside, nfreq) + float32 [nfreq, nelem * 12*nside^2]
+# with nelem = nx*ny + ny*nz + nz*nx surface elements (ASOC.py:909-944)
+# ---------------------------------------------------------------------------------------
+
+def roi_elements(n):
+    return int(n[0]) * int(n[1]) + int(n[1]) * int(n[2]) + int(n[2]) * int(n[0])
+
+
+def open_roi_load(filename, ROI_NSIDE, NFREQ):
+    """memory map of a record to load.  Returns (DIM[3], data[NFREQ, nelem*12*nside^2])."""
+    hdr = np.fromfile(filename, np.int32, 5)
+    if hdr.size != 5:
+        raise ValueError("ROI file %s: short header" % filename)
+    if hdr[3] != ROI_NSIDE:
+        raise ValueError("ROI file %s has nside %d, ini-file has %d" % (filename, hdr[3], ROI_NSIDE))
+    if hdr[4] != NFREQ:
+        raise ValueError("ROI file %s has %d, current run %d frequencies" % (filename, hdr[4], NFREQ))
+    n = roi_elements(hdr[:3]) * 12 * ROI_NSIDE * ROI_NSIDE
+    return np.asarray(hdr[:3], np.int32), np.memmap(filename, dtype=np.float32, mode='r', offset=20, shape=(NFREQ, n))
+
+
+def create_roi_save(filename, ROI, ROI_STEP, ROI_NSIDE, NFREQ):
+    """header + zeroed record on disk, as a writable memory map [NFREQ, nelem*12*nside^2] (ASOC.py:927-940)"""
+    n = [(int(ROI[2 * i + 1]) - int(ROI[2 * i]) + 1) * int(ROI_STEP) for i in range(3)]
+    np.asarray(n + [ROI_NSIDE, NFREQ], np.int32).tofile(filename)
+    npix = roi_elements(n) * 12 * ROI_NSIDE * ROI_NSIDE
+    with open(filename, "ab") as fp:
+        fp.truncate(20 + 4 * NFREQ * npix)
+    m = np.memmap(filename, dtype=np.float32, mode='r+', offset=20, shape=(NFREQ, npix))
+    m[:, :] = 0.0
+    return m

@@ -90,6 +90,14 @@ def hpbg_sca_launch(BGPAC, NX, NY, NZ):
     return dict(GLOBAL=GLOBAL, BATCH=BATCH, PACKETS=PACKETS, WBG=WBG)
 
 
+def roi_launch(ROIPAC, NELEM, ROI_NSIDE, LOCAL=LOCAL_GPU):
+    """Packets of a loaded ROI record (ASOC.py:1094-1105): 100 work items per surface element, each sends a whole
+    number of Healpix maps.  PACKETS carries the number of surface elements.  Returns dict(GLOBAL, BATCH, PACKETS)."""
+    npix = 12 * ROI_NSIDE * ROI_NSIDE
+    BATCH = max([1, int(ROIPAC / (100.0 * npix * NELEM))]) * npix
+    return dict(GLOBAL=Fix(100 * NELEM, LOCAL), BATCH=BATCH, PACKETS=NELEM)
+
+
 def cl_launch(PAC, CELLS, GLOBAL=GLOBAL_0):
     """Cell emission: diffuse (ASOC.py:1086-1090) or dust re-emission (ASOC.py:1640).
     Returns dict(GLOBAL, BATCH, PACKETS)."""

@@ -54,6 +54,33 @@ class OracleEngine:
     def set_emindex(self, EMINDEX):
         self.EMINDEX = np.asarray(EMINDEX, np.int32).copy()
 
+    # region of interest
+    def set_roi_save(self, ROI, ROI_STEP=1, ROI_NSIDE=16):
+        self.roi = None if ROI is None else (np.asarray(ROI, np.int32).copy(), int(ROI_STEP), int(ROI_NSIDE))
+        self.roi_rec = None
+        if ROI is not None:
+            n = [(int(ROI[2 * i + 1]) - int(ROI[2 * i]) + 1) * int(ROI_STEP) for i in range(3)]
+            self.roi_rec = np.zeros((n[0] * n[1] + n[1] * n[2] + n[2] * n[0]) * 12 * int(ROI_NSIDE) ** 2, np.float32)
+            return self.roi_rec.size
+        return 0
+
+    def roi_zero(self):
+        self.roi_rec[:] = 0
+
+    def roi_read(self):
+        return self.roi_rec.copy()
+
+    def set_roi_load(self, DIM, ROI_NSIDE, LOAD):
+        self.roi_load = None if LOAD is None else (np.asarray(DIM, np.int32).copy(), int(ROI_NSIDE), np.asarray(LOAD, np.float32).copy())
+
+    def _roi(self, job, source):
+        if getattr(self, "roi", None) is not None:
+            job.ROI, job.ROI_STEP, job.ROI_NSIDE = self.roi
+            job.ROI_SAVE = self.roi_rec
+        if source == 3 and getattr(self, "roi_load", None) is not None:
+            job.ROI_DIM, job.ROI_NSIDE, job.ROI_LOAD = self.roi_load
+        return job
+
     def bind_tally(self, which, ptr):
         raise NotImplementedError
 
@@ -69,7 +96,7 @@ class OracleEngine:
 
     def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None, GLOBAL=None,
                gid_first=0, gid_count=None):
-        job = self._job(SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS, PS, XPS)
+        job = self._roi(self._job(SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS, PS, XPS), SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
         _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n
@@ -87,6 +114,7 @@ class OracleEngine:
     def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
         job = self._job(SOURCE, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
         job.WITH_ALI, job.XAB, job.EMINDEX = self.ali, self.T[2], self.EMINDEX
+        self._roi(job, SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
         _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
         self.events += n

@@ -241,3 +241,55 @@ def test_mirror_key_reaches_the_engine(tmp_path):
     mir = AbsorptionRun(User(_write_model(d, cloud, extra="mirror xZ\n")), eng).run()[0]
     assert eng.mirror == 1 + 32
     assert not np.array_equal(mir, plain) and mir.sum(dtype=np.float64) > plain.sum(dtype=np.float64)
+
+
+def test_nested_run_roi_save_then_load(tmp_path):
+    """roi/roisave in an outer run, roiload/roipac in the nested one (ASOC.py:909-944, 1094-1105, 1301, 1415-1475):
+    file format, per-frequency records (x GL^2), the SOURCE 3 launch and its scaling -- re-derived here."""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    os.chdir(d)
+    outer = synth.cartesian_cloud(8, seed=3)
+    ROI = [2, 5, 2, 5, 3, 4]
+    GL = 5.0e-7                                                    # the model of _write_model is opaque at 0.5 pc per cell
+    ini = _write_model(d, outer, extra="gridlength %g\nroi %d %d %d %d %d %d\nroisave %s/roi.save 2\nroinside 2\n" % (GL, *ROI, d))
+    U = User(ini)
+    assert U.WITH_ROI_SAVE == 1 and U.ROI_STEP == 2 and U.ROI_NSIDE == 2 and list(U.ROI) == ROI
+    run = AbsorptionRun(U, OracleEngine("soc"))
+    run.run()
+    hdr = np.fromfile(os.path.join(d, "roi.save"), np.int32, 5)
+    assert list(hdr) == [8, 8, 4, 2, 3]                                    # (nx, ny, nz) elements, nside, nfreq
+    nelem = 8 * 8 + 8 * 4 + 4 * 8
+    rec = np.fromfile(os.path.join(d, "roi.save"), np.float32, offset=20).reshape(3, nelem * 48)
+    assert (rec > 0).sum() > 100
+    # independent evaluation of frequency 1
+    orc = Oracle("soc")
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], GL)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 3, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, outer.AREA)
+    job = Job(outer, FCSC[0, 1], ABS=AFABS[0][1], SCA=AFSCA[0][1], SOURCE=1, BATCH=L["BATCH"],
+              SEED=launch.launch_seed(math.pi / 4, 1), BG=np.float32(float(IBG[1]) * L["WBG"] / float(FFREQ[1])),
+              TW=launch.trapezoid_weight(FFREQ, 1), GLOBAL=L["GLOBAL"], WITH_INT=1, ROI=ROI, ROI_STEP=2, ROI_NSIDE=2)
+    orc.sim(job, 0)
+    assert np.array_equal(rec[1], job.ROI_SAVE * np.float32(GL * GL))
+
+    # nested run: the ROI region at twice the resolution, fed by the record
+    inner = synth.cartesian_cloud(8, seed=4, NZ=4)
+    d2 = os.path.join(d, "inner")
+    os.makedirs(d2)
+    ini2 = _write_model(d2, inner, extra="gridlength %g\nroiload %s/roi.save 1.5\nroipac 500000\nroinside 2\nbgpackets 0\n" % (GL, d))
+    U2 = User(ini2)
+    assert U2.WITH_ROI_LOAD == 1 and U2.ROI_LOAD_SCALE == 1.5 and U2.ROIPAC == 500000
+    run2 = AbsorptionRun(U2, OracleEngine("soc"))
+    C2, _ = run2.run()
+    L3 = launch.roi_launch(500000, nelem, 2)
+    assert L3 == dict(GLOBAL=launch.Fix(100 * nelem, 32), BATCH=max(1, int(500000 / (100.0 * 48 * nelem))) * 48, PACKETS=nelem)
+    T = np.zeros(inner.CELLS, np.float32)
+    for i in range(3):
+        job = Job(inner, FCSC[0, i], ABS=AFABS[0][i], SCA=AFSCA[0][i], SOURCE=3, BATCH=L3["BATCH"], PACKETS=nelem,
+                  SEED=launch.launch_seed(math.pi / 4, i), BG=0.0, TW=launch.trapezoid_weight(FFREQ, i), GLOBAL=L3["GLOBAL"],
+                  WITH_INT=1, ROI_LOAD=np.asarray(rec[i] * 1.5 / (GL * GL), np.float32), ROI_DIM=[8, 8, 4], ROI_NSIDE=2)
+        orc.sim(job, 0, TABS=T)
+    assert T.sum() > 0 and np.array_equal(C2, T)
