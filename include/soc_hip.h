@@ -63,9 +63,12 @@ int soc_set_mirror(soc_ctx *ctx, int mask);
 
 /* how launches are executed (no counterpart in the reference; results are the same packets):
  *   mode 0  direct: one lane per work item, one global float atomic per tally event
- *   mode 1  brick sweep: packets sorted by brick of 2^brick_log2 root cells per edge, tallies
- *           accumulated in LDS and flushed per brick (Cartesian grids, SimRAM_PB)
- *   mode -1 automatic (default): brick sweep where it applies, direct otherwise          */
+ *   mode 1  brick sweep (SimRAM_PB): packets sorted by brick, tallies accumulated in LDS and flushed per
+ *           brick; a brick is 2^brick_log2 root cells per edge on Cartesian grids, a set of <= 8192
+ *           neighbouring leaves on hierarchies (built at the first sweep after soc_set_grid)
+ *   mode -1 automatic (default): brick sweep where it pays -- Cartesian grids from 65536 work items on,
+ *           hierarchies for launches deferred by soc_batch_begin (two or more per sweep) -- direct
+ *           otherwise (reflecting faces, region-of-interest records, SOURCE 3)                     */
 int soc_set_exec(soc_ctx *ctx, int mode, int brick_log2);
 
 /* replaces the per-frequency uploads of ABS, SCA (ASOC.py:1171-1175); ndust must be 1
@@ -114,8 +117,8 @@ int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
  * runs one kernel per frequency and waits for it, ASOC.py:1360-1461).  Between soc_batch_begin and
  * soc_batch_end a launch that qualifies for the brick sweep with scalar opacities and without the
  * per-frequency INT tally is recorded with a snapshot of its inputs (ABS, SCA, scattering table,
- * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default 4,
- * at most 8): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
+ * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default: 4 on
+ * Cartesian grids, 8 on hierarchies; at most 8): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
  * flight per pass.  Any other call that reads or changes engine state executes what is pending
  * first; launches that do not qualify run immediately as always. */
 int soc_batch_begin(soc_ctx *ctx, int max_launches);
