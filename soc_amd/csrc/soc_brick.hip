@@ -98,6 +98,11 @@ struct SocBrickArgs {
     int *total;                  // packets still in flight after this pass
     int ev_brick;                // scan: first event queue (descriptors from here on belong to soc_brick_events)
     int HS;                      // arrivals per destination, per workgroup: 0 = LDS table indexed by queue, else hash table of HS entries
+    // population control: work items [0, target) start at once, the others are admitted (in order) as work items
+    // finish, so that the sweep runs with `target` packets in flight until the last launch drains
+    int target, nl;
+    uint32_t first[SOC_MAXLAUNCH + 1];
+    int *admit;                  // [0] next work item to admit; per launch l: [1+3l] first id, [2+3l] how many, [3+3l] where (this pass)
     // hierarchical grids: bricks are sets of <= CAP leaf cells (soc_oct_build)
     int CAP;
     const float2 *DS;            // [CELLS] density or link as in DENS | brick << 14 + tally slot of a leaf (bits)
@@ -211,10 +216,12 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
         pk[t] = p;
         idq0[t] = t;
     }
-    // every launch starts in its own creation queue NB + 2l
+    // every launch starts in its own creation queue NB + 2l; the first A.target work items at once
+    const uint32_t active = min(count, (uint32_t)A.target);
     uint32_t dbase = 0;
     for (int l = 0; l < K.n; l++) {
-        const uint32_t cnt = K.first[l + 1] - K.first[l];
+        const uint32_t hi = min(K.first[l + 1], active);
+        const uint32_t cnt = (hi > K.first[l]) ? (hi - K.first[l]) : 0u;
         const uint32_t nd = (cnt + A.P - 1) / A.P;
         if (t >= dbase && t < dbase + nd) {
             const uint32_t k = t - dbase;
@@ -227,7 +234,7 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
         }
         dbase += nd;
     }
-    if (t == 0) { ndesc0[0] = (int)dbase;  ndesc0[2] = 0; }
+    if (t == 0) { ndesc0[0] = (int)dbase;  ndesc0[2] = 0;  A.admit[0] = (int)active;  *A.total = (int)active; }
     if (t <= (uint32_t)(A.NB + 2 * K.n)) hist[t] = 0;
 }
 
@@ -645,7 +652,27 @@ __global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const Soc
 __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
 {
     __shared__ int sSum[1024], sSumD[1024];
+    __shared__ int sAdm[SOC_MAXLAUNCH];
     const int NB = A.NB, tid = threadIdx.x;
+    // admission: the population of the last pass (*A.total) against the target; new work items go to the end
+    // of their launch's creation queue (soc_brick_scatter writes their ids)
+    if (tid < SOC_MAXLAUNCH) sAdm[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const int next = A.admit[0], count = (int)A.first[A.nl];
+        int n = min(A.target - *A.total, count - next);
+        if (n < 0) n = 0;
+        for (int l = 0; l < A.nl; l++) {
+            const int lo = max(next, (int)A.first[l]), hi = min(next + n, (int)A.first[l + 1]);
+            const int m = (hi > lo) ? (hi - lo) : 0;
+            sAdm[l] = m;
+            A.admit[1 + 3 * l] = lo;
+            A.admit[2 + 3 * l] = m;
+            if (m) atomicAdd(&A.hist[A.ev_brick + 2 * l], m);            // at L2: the loads below must see it
+        }
+        A.admit[0] = next + n;
+    }
+    __syncthreads();
     const int per = (NB + 1023) / 1024;
     const int b0 = tid * per, b1 = min(NB, b0 + per);
     int s = 0, sd = 0;
@@ -671,6 +698,10 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         A.off[b] = off;
         A.cursor[b] = 0;
         if (b == A.ev_brick) A.ndesc_next[2] = offd;
+        if (b >= A.ev_brick && ((b - A.ev_brick) & 1) == 0) {           // a creation queue: the admitted ids go to its end
+            const int l = (b - A.ev_brick) >> 1;
+            if (l < A.nl && sAdm[l]) A.admit[3 + 3 * l] = off + c - sAdm[l];
+        }
         const int nk = (c + A.P - 1) / A.P;               // chunks of equal size (a queue of P+1 is not 2048 + 1)
         for (int k = 0, o = off; k < nk; k++) {
             SocDesc d;
@@ -693,8 +724,18 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
 }
 
 // counting-sort placement: ids of the current queue -> next queues, by destination brick
-__global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A)
+__global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A, const int nsort)
 {
+    if ((int)blockIdx.x >= nsort) {
+        // admission (see soc_brick_scan): 16 workgroups per launch write the new ids to the end of its creation queue
+        const int e = (int)blockIdx.x - nsort, l = e >> 4, part = e & 15;
+        const int start = A.admit[1 + 3 * l], n = A.admit[2 + 3 * l];
+        if (n > 0) {
+            const int dst = A.admit[3 + 3 * l];
+            for (int i = part * SOC_BRICK_T + threadIdx.x; i < n; i += 16 * SOC_BRICK_T) A.idq_next[dst + i] = (uint32_t)(start + i);
+        }
+        return;
+    }
     if ((int)blockIdx.x >= *A.ndesc) return;
     const SocDesc D = A.desc[blockIdx.x];
     extern __shared__ int sB[];                          // [NB], or keys[HS] + counts[HS]
@@ -757,7 +798,7 @@ struct SocBrickBuffers {
     int    cap_nq = 0, cap_desc = 0;
     SocPk2 *pk = nullptr;
     uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr;
-    int *hist = nullptr, *off = nullptr, *cursor = nullptr, *ndesc = nullptr, *total = nullptr;
+    int *hist = nullptr, *off = nullptr, *cursor = nullptr, *ndesc = nullptr, *total = nullptr, *admit = nullptr;
     SocDesc *desc[2] = { nullptr, nullptr };
 };
 
@@ -782,7 +823,7 @@ void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
     SocBrickBuffers &b = g_bb[device];
-    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.desc[0], b.desc[1] };
+    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     b = SocBrickBuffers();
     soc_oct_release(device);
@@ -970,7 +1011,7 @@ static void soc_brick_launch_pass(int vkey, int nblocks, int T, size_t lds, hipS
 }
 
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
-                            hipStream_t st, int *passes_out)
+                            int population, hipStream_t st, int *passes_out)
 {
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     if (nlaunch > 1 && (V.abu || V.wint)) return hipErrorNotSupported;
@@ -1059,8 +1100,15 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         BCHK(brick_alloc(&bb.desc[1], maxdesc));
         bb.cap_desc = maxdesc;
     }
-    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1)); }
+    if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1));  BCHK(brick_alloc(&bb.admit, 1 + 3 * SOC_MAXLAUNCH)); }
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
+    A.admit = bb.admit;
+    // packets in flight: the work items of the first `population` launches (0: all of them); the rest are admitted
+    // as those finish -- one tail per sweep instead of one per `population` launches
+    A.nl = K.n;
+    for (int l = 0; l <= SOC_MAXLAUNCH; l++) A.first[l] = K.first[l];
+    if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
+    A.target = (population > 0 && population < K.n) ? (int)K.first[population] : (int)count;
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
@@ -1089,7 +1137,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             Q.NB = NQ - 1;
             Q.ev_brick = A.NB;
             soc_brick_scan<<<1, 1024, 0, st>>>(Q);
-            soc_brick_scatter<<<maxdesc, SOC_BRICK_T, lds_scat, st>>>(Q);
+            soc_brick_scatter<<<maxdesc + 16 * K.n, SOC_BRICK_T, lds_scat, st>>>(Q, maxdesc);
         }
         BCHK(hipGetLastError());
         BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -134,7 +134,9 @@ static int flush_pending(soc_ctx *c)
         HIPCHK(c, soc_launch_sim_pb(c->G, todo[0], V, c->stream));
         return SOC_OK;
     }
-    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, c->stream, &c->last_passes);
+    // Cartesian grids: 4 launches' worth of packets in flight was measured best (C2; more spills the last-level cache),
+    // hierarchies: all of them
+    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, V.octree ? 0 : 4, c->stream, &c->last_passes);
     if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
     return SOC_OK;
 }
@@ -577,7 +579,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -592,8 +594,8 @@ int soc_batch_begin(soc_ctx *c, int max_launches)
         return fail(c, SOC_ERR_ARG, "soc_batch_begin: max_launches %d (1..%d, 0 = default)", max_launches, SOC_MAXLAUNCH);
     FLUSH(c);
     c->batching = true;
-    // default: what was measured best -- 4 launches per sweep on Cartesian grids (C2), all 8 on hierarchies
-    c->batch_max = max_launches ? max_launches : ((c->have_grid && c->G.LEVELS > 1) ? SOC_MAXLAUNCH : 4);
+    // default: as many as one sweep takes (the packets in flight are limited separately, see flush_pending)
+    c->batch_max = max_launches ? max_launches : SOC_MAXLAUNCH;
     return SOC_OK;
 }
 
