@@ -88,9 +88,9 @@ struct SocBrickArgs {
     const uint32_t *idq;         // current queue (ids sorted by brick)
     uint32_t *idq_next;
     uint32_t *keyq;              // destination brick of every entry of the current queue
+    uint32_t *posq;              // ... and its place in that queue
     int *hist;                   // [NB+1] arrivals per brick in the next pass; [NB] = finished
     int *off;                    // [NB+1] offsets of the next queues (scan output)
-    int *cursor;                 // [NB]
     const SocDesc *desc;         // descriptors of the current pass
     const int *ndesc;
     SocDesc *desc_next;
@@ -136,20 +136,32 @@ __device__ __forceinline__ int soc_qh_find(int *sH, int HS, int key)
     }
     return -1;
 }
-__device__ __forceinline__ void soc_qh_add(int *sH, int HS, int key, int *ghist)
+// The place of a packet in its destination queue is settled in the pass itself: the LDS count a packet bumps
+// is its rank among the workgroup's packets for that queue (returned as entry << 12 | rank); at the end the
+// workgroup adds its counts to the global histogram, and what the add returns is where its packets start in
+// the queue.  The sort is then a plain permutation (soc_brick_scatter).  SOC_POS_FINAL: counted in global
+// memory directly (hash table full around that key), the value is the place itself.
+#define SOC_POS_FINAL 0x80000000u
+__device__ __forceinline__ uint32_t soc_qh_rank(int *sH, int HS, int key, int *ghist)
 {
-    if (HS == 0) { atomicAdd(&sH[key], 1);  return; }
+    if (HS == 0) return ((uint32_t)key << 12) | (uint32_t)atomicAdd(&sH[key], 1);
     const int h = soc_qh_find(sH, HS, key);
-    if (h >= 0) atomicAdd(&sH[HS + h], 1);
-    else        atomicAdd(&ghist[key], 1);
+    if (h >= 0) return ((uint32_t)h << 12) | (uint32_t)atomicAdd(&sH[HS + h], 1);
+    return SOC_POS_FINAL | (uint32_t)atomicAdd(&ghist[key], 1);
 }
-__device__ __forceinline__ void soc_qh_flush(const int *sH, int HS, int NQ, int *ghist)
+// counts -> first places (all threads of the workgroup; barrier before and after by the caller)
+__device__ __forceinline__ void soc_qh_bases(int *sH, int HS, int NQ, int *ghist)
 {
     if (HS == 0) {
-        for (int i = threadIdx.x; i < NQ; i += blockDim.x) { const int c = sH[i];  if (c) atomicAdd(&ghist[i], c); }
+        for (int i = threadIdx.x; i < NQ; i += blockDim.x) { const int c = sH[i];  if (c) sH[i] = atomicAdd(&ghist[i], c); }
     } else {
-        for (int i = threadIdx.x; i < HS; i += blockDim.x) { const int k = sH[i], c = sH[HS + i];  if (k >= 0 && c) atomicAdd(&ghist[k], c); }
+        for (int i = threadIdx.x; i < HS; i += blockDim.x) { const int k = sH[i], c = sH[HS + i];  if (k >= 0 && c) sH[HS + i] = atomicAdd(&ghist[k], c); }
     }
+}
+__device__ __forceinline__ uint32_t soc_qh_place(const int *sH, int HS, uint32_t pack)
+{
+    if (pack & SOC_POS_FINAL) return pack & ~SOC_POS_FINAL;
+    return (uint32_t)sH[(HS ? HS : 0) + (pack >> 12)] + (pack & 4095u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -256,6 +268,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0] next packet, [1] tally events
     float *sL   = (float *)(sCtl + 2);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
     int   *sOFF = (int *)(sL + 3 * SOC_MAXLAUNCH);         // [SOC_MAXL] first cell of every level
+    uint32_t *sPos = (uint32_t *)(sOFF + SOC_MAXL);        // [P] table entry << 12 | rank of every packet of the chunk
     const SocSim &S = K.S[0];                              // what the launches share: tallies, stats, OPT (n == 1)
     if ((int)threadIdx.x < K.n) {
         sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
@@ -300,7 +313,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                         soc_st4(&q->C, make_float4(tau, dens, __int_as_float(lid | (level << SOC_LVL_SHIFT) | lsh), __int_as_float(ind)));
                         if (key >= A.NB) SOC_NT_STORE((uint32_t)mybrick, &q->D.w);   // scattering: the brick to come back to
                         SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + slot]);
-                        soc_qh_add(sH, A.HS, key, A.hist);
+                        sPos[slot] = soc_qh_rank(sH, A.HS, key, A.hist);
                     }
                     slot = atomicAdd(&sCtl[0], 1);
                     have = slot < D.count;
@@ -517,7 +530,9 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             }
         }
     }
-    soc_qh_flush(sH, A.HS, NQ, A.hist);
+    soc_qh_bases(sH, A.HS, NQ, A.hist);
+    __syncthreads();
+    for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, sPos[j]);
     if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
 }
 
@@ -550,6 +565,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
     if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
     __syncthreads();
     unsigned int n_tally = 0, n_pkt = 0, n_scat = 0;
+    uint32_t mypack = 0;                                   // one packet per lane (D.count <= blockDim.x)
 
     for (int j = threadIdx.x; j < D.count; j += blockDim.x) {
         const uint32_t wid = A.idq[D.start + j];
@@ -619,13 +635,15 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), (uint32_t)key);
         pk[wid] = p;
         A.keyq[D.start + j] = (uint32_t)key;
-        soc_qh_add(sH, A.HS, key, A.hist);
+        mypack = soc_qh_rank(sH, A.HS, key, A.hist);
     }
     atomicAdd(&sCtl[0], (int)n_tally);
     atomicAdd(&sCtl[1], (int)n_pkt);
     atomicAdd(&sCtl[2], (int)n_scat);
     __syncthreads();
-    soc_qh_flush(sH, A.HS, NQ, A.hist);
+    soc_qh_bases(sH, A.HS, NQ, A.hist);
+    __syncthreads();
+    if ((int)threadIdx.x < D.count) A.posq[D.start + threadIdx.x] = soc_qh_place(sH, A.HS, mypack);
     if (threadIdx.x == 0 && S.stats) {
         atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[0]);
         atomicAdd(S.stats + 1, (unsigned long long)(unsigned int)sCtl[1]);
@@ -696,7 +714,6 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
     for (int b = b0; b < b1; b++) {
         const int c = A.hist[b];
         A.off[b] = off;
-        A.cursor[b] = 0;
         if (b == A.ev_brick) A.ndesc_next[2] = offd;
         if (b >= A.ev_brick && ((b - A.ev_brick) & 1) == 0) {           // a creation queue: the admitted ids go to its end
             const int l = (b - A.ev_brick) >> 1;
@@ -723,7 +740,7 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
     }
 }
 
-// counting-sort placement: ids of the current queue -> next queues, by destination brick
+// the sort: ids of the current queue -> next queues; every entry knows its queue (keyq) and its place in it (posq)
 __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A, const int nsort)
 {
     if ((int)blockIdx.x >= nsort) {
@@ -738,54 +755,9 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A,
     }
     if ((int)blockIdx.x >= *A.ndesc) return;
     const SocDesc D = A.desc[blockIdx.x];
-    extern __shared__ int sB[];                          // [NB], or keys[HS] + counts[HS]
-    const int HS = A.HS;
-    soc_qh_init(sB, HS, A.NB);
-    __syncthreads();
-    uint32_t key[SOC_BRICK_PMAX / SOC_BRICK_T];
-    int      rank[SOC_BRICK_PMAX / SOC_BRICK_T];         // rank within (workgroup, destination); hash mode: | entry << 16
-#pragma unroll
-    for (int k = 0; k < SOC_BRICK_PMAX / SOC_BRICK_T; k++) {
-        const int j = k * SOC_BRICK_T + threadIdx.x;
-        key[k] = (uint32_t)A.NB;
-        rank[k] = 0;
-        if (j < D.count) {
-            key[k] = A.keyq[D.start + j];
-            if (key[k] < (uint32_t)A.NB) {
-                if (HS == 0) {
-                    rank[k] = atomicAdd(&sB[key[k]], 1);
-                } else {
-                    const int h = soc_qh_find(sB, HS, (int)key[k]);
-                    if (h >= 0) {
-                        rank[k] = atomicAdd(&sB[HS + h], 1) | (h << 16);
-                    } else {                             // table full around this key: place it now
-                        A.idq_next[A.off[key[k]] + atomicAdd(&A.cursor[key[k]], 1)] = A.idq[D.start + j];
-                        key[k] = (uint32_t)A.NB;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (HS == 0) {
-        for (int i = threadIdx.x; i < A.NB; i += SOC_BRICK_T) {
-            const int c = sB[i];
-            if (c) sB[i] = A.off[i] + atomicAdd(&A.cursor[i], c);
-        }
-    } else {
-        for (int i = threadIdx.x; i < HS; i += SOC_BRICK_T) {
-            const int q = sB[i], c = sB[HS + i];
-            if (q >= 0 && c) sB[HS + i] = A.off[q] + atomicAdd(&A.cursor[q], c);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < SOC_BRICK_PMAX / SOC_BRICK_T; k++) {
-        const int j = k * SOC_BRICK_T + threadIdx.x;
-        if (j < D.count && key[k] < (uint32_t)A.NB) {
-            const int base = (HS == 0) ? sB[key[k]] : sB[HS + (rank[k] >> 16)];
-            A.idq_next[base + (rank[k] & 0xffff)] = A.idq[D.start + j];
-        }
+    for (int j = threadIdx.x; j < D.count; j += SOC_BRICK_T) {
+        const uint32_t key = A.keyq[D.start + j];
+        if (key < (uint32_t)A.NB) A.idq_next[A.off[key] + A.posq[D.start + j]] = A.idq[D.start + j];
     }
 }
 
@@ -797,8 +769,8 @@ struct SocBrickBuffers {
     size_t cap_items = 0;
     int    cap_nq = 0, cap_desc = 0;
     SocPk2 *pk = nullptr;
-    uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr;
-    int *hist = nullptr, *off = nullptr, *cursor = nullptr, *ndesc = nullptr, *total = nullptr, *admit = nullptr;
+    uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr, *posq = nullptr;
+    int *hist = nullptr, *off = nullptr, *ndesc = nullptr, *total = nullptr, *admit = nullptr;
     SocDesc *desc[2] = { nullptr, nullptr };
 };
 
@@ -823,7 +795,7 @@ void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
     SocBrickBuffers &b = g_bb[device];
-    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.hist, b.off, b.cursor, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
+    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.posq, b.hist, b.off, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     b = SocBrickBuffers();
     soc_oct_release(device);
@@ -1024,7 +996,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     A.P = (V.octree ? 8 : 4) * A.T;                  // hierarchies: one chunk per brick queue (measured)
     A.KCAP = 32;
     A.FTH = 16;
-    A.CAP = 8192;
+    A.CAP = 6144;                                    // with P = 4096: 48 KB of LDS, three workgroups per CU (measured)
     A.TAIL = 0;
     if (const char *e = getenv("SOC_BRICK_TAIL")) A.TAIL = atoi(e);
     if (const char *e = getenv("SOC_BRICK_T")) A.T = atoi(e);
@@ -1085,13 +1057,13 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         BCHK(brick_alloc(&bb.idq[0], count));
         BCHK(brick_alloc(&bb.idq[1], count));
         BCHK(brick_alloc(&bb.keyq, count));
+        BCHK(brick_alloc(&bb.posq, count));
         bb.cap_items = count;
     }
     if (bb.cap_nq < NQ) {
         BCHK(hipStreamSynchronize(st));
         BCHK(brick_alloc(&bb.hist, NQ));
         BCHK(brick_alloc(&bb.off, NQ));
-        BCHK(brick_alloc(&bb.cursor, NQ));
         bb.cap_nq = NQ;
     }
     if (bb.cap_desc < maxdesc) {
@@ -1101,7 +1073,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         bb.cap_desc = maxdesc;
     }
     if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1));  BCHK(brick_alloc(&bb.admit, 1 + 3 * SOC_MAXLAUNCH)); }
-    A.pk = bb.pk;  A.keyq = bb.keyq;  A.hist = bb.hist;  A.off = bb.off;  A.cursor = bb.cursor;  A.total = bb.total;
+    A.pk = bb.pk;  A.keyq = bb.keyq;  A.posq = bb.posq;  A.hist = bb.hist;  A.off = bb.off;  A.total = bb.total;
     A.admit = bb.admit;
     // packets in flight: the work items of the first `population` launches (0: all of them); the rest are admitted
     // as those finish -- one tail per sweep instead of one per `population` launches
@@ -1112,10 +1084,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL) * 4;
+    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
-    const size_t lds_scat = (size_t)nh * 4;
     if (lds > 160 * 1024) return hipErrorNotSupported;
     const int vkey = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
     const int slices = (A.P + A.T - 1) / A.T;
@@ -1137,7 +1108,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             Q.NB = NQ - 1;
             Q.ev_brick = A.NB;
             soc_brick_scan<<<1, 1024, 0, st>>>(Q);
-            soc_brick_scatter<<<maxdesc + 16 * K.n, SOC_BRICK_T, lds_scat, st>>>(Q, maxdesc);
+            soc_brick_scatter<<<maxdesc + 16 * K.n, SOC_BRICK_T, 0, st>>>(Q, maxdesc);
         }
         BCHK(hipGetLastError());
         BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));
