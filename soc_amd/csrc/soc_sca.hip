@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
     int   mlevel = 0, mind = -1, lvl_post = 0;
     float free_path = 0.0f, tau = 0.0f, taup = 0.0f;
     float dxrem = 0.0f, invd2 = 0.0f;                    // Healpix: distance left to the observer, 1/d^2
+    float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;            // correctly rounded reciprocals of the current ray's direction
     int   scat = 0, idir = 0;
     unsigned int n_add = 0, n_pkt = 0, n_scat = 0;
 
@@ -294,6 +295,8 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                     }
                 }
             }
+            // every change of the current ray's direction happens in this arm: its reciprocals for GetStep
+            if (!stepping) { rux = 1.0f / w.ux;  ruy = 1.0f / w.uy;  ruz = 1.0f / w.uz; }
         }
         if (__ballot(mode != SCA_M_DONE) == 0ull) break;
 
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
             float kabs, ksca;
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
             else     { kabs = S.ABS;  ksca = S.SCA; }
-            const float ds = soc_getstep<OCT, DBL>(G, sOFF, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
+            const float ds = soc_getstep_rcp<OCT, DBL>(G, sOFF, w.px, w.py, w.pz, w.ux, w.uy, w.uz, rux, ruy, ruz, w.level, w.ind, w.dens);
             if (mode == SCA_M_PEEL) {
                 if (HPX) {
                     // only as far as the observer (:329-335); SimRAM_PB adds its 1.0e-6 in double (:982)
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                 } else {
                     tau += dtau;
                     if ((S.MIRROR > 0) && (w.ind < 0))       // kernel_ASOC_sca.c:983, :1283, :1781
+                    {
                         soc_mirror<OCT>(G, sOFF, S.MIRROR, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
+                        rux = 1.0f / w.ux;  ruy = 1.0f / w.uy;  ruz = 1.0f / w.uz;          // a reflected component changed sign
+                    }
                     if (w.ind < 0) mode = SCA_M_CREATE;
                 }
             }

@@ -165,6 +165,34 @@ __device__ __forceinline__ float soc_getstep(const SocGrid &G, const int *sOFF, 
     return s;
 }
 
+// GetStep with the reference's results from fewer instructions (each identity is tested in tests/test_math.py):
+// fmod(p,1) of a non-negative p is v_fract; n/u from the cached, correctly rounded r = 1/u by Markstein's
+// correction (soc_div_by_rcp).  For rays whose direction is fixed over many steps (the brick walk, the
+// scattered-light kernels).
+template <bool OCT, bool DBL>
+__device__ __forceinline__ float soc_getstep_rcp(const SocGrid &G, const int *sOFF, float &px, float &py, float &pz,
+                                                 float ux, float uy, float uz, float rux, float ruy, float ruz,
+                                                 int &level, int &ind, float &dens)
+{
+    float fx, fy, fz;
+    if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
+        fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
+    } else {
+        fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
+    }
+    const float ax = soc_div_by_rcp(((ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fx, ux, rux);
+    const float ay = soc_div_by_rcp(((uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fy, uy, ruy);
+    const float az = soc_div_by_rcp(((uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS) - fz, uz, ruz);
+    float s = __builtin_fminf(ax, __builtin_fminf(ay, az));
+    px += s * ux;
+    py += s * uy;
+    pz += s * uz;
+    s = soc_scale_down(s, level);
+    if (DBL) soc_index<OCT, double>(G, sOFF, px, py, pz, level, ind, dens);
+    else     soc_index<OCT, float>(G, sOFF, px, py, pz, level, ind, dens);
+    return s;
+}
+
 // Deflect (kernel_ASOC_aux.c:499-533)
 __device__ __forceinline__ void soc_deflect(float &ux, float &uy, float &uz, const float COS_THETA, const float phi)
 {
