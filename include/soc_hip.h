@@ -79,6 +79,15 @@ int soc_set_optical(soc_ctx *ctx, const float *ABS, const float *SCA, int ndust)
  * OPT[CELLS][2] = (abs, sca) per cell; NULL switches back to scalar ABS/SCA */
 int soc_set_opt(soc_ctx *ctx, const float *OPT);
 
+/* The same OPT without the 8*CELLS-byte upload per frequency (ASOC.py:1146-1160, "0.43 s / 2.5 s" :1177): the
+ * abundances go to the device once -- ABU[CELLS][NDUST], or with single != 0 ABU[CELLS] for two species with
+ * abundances ABU and 1-ABU (USER.SINGLE_ABU, :1148-1153); ABU = NULL forgets them -- and for every frequency
+ * soc_set_optical_abu(AFABS[NDUST], AFSCA[NDUST]) computes OPT = sum ABU * AF on the device, in the order and
+ * precision of the numpy expressions (bit-identical to the host's OPT).  soc_read_opt copies OPT back. */
+int soc_set_abundances(soc_ctx *ctx, int NDUST, int single, const float *ABU);
+int soc_set_optical_abu(soc_ctx *ctx, const float *AFABS, const float *AFSCA, int ndust);
+int soc_read_opt(soc_ctx *ctx, float *OPT);
+
 /* replaces the DSC/CSC row uploads (ASOC.py:1234-1243, ASOCS.py:625-626); DSC may be NULL
  * (unused by the absorption kernels, required by soc_sca_sim_ps/pb); BINS = USER.DSC_BINS */
 int soc_set_scatter_table(soc_ctx *ctx, const float *DSC, const float *CSC, int BINS);

@@ -135,6 +135,8 @@ class AbsorptionRun:
         e.set_cloud(c)
         e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 2))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
+        if self.WITH_ABU:
+            e.set_abundances(self.ABU, single=bool(U.SINGLE_ABU))
         if self.comm:
             self.comm.attach(e, c.CELLS)
 
@@ -142,15 +144,9 @@ class AbsorptionRun:
         """scalar ABS,SCA summed over species, or OPT[CELLS,2] with abundances (ASOC.py:1146-1175)"""
         e = self.eng
         if self.WITH_ABU:
-            OPT = np.zeros((self.cloud.CELLS, 2), np.float32)
-            if self.U.SINGLE_ABU:
-                OPT[:, 0] += self.ABU * self.AFABS[0][IFREQ] + (1.0 - self.ABU) * self.AFABS[1][IFREQ]
-                OPT[:, 1] += self.ABU * self.AFSCA[0][IFREQ] + (1.0 - self.ABU) * self.AFSCA[1][IFREQ]
-            else:
-                for idust in range(self.NDUST):
-                    OPT[:, 0] += self.ABU[:, idust] * self.AFABS[idust][IFREQ]
-                    OPT[:, 1] += self.ABU[:, idust] * self.AFSCA[idust][IFREQ]
-            e.set_opt(OPT)
+            # OPT = sum over species of ABU * (AFABS, AFSCA) is built on the device from the abundances uploaded
+            # once (setup_engine); the reference uploads 8*CELLS bytes per frequency (ASOC.py:1146-1160,1177)
+            e.set_optical_abu([a[IFREQ] for a in self.AFABS], [a[IFREQ] for a in self.AFSCA])
             ABS = np.float32(sum(a[IFREQ] for a in self.AFABS))
             SCA = np.float32(sum(a[IFREQ] for a in self.AFSCA))
         else:

@@ -40,6 +40,9 @@ struct soc_ctx {
     int   *dEMINDEX = nullptr;
     bool   have_emit = false, have_emindex = false, with_ali = false;
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
+    float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
+    int    abu_ndust = 0, abu_single = 0;
+    size_t abu_cells = 0;
     SocRoi roi{};                                 // region of interest (host copy of *dRoi)
     SocRoi *dRoi = nullptr;
     float *dRoiSave = nullptr, *dRoiLoad = nullptr;
@@ -200,7 +203,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -279,6 +282,7 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
         if (c->dXAB) { (void)hipFree(c->dXAB); c->dXAB = nullptr; }
         if (c->dEMINDEX) { (void)hipFree(c->dEMINDEX); c->dEMINDEX = nullptr; }
         c->have_T = false;  c->with_ali = false;  c->have_emindex = false;
+        c->abu_ndust = 0;  c->abu_cells = 0;
     }
     c->G = G;
     c->have_grid = true;
@@ -347,6 +351,58 @@ int soc_set_opt(soc_ctx *c, const float *OPT)
     }
     if (!c->dOPT) HIPCHK(c, dev_alloc(&c->dOPT, (size_t)c->G.CELLS));
     HIPCHK(c, hipMemcpyAsync(c->dOPT, OPT, (size_t)c->G.CELLS * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_abundances(soc_ctx *c, int NDUST, int single, const float *ABU)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_abundances: call soc_set_grid first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!ABU) {                                             // off
+        c->abu_ndust = 0;
+        c->abu_cells = 0;
+        return SOC_OK;
+    }
+    if (NDUST < 1 || NDUST > 64 || (single && NDUST != 2))
+        return fail(c, SOC_ERR_ARG, "soc_set_abundances: NDUST %d (1..64; the one-abundance form describes exactly two species)", NDUST);
+    const size_t n = (size_t)c->G.CELLS * (single ? 1 : NDUST);
+    for (size_t i = 0; i < n; i++)
+        if (!std::isfinite(ABU[i])) return fail(c, SOC_ERR_ARG, "soc_set_abundances: ABU[%zu] is not finite", i);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, dev_alloc(&c->dABU, n));
+    HIPCHK(c, dev_alloc(&c->dAF, (size_t)2 * NDUST));
+    HIPCHK(c, hipMemcpyAsync(c->dABU, ABU, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->abu_ndust = NDUST;  c->abu_single = single ? 1 : 0;  c->abu_cells = (size_t)c->G.CELLS;
+    return SOC_OK;
+}
+
+int soc_set_optical_abu(soc_ctx *c, const float *AFABS, const float *AFSCA, int ndust)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->abu_ndust || c->abu_cells != (size_t)c->G.CELLS) return fail(c, SOC_ERR_STATE, "soc_set_optical_abu: call soc_set_abundances (after soc_set_grid) first");
+    if (!AFABS || !AFSCA || ndust != c->abu_ndust) return fail(c, SOC_ERR_ARG, "soc_set_optical_abu: need the cross sections of the %d species", c->abu_ndust);
+    HIPCHK(c, hipSetDevice(c->device));
+    float af[128];
+    for (int d = 0; d < ndust; d++) { af[d] = AFABS[d];  af[ndust + d] = AFSCA[d]; }
+    if (!c->dOPT) HIPCHK(c, dev_alloc(&c->dOPT, (size_t)c->G.CELLS));
+    HIPCHK(c, hipMemcpyAsync(c->dAF, af, (size_t)2 * ndust * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));             // af is on the stack
+    HIPCHK(c, soc_launch_opt(c->G.CELLS, ndust, c->abu_single, c->dABU, c->dAF, c->dOPT, c->stream));
+    return SOC_OK;
+}
+
+int soc_read_opt(soc_ctx *c, float *OPT)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->dOPT || !OPT) return fail(c, SOC_ERR_STATE, "soc_read_opt: no per-cell opacities are set");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(OPT, c->dOPT, (size_t)c->G.CELLS * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
 }

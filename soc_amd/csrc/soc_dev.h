@@ -100,6 +100,9 @@ hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin
 hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
                                const float *T, float *EMIT, hipStream_t st);
 
+// OPT from abundances on the device (soc_emit.hip)
+hipError_t soc_launch_opt(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT, hipStream_t st);
+
 // map making (soc_map.hip): one launch of Mapping / HealpixMapping (kernel_ASOC_map.c:496-516, 890-910)
 struct SocMapArgs {
     int   mode;                    // 0 Mapping, 1 HealpixMapping (NSIDE = NPIX_X)

@@ -63,3 +63,37 @@ hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LE
     soc_emission_kernel<<<blocks, 256, 0, st>>>(c0, c1, nfreq, FACTOR, LENGTH, FREQ, FABS, T, EMIT);
     return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------
+// OPT[CELLS][2] = sum over species of ABU * (AFABS, AFSCA), on the device: the reference builds it on the host
+// for every frequency and uploads 8*CELLS bytes (ASOC.py:1146-1160; "0.43 s / 2.5 s", :1177).  Same fp32
+// operations in the same order as the numpy expressions, so the values are the host's bit for bit.
+// ------------------------------------------------------------------------------------
+__global__ void soc_opt_kernel(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT)
+{
+    // AF = [AFABS[0..ndust), AFSCA[0..ndust)] of the current frequency
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < cells; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.0f, s = 0.0f;
+        if (single) {                                    // two species with abundances ABU and 1-ABU (ASOC.py:1148-1153)
+            const float x = ABU[i], y = 1.0f - x;
+            a = a + (x * AF[0] + y * AF[1]);
+            s = s + (x * AF[2] + y * AF[3]);
+        } else {
+            for (int d = 0; d < ndust; d++) {            // ASOC.py:1155-1157
+                const float x = ABU[(size_t)i * ndust + d];
+                a = a + x * AF[d];
+                s = s + x * AF[ndust + d];
+            }
+        }
+        OPT[i] = make_float2(a, s);
+    }
+}
+
+hipError_t soc_launch_opt(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT, hipStream_t st)
+{
+    if (cells <= 0) return hipSuccess;
+    const int blocks = (cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384;
+    soc_opt_kernel<<<blocks, 256, 0, st>>>(cells, ndust, single, ABU, AF, OPT);
+    return hipGetLastError();
+}

@@ -45,6 +45,9 @@ API = {
     "soc_batch_end": (C.c_int, [C.c_void_p]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
+    "soc_set_abundances": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _F]),
+    "soc_set_optical_abu": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
+    "soc_read_opt": (C.c_int, [C.c_void_p, _F]),
     "soc_set_roi_save": (C.c_int, [C.c_void_p, _I, C.c_int, C.c_int]),
     "soc_roi_zero": (C.c_int, [C.c_void_p]),
     "soc_roi_read": (C.c_int, [C.c_void_p, _F, C.c_long]),
@@ -204,6 +207,28 @@ class Engine:
         if OPT.size != 2 * self.CELLS:
             raise SocError("set_opt: OPT must hold 2*CELLS floats")
         self._chk(self.lib.soc_set_opt(self.h, _f(OPT)))
+
+    def set_abundances(self, ABU, single=False):
+        """abundances once per run: ABU[CELLS, NDUST], or ABU[CELLS] with single=True (two species, ABU and 1-ABU);
+        None forgets them.  set_optical_abu then builds OPT on the device for every frequency."""
+        if ABU is None:
+            self._chk(self.lib.soc_set_abundances(self.h, 0, 0, None))
+            return
+        ABU = np.ascontiguousarray(ABU, np.float32)
+        ndust = 2 if single else (ABU.shape[1] if ABU.ndim == 2 else 1)
+        if ABU.size != self.CELLS * (1 if single else ndust):
+            raise SocError("set_abundances: ABU must hold CELLS x NDUST values")
+        self._chk(self.lib.soc_set_abundances(self.h, int(ndust), int(bool(single)), _f(ABU)))
+
+    def set_optical_abu(self, AFABS, AFSCA):
+        a = np.ascontiguousarray(AFABS, np.float32).ravel()
+        s = np.ascontiguousarray(AFSCA, np.float32).ravel()
+        self._chk(self.lib.soc_set_optical_abu(self.h, _f(a), _f(s), int(a.size)))
+
+    def read_opt(self):
+        out = np.zeros((self.CELLS, 2), np.float32)
+        self._chk(self.lib.soc_read_opt(self.h, _f(out)))
+        return out
 
     def set_scatter_table(self, DSC, CSC):
         CSC = np.ascontiguousarray(CSC, np.float32)

@@ -37,6 +37,25 @@ class OracleEngine:
     def set_opt(self, OPT):
         self.OPT = OPT
 
+    def set_abundances(self, ABU, single=False):
+        self.ABU, self.abu_single = (None if ABU is None else np.asarray(ABU, np.float32)), bool(single)
+
+    def set_optical_abu(self, AFABS, AFSCA):
+        """the numpy expressions of ASOC.py:1146-1160"""
+        OPT = np.zeros((self.cloud.CELLS, 2), np.float32)
+        if self.abu_single:
+            OPT[:, 0] += self.ABU * np.float32(AFABS[0]) + (1.0 - self.ABU) * np.float32(AFABS[1])
+            OPT[:, 1] += self.ABU * np.float32(AFSCA[0]) + (1.0 - self.ABU) * np.float32(AFSCA[1])
+        else:
+            ABU = self.ABU.reshape(self.cloud.CELLS, -1)
+            for d in range(ABU.shape[1]):
+                OPT[:, 0] += ABU[:, d] * np.float32(AFABS[d])
+                OPT[:, 1] += ABU[:, d] * np.float32(AFSCA[d])
+        self.OPT = OPT
+
+    def read_opt(self):
+        return self.OPT.copy()
+
     def set_scatter_table(self, DSC, CSC):
         self.DSC, self.CSC = DSC, CSC
 

@@ -187,3 +187,43 @@ def test_errors_are_reported_not_fatal(engine):
         engine.set_scatter_table(None, np.linspace(1, -1, 100))
         engine.set_optical(1e-3, 1e-3)
         engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=100, gid_first=90, gid_count=20)
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_opt_from_abundances_on_device(single, engine, oracle_soc):
+    """soc_set_abundances + soc_set_optical_abu: OPT built on the device is the numpy OPT of ASOC.py:1146-1160
+    bit for bit, and a launch with it is the launch with the uploaded OPT"""
+    cl = cases._oct8()
+    rr = np.random.default_rng(8)
+    ndust = 2 if single else 3
+    ABU = rr.uniform(0.0, 1.0, cl.CELLS if single else (cl.CELLS, ndust)).astype(np.float32)
+    AFABS = (1e-4 * rr.uniform(0.3, 3, ndust)).astype(np.float32)
+    AFSCA = (3e-4 * rr.uniform(0.3, 3, ndust)).astype(np.float32)
+    OPT = np.zeros((cl.CELLS, 2), np.float32)
+    if single:
+        OPT[:, 0] += ABU * AFABS[0] + (1.0 - ABU) * AFABS[1]
+        OPT[:, 1] += ABU * AFSCA[0] + (1.0 - ABU) * AFSCA[1]
+    else:
+        for d in range(ndust):
+            OPT[:, 0] += ABU[:, d] * AFABS[d]
+            OPT[:, 1] += ABU[:, d] * AFSCA[d]
+    engine.set_cloud(cl)
+    engine.set_abundances(ABU, single=single)
+    engine.set_optical_abu(AFABS, AFSCA)
+    assert np.array_equal(engine.read_opt().view(np.uint32), OPT.view(np.uint32))
+    job = Job(cl, cases._CSC, SOURCE=1, BATCH=6, SEED=0.3, OPT=OPT)
+    T, _, n = oracle_soc.sim(job, 0)
+    engine.set_features(0, 0, 0)
+    engine.set_scatter_table(job.DSC, job.CSC)
+    engine.set_optical(0.0, 0.0)
+    engine.set_mirror(0)
+    engine.set_exec(0, 4)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.sim_pb(1, 0, job.BATCH, job.SEED, job.BG, job.TW, GLOBAL=job.GLOBAL)
+    engine.sync()
+    assert engine.stats()["tally_events"] == n
+    assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
+    engine.set_abundances(None)
+    engine.set_opt(None)
+    engine.set_exec(-1, 4)

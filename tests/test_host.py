@@ -293,3 +293,43 @@ def test_nested_run_roi_save_then_load(tmp_path):
                   WITH_INT=1, ROI_LOAD=np.asarray(rec[i] * 1.5 / (GL * GL), np.float32), ROI_DIM=[8, 8, 4], ROI_NSIDE=2)
         orc.sim(job, 0, TABS=T)
     assert T.sum() > 0 and np.array_equal(C2, T)
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_abundance_run(single, tmp_path):
+    """optical <dust> <abundance file> (+ singleabu): per-cell opacities = sum of abundance x cross section
+    (ASOC.py:1146-1160), built by the engine from abundances handed over once"""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    os.chdir(d)
+    cloud = synth.cartesian_cloud(6, seed=2)
+    rr = np.random.default_rng(4)
+    abu = rr.uniform(0.2, 1.0, cloud.CELLS).astype(np.float32)
+    abu.tofile(os.path.join(d, "a.abu"))
+    GL = 5.0e-7
+    ini = _write_model(d, cloud, nfreq=2, extra="gridlength %g\n" % GL)
+    with open(os.path.join(d, "m2.dust"), "w") as fp:
+        fp.write("eqdust\n 1.0e-7\n 0.7e-4\n2\n 4.00000e+14  0.6  2.0e-2  1.2e-1\n 4.67700e+14  0.6  2.5e-2  1.0e-1\n")
+    txt = open(ini).read().replace("optical %s/m.dust\n" % d, "optical %s/m.dust %s/a.abu\noptical %s/m2.dust\n" % (d, d, d))
+    txt = txt.replace("dsc %s/m.dsc 500\n" % d, "dsc %s/m.dsc 500\n" % d) + ("singleabu\n" if single else "")
+    open(ini, "w").write(txt)
+    U = User(ini)
+    assert U.file_abundance == [os.path.join(d, "a.abu"), "#"] and U.SINGLE_ABU == int(single)
+    run = AbsorptionRun(U, OracleEngine("soc"))
+    CT, _ = run.run()
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust"), os.path.join(d, "m2.dust")], GL)
+    second = (1.0 - abu) if single else np.ones(cloud.CELLS, np.float32)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 2, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, cloud.AREA)
+    T = np.zeros(cloud.CELLS, np.float32)
+    for i in range(2):
+        OPT = np.zeros((cloud.CELLS, 2), np.float32)
+        OPT[:, 0] = abu * AFABS[0][i] + second * AFABS[1][i]
+        OPT[:, 1] = abu * AFSCA[0][i] + second * AFSCA[1][i]
+        job = Job(cloud, FCSC[0, i], SOURCE=1, BATCH=L["BATCH"], SEED=launch.launch_seed(math.pi / 4, i),
+                  BG=np.float32(float(IBG[i]) * L["WBG"] / float(FFREQ[i])), TW=launch.trapezoid_weight(FFREQ, i),
+                  GLOBAL=L["GLOBAL"], WITH_INT=1, OPT=OPT)
+        Oracle("soc").sim(job, 0, TABS=T)
+    assert T.sum() > 0 and np.allclose(CT, T, rtol=2e-6)
