@@ -66,3 +66,72 @@ def test_sharding_and_seed_change(engine, big):
     Ts, sts = run(engine, big, 8, 0.75)
     assert sts["tally_events"] != stw["tally_events"]
     assert abs(Ts.sum(dtype=np.float64) / Tw.sum(dtype=np.float64) - 1) < 5e-3
+
+
+def test_full_size_direct_kernel_equals_brick_sweep(engine, big):
+    """the two execution modes run the same packets: integer event counts equal, tallies to summation order;
+    and four deferred launches in one sweep equal the four run one after the other"""
+    engine.set_exec(0, 4)
+    Td, sd = run(engine, big, 16, 0.41)
+    assert engine.last_passes() == 0
+    engine.set_exec(1, 4)
+    Tb, sb = run(engine, big, 16, 0.41)
+    assert engine.last_passes() > 0
+    assert sb == sd
+    assert np.allclose(Tb, Td, rtol=2e-5, atol=0)
+    G = 8 * big.AREA
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    for k in range(4):
+        engine.sim_pb(1, 0, 8, 0.1 + 0.2 * k, 1.0 + k, 1.0, GLOBAL=G)
+    engine.batch_end()
+    Tq, sq = engine.read_tally(0), engine.stats()
+    engine.zero(0)
+    engine.stats(reset=True)
+    for k in range(4):
+        engine.sim_pb(1, 0, 8, 0.1 + 0.2 * k, 1.0 + k, 1.0, GLOBAL=G)
+    Ts, ss = engine.read_tally(0), engine.stats()
+    assert sq == ss
+    assert np.allclose(Tq, Ts, rtol=2e-5, atol=0)
+
+
+def test_full_size_hierarchy_direct_equals_brick_sweep(engine):
+    """BASELINE configs[2] geometry (256^3 roots, 4 levels, Index in double): 3.1e6 work items through the
+    direct kernel, the brick sweep, and two launches deferred into one sweep"""
+    cloud = synth.octree_cloud(256, levels=4, frac=0.10, seed=1234)
+    _, csc = synth.hg_scattering_table(0.6)
+    engine.set_cloud(cloud)
+    engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_scatter_table(None, csc)
+    engine.set_optical(0.5 * ABS, 0.5 * SCA)
+    engine.set_opt(None)
+    G = 8 * cloud.AREA
+    engine.set_exec(0, 4)
+    Td, sd = run(engine, cloud, 2, 0.41)
+    assert sd["packets"] == 2 * G
+    steps = sd["tally_events"] / sd["packets"]
+    assert 256 < steps < 330                                     # ~N for the root grid + the refined cells on the way
+    engine.set_exec(1, 4)
+    Tb, sb = run(engine, cloud, 2, 0.41)
+    assert engine.last_passes() > 0
+    assert sb == sd
+    leaf = cloud.DENS > 0
+    assert (Tb[~leaf] == 0).all() and (Td[~leaf] == 0).all()    # refined cells never receive a tally
+    assert np.allclose(Tb[leaf], Td[leaf], rtol=2e-5, atol=1e-6 * Td.max())
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    engine.sim_pb(1, 0, 2, 0.41, 1.0, 1.0, GLOBAL=G)
+    engine.sim_pb(1, 0, 1, 0.77, 3.0, 1.0, GLOBAL=G)
+    engine.batch_end()
+    Tq, sq = engine.read_tally(0), engine.stats()
+    assert engine.last_passes() > 0
+    engine.set_exec(0, 4)
+    T2, s2 = run(engine, cloud, 1, 0.77, BG=3.0)
+    assert sq["tally_events"] == sd["tally_events"] + s2["tally_events"] and sq["packets"] == 3 * G
+    assert np.allclose(Tq[leaf], (Td + T2)[leaf], rtol=2e-5, atol=1e-6 * Td.max())
+    engine.set_exec(-1, 4)
