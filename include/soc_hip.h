@@ -124,8 +124,8 @@ int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
 
 /* Deferred execution of consecutive soc_sim_pb launches (no counterpart in the reference, which
  * runs one kernel per frequency and waits for it, ASOC.py:1360-1461).  Between soc_batch_begin and
- * soc_batch_end a launch that qualifies for the brick sweep with scalar opacities and without the
- * per-frequency INT tally is recorded with a snapshot of its inputs (ABS, SCA, scattering table,
+ * soc_batch_end a launch that qualifies for the brick sweep and runs without the per-frequency INT
+ * tally is recorded with a snapshot of its inputs (ABS, SCA or the per-cell OPT, scattering table,
  * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default: 4 on
  * Cartesian grids, 8 on hierarchies; at most 8): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
  * flight per pass.  Any other call that reads or changes engine state executes what is pending

@@ -98,6 +98,7 @@ struct SocBrickArgs {
     int *total;                  // packets still in flight after this pass
     int ev_brick;                // scan: first event queue (descriptors from here on belong to soc_brick_events)
     int HS;                      // arrivals per destination, per workgroup: 0 = LDS table indexed by queue, else hash table of HS entries
+    long long opt_stride;        // per-cell opacities of launch l start at OPT + l * opt_stride (several launches with abundances)
     // population control: work items [0, target) start at once, the others are admitted (in order) as work items
     // finish, so that the sweep runs with `target` packets in flight until the last launch drains
     int target, nl;
@@ -354,7 +355,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 ind0 = ind;  level0 = level;
                 const int   lid0 = lid;
                 const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-                if (ABU) { float2 o = S.OPT[sOFF[level] + ind];  kabs = o.x;  ksca = o.y; }
+                if (ABU) { float2 o = S.OPT[(lsh >> SOC_LCH_SHIFT) * A.opt_stride + sOFF[level] + ind];  kabs = o.x;  ksca = o.y; }
                 float fx, fy, fz;
                 if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
                     fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
@@ -445,7 +446,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
         if (mode == SOC_BM_STEP) {
             const int   oind = ind, lid0 = lid;
             const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-            if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
+            if (ABU) { float2 o = S.OPT[(lsh >> SOC_LCH_SHIFT) * A.opt_stride + oind];  kabs = o.x;  ksca = o.y; }
             // GetStep (kernel_ASOC_aux.c:282-315) with the same results from fewer instructions:
             //  * fmod(p,1) of a positive p is v_fract (exact); a lane with a negative coordinate (possible
             //    only right after a failed-step nudge) sends the wave through the general form;
@@ -958,7 +959,7 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
 }
 
 // LB: log2 of the brick edge (Cartesian grids; hierarchies use bricks of <= CAP leaves).  nlaunch launches
-// (same geometry, same tallies; scalar opacities and no INT tally when nlaunch > 1) share one sweep: more
+// (same geometry, same tallies; no INT tally when nlaunch > 1) share one sweep: more
 // packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
 // others.  Returns hipErrorNotSupported when the launches cannot use bricks.
 template <bool OCT, bool DBL>
@@ -986,7 +987,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
                             int population, hipStream_t st, int *passes_out)
 {
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
-    if (nlaunch > 1 && (V.abu || V.wint)) return hipErrorNotSupported;
+    if (nlaunch > 1 && V.wint) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
@@ -1044,6 +1045,13 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     }
     if (K.n == 0) { if (passes_out) *passes_out = 0;  return hipSuccess; }
     for (int l = K.n; l <= SOC_MAXLAUNCH; l++) K.first[l] = count;
+    // several launches with per-cell opacities: their OPT arrays are slots of one buffer (soc_capi.hip)
+    A.opt_stride = 0;
+    if (V.abu && K.n > 1) {
+        A.opt_stride = (long long)(K.S[1].OPT - K.S[0].OPT);
+        for (int l = 1; l < K.n; l++)
+            if ((long long)(K.S[l].OPT - K.S[0].OPT) != l * A.opt_stride) return hipErrorInvalidValue;
+    }
     const int NQ = A.NB + 2 * K.n + 1;
     const int maxdesc = (int)((count + A.P - 1) / A.P) + NQ + K.n;
     A.HS = (NQ > 4096) ? 1024 : 0;

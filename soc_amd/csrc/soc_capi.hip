@@ -63,6 +63,8 @@ struct soc_ctx {
     int    batch_max = 4;
     std::vector<SocSim> pending;
     float *dCSCslot[SOC_MAXLAUNCH] = {};
+    float2 *dOPTslots = nullptr;                  // [SOC_MAXLAUNCH][CELLS] per-cell opacities of deferred launches
+    size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
     // rng
     uint64_t *dSeedTab = nullptr;
@@ -129,7 +131,7 @@ static int flush_pending(soc_ctx *c)
     todo.swap(c->pending);
     SocVariant V;
     V.octree = c->G.LEVELS > 1;  V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
-    V.abu = 0;  V.wint = 0;                                  // what makes a launch deferrable (see soc_sim_pb)
+    V.abu = todo[0].OPT != nullptr;  V.wint = 0;             // what makes a launch deferrable (see soc_sim_pb)
     HIPCHK(c, hipSetDevice(c->device));
     if (V.octree && todo.size() == 1 && c->exec_mode < 0) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
@@ -203,7 +205,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -341,7 +343,7 @@ int soc_set_optical(soc_ctx *c, const float *ABS, const float *SCA, int ndust)
 int soc_set_opt(soc_ctx *c, const float *OPT)
 {
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
+    // no flush: a deferred launch keeps its own copy of the opacities (soc_sim_pb)
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_opt: call soc_set_grid first");
     HIPCHK(c, hipSetDevice(c->device));
     if (!OPT) {
@@ -383,7 +385,7 @@ int soc_set_abundances(soc_ctx *c, int NDUST, int single, const float *ABU)
 int soc_set_optical_abu(soc_ctx *c, const float *AFABS, const float *AFSCA, int ndust)
 {
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
+    // no flush: a deferred launch keeps its own copy of the opacities (soc_sim_pb)
     if (!c->abu_ndust || c->abu_cells != (size_t)c->G.CELLS) return fail(c, SOC_ERR_STATE, "soc_set_optical_abu: call soc_set_abundances (after soc_set_grid) first");
     if (!AFABS || !AFSCA || ndust != c->abu_ndust) return fail(c, SOC_ERR_ARG, "soc_set_optical_abu: need the cross sections of the %d species", c->abu_ndust);
     HIPCHK(c, hipSetDevice(c->device));
@@ -607,13 +609,14 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.abu && !V.wint));
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
-    const bool defer = c->batching && bricks && !V.abu && !V.wint;
+    const bool defer = c->batching && bricks && !V.wint;
     if (!defer) FLUSH(c);
+    if (defer && !c->pending.empty() && ((c->pending[0].OPT != nullptr) != (V.abu != 0))) FLUSH(c);   // one kernel variant per sweep
     const int slot = defer ? (int)c->pending.size() : 0;
     if (SOURCE == 0) {
         r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false, slot);
@@ -630,6 +633,16 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         }
         HIPCHK(c, hipMemcpyAsync(c->dCSCslot[slot], c->dCSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
         S.CSC = c->dCSCslot[slot];
+        if (V.abu) {                                        // the per-cell opacities of this launch: slot of one buffer
+            const size_t cells = (size_t)c->G.CELLS;
+            if (c->optslot_cells != cells) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, dev_alloc(&c->dOPTslots, cells * SOC_MAXLAUNCH));
+                c->optslot_cells = cells;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->dOPTslots + (size_t)slot * cells, c->dOPT, cells * 8, hipMemcpyDeviceToDevice, c->stream));
+            S.OPT = c->dOPTslots + (size_t)slot * cells;
+        }
         c->pending.push_back(S);
         if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
         return SOC_OK;

@@ -217,3 +217,43 @@ def test_deferred_launches_on_hierarchy(engine, oracle_soc):
     Td, sd, pd = run(3, False)
     assert pd == 0 and sd["tally_events"] == n
     assert_tally_close(Td, T, rtol=1e-5)
+
+
+@pytest.mark.parametrize("octree", [False, True])
+def test_deferred_launches_with_abundances(octree, engine, oracle_soc):
+    """launches with per-cell opacities (a different OPT each, built on the device from abundances) share one
+    sweep: every deferred launch keeps its own copy of OPT"""
+    cl = synth.octree_cloud(40, levels=3, frac=0.1, seed=3) if octree else synth.cartesian_cloud(40, seed=21)
+    rr = np.random.default_rng(5)
+    ABU = rr.uniform(0.1, 1.0, (cl.CELLS, 2)).astype(np.float32)
+    AF = [((2e-5, 1e-5), (6e-5, 2e-5)), ((1e-5, 4e-5), (3e-5, 5e-5)), ((3e-5, 2e-5), (2e-5, 8e-5))]
+    _, csc = synth.hg_scattering_table(0.6)
+    T = np.zeros(cl.CELLS, np.float32)
+    n = 0
+    for k, (fa, fs) in enumerate(AF):
+        OPT = np.zeros((cl.CELLS, 2), np.float32)
+        for d in range(2):
+            OPT[:, 0] += ABU[:, d] * np.float32(fa[d])
+            OPT[:, 1] += ABU[:, d] * np.float32(fs[d])
+        _, _, m = oracle_soc.sim(Job(cl, csc, SOURCE=1, BATCH=2, SEED=0.2 + 0.3 * k, BG=1.0 + k, OPT=OPT), 0, TABS=T, nthreads=8)
+        n += m
+    engine.set_cloud(cl)
+    engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_scatter_table(None, csc)
+    engine.set_optical(0.0, 0.0)
+    engine.set_abundances(ABU)
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    for k, (fa, fs) in enumerate(AF):
+        engine.set_optical_abu(fa, fs)
+        engine.sim_pb(1, 0, 2, 0.2 + 0.3 * k, 1.0 + k, 1.0, GLOBAL=8 * cl.AREA)
+    engine.batch_end()
+    engine.sync()
+    assert engine.last_passes() > 0, "the launches were not deferred into a brick sweep"
+    assert engine.stats()["tally_events"] == n
+    assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
+    engine.set_abundances(None)
+    engine.set_opt(None)
