@@ -161,8 +161,15 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU"):
+            # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+            # (RCCL refuses two ranks on one device).  Not a measurement.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     work = c3_workload() if args.workload == "C3" else c2_workload()
     if args.in_flight == 0:
