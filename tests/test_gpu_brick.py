@@ -257,3 +257,43 @@ def test_deferred_launches_with_abundances(octree, engine, oracle_soc):
     assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
     engine.set_abundances(None)
     engine.set_opt(None)
+
+
+def _clustered_hierarchy(NX, NY, NZ, levels, seed=2):
+    """rectangular root grid; the corner cells (root coordinates < 3) and a few scattered ones are refined, and of
+    every further level the first 216 cells again: a deep, clustered hierarchy whose first root cells carry
+    subtrees of hundreds of leaves"""
+    rr = np.random.default_rng(seed)
+    H = [rr.uniform(500.0, 2000.0, NX * NY * NZ)]
+    for l in range(levels - 1):
+        cur = H[l]
+        if l == 0:
+            x, y, z = np.arange(NX * NY * NZ) % NX, (np.arange(NX * NY * NZ) // NX) % NY, np.arange(NX * NY * NZ) // (NX * NY)
+            sel = (x < 3) & (y < 3) & (z < 3)
+            sel |= rr.uniform(size=sel.size) < 0.05
+        else:
+            sel = np.ones(cur.size, bool)
+            sel[8 * 27:] = False                                 # children of the scattered cells stay leaves
+        parents = np.flatnonzero(sel)
+        kids = (cur[parents][:, None] * rr.uniform(0.7, 1.3, (parents.size, 8))).reshape(-1)
+        H.append(kids)
+        cur = cur.astype(np.float32)
+        cur[parents] = -synth.I2F((8 * np.arange(parents.size)).astype(np.int32)).astype(np.float32)
+        H[l] = cur
+    return synth.Cloud(NX, NY, NZ, [np.asarray(h, np.float32) for h in H])
+
+
+@pytest.mark.parametrize("cap", [8, 40, 700])
+def test_brick_sweep_on_a_clustered_rectangular_hierarchy(cap, engine, oracle_soc, monkeypatch):
+    """brick builder: root grid not a multiple of the 16-cell cube, subtrees far above the cap (split level by
+    level), bricks spanning several cubes"""
+    monkeypatch.setenv("SOC_BRICK_CAP", str(cap))
+    cl = _clustered_hierarchy(19, 7, 5, 4)
+    assert cl.LEVELS == 4 and cl.LCELLS[2] == 1728 and cl.LCELLS[3] == 1728
+    job = Job(cl, cases._CSC, ABS=2e-5, SCA=6e-5, SOURCE=1, BATCH=3, SEED=0.3711)
+    T, _, n = oracle_soc.sim(job, 0, nthreads=8)
+    Tg, _, st = run_engine(engine, job, 0, exec_mode=1)
+    assert engine.last_passes() > 0 and st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    assert (Tg[cl.DENS <= 0] == 0).all()
+    engine.set_exec(-1, 4)
