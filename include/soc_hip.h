@@ -157,7 +157,8 @@ int soc_set_roi_load(soc_ctx *ctx, const int32_t *DIM, int ROI_NSIDE, const floa
  * pixel probability for `hpbg ... weighted` runs (-D HPBG_WEIGHTED=1) or NULL */
 int soc_set_hpbg(soc_ctx *ctx, const float *BG, const float *HPBGP);
 
-/* replaces the kernel_ram_hp launch (ASOC.py:1349-1354 -> SimRAM_HP, kernel_ASOC.c:826-850) */
+/* replaces the kernel_ram_hp launch (ASOC.py:1349-1354 -> SimRAM_HP, kernel_ASOC.c:826-850); executed like
+ * soc_sim_pb (direct kernel or brick sweep, deferred inside soc_batch_begin/end with its own copy of the sky) */
 int soc_sim_hp(soc_ctx *ctx, int PACKETS, int BATCH, float SEED, float TW, int GLOBAL, int gid_first, int gid_count);
 
 /* replaces queue.finish() (ASOC.py:1461) */

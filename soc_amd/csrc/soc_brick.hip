@@ -182,6 +182,12 @@ struct SocBrickLane {
     int   level, ind, scat;
     soc_rng_t rng;
 
+    __device__ __forceinline__ void begin_conditioned()    // SimRAM_HP: the direction is conditioned at creation
+    {
+        scat = 0;
+        tau  = 0.0f;
+        free_path = -soc_logf(soc_rand(&rng));
+    }
     __device__ __forceinline__ void begin()
     {
         if (soc_fabsf(ux) < SOC_DEPS) ux = SOC_DEPS;
@@ -615,10 +621,15 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             const SocSurfElem E = soc_surface_element(G, S, id);
             while (true) {
                 if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
-                soc_pb_create<OCT>(G, S, sOFF, E, III, w);
+                if (S.SOURCE == SOC_SOURCE_HP) {                               // SimRAM_HP (kernel_ASOC.c:878-955)
+                    soc_hp_create<OCT>(G, S, sOFF, w);
+                    w.begin_conditioned();
+                } else {
+                    soc_pb_create<OCT>(G, S, sOFF, E, III, w);
+                    w.begin();
+                }
                 III++;
                 n_pkt++;
-                w.begin();
                 if (w.ind >= 0) {
                     if (OCT) {
                         const uint32_t si = __float_as_uint(A.DS[sOFF[w.level] + w.ind].y);
@@ -1029,7 +1040,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         const SocSim &S = Sin[l];
         if (S.BATCH >= (1 << 24)) return hipErrorNotSupported;       // III shares a word with the scattering count
         uint32_t c = S.gid_count;
-        if (S.SOURCE == 1 && !getenv("SOC_EXPERIMENT_OVERSUB")) {
+        if ((S.SOURCE == 1 || S.SOURCE == SOC_SOURCE_HP) && !getenv("SOC_EXPERIMENT_OVERSUB")) {
             const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
             if ((long long)S.gid0 >= lim) c = 0;
             else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);

@@ -64,6 +64,7 @@ struct soc_ctx {
     std::vector<SocSim> pending;
     float *dCSCslot[SOC_MAXLAUNCH] = {};
     float2 *dOPTslots = nullptr;                  // [SOC_MAXLAUNCH][CELLS] per-cell opacities of deferred launches
+    float *dHPslots = nullptr;                    // [SOC_MAXLAUNCH][2][49152] Healpix skies of deferred SimRAM_HP launches
     size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
     // rng
@@ -136,7 +137,13 @@ static int flush_pending(soc_ctx *c)
     if (V.octree && todo.size() == 1 && c->exec_mode < 0) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
         c->last_passes = 0;
-        HIPCHK(c, soc_launch_sim_pb(c->G, todo[0], V, c->stream));
+        if (todo[0].SOURCE == SOC_SOURCE_HP) {
+            SocSim S1 = todo[0];
+            S1.SOURCE = 1;
+            HIPCHK(c, soc_launch_sim_hp(c->G, S1, V, c->stream));
+        } else {
+            HIPCHK(c, soc_launch_sim_pb(c->G, todo[0], V, c->stream));
+        }
         return SOC_OK;
     }
     // Cartesian grids: 4 launches' worth of packets in flight was measured best (C2; more spills the last-level cache),
@@ -205,7 +212,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -580,6 +587,8 @@ static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *P
     return SOC_OK;
 }
 
+static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot);
+
 int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
                const float *PSPOS, const float *PS, int NO_PS,
                const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
@@ -626,23 +635,8 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     }
     c->last_passes = 0;
     if (defer) {
-        if (c->csc_slot_bins != c->BINS) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int k = 0; k < SOC_MAXLAUNCH; k++) HIPCHK(c, dev_alloc(&c->dCSCslot[k], (size_t)c->BINS));
-            c->csc_slot_bins = c->BINS;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->dCSCslot[slot], c->dCSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
-        S.CSC = c->dCSCslot[slot];
-        if (V.abu) {                                        // the per-cell opacities of this launch: slot of one buffer
-            const size_t cells = (size_t)c->G.CELLS;
-            if (c->optslot_cells != cells) {
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                HIPCHK(c, dev_alloc(&c->dOPTslots, cells * SOC_MAXLAUNCH));
-                c->optslot_cells = cells;
-            }
-            HIPCHK(c, hipMemcpyAsync(c->dOPTslots + (size_t)slot * cells, c->dOPT, cells * 8, hipMemcpyDeviceToDevice, c->stream));
-            S.OPT = c->dOPTslots + (size_t)slot * cells;
-        }
+        r = snapshot_inputs(c, S, V, slot);
+        if (r) return r;
         c->pending.push_back(S);
         if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
         return SOC_OK;
@@ -679,7 +673,7 @@ int soc_batch_end(soc_ctx *c)
 int soc_set_hpbg(soc_ctx *c, const float *BG, const float *HPBGP)
 {
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
+    // no flush: a deferred SimRAM_HP launch keeps its own copy of the sky (soc_sim_hp)
     if (!BG) return fail(c, SOC_ERR_ARG, "soc_set_hpbg: BG is NULL");
     const int NPIX = 49152;                                 // NSIDE = 64, fixed in the reference (ASOC.py:297)
     for (int i = 0; i < NPIX; i++)
@@ -796,11 +790,34 @@ int soc_set_roi_load(soc_ctx *c, const int32_t *DIM, int ROI_NSIDE, const float 
     return roi_upload(c);
 }
 
+// what a deferred launch needs besides its SocSim: its own copies of the scattering table and, with abundances,
+// of the per-cell opacities (the caller overwrites both for the next frequency)
+static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot)
+{
+    if (c->csc_slot_bins != c->BINS) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < SOC_MAXLAUNCH; k++) HIPCHK(c, dev_alloc(&c->dCSCslot[k], (size_t)c->BINS));
+        c->csc_slot_bins = c->BINS;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dCSCslot[slot], c->dCSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
+    S.CSC = c->dCSCslot[slot];
+    if (V.abu) {                                            // the per-cell opacities of this launch: slot of one buffer
+        const size_t cells = (size_t)c->G.CELLS;
+        if (c->optslot_cells != cells) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_alloc(&c->dOPTslots, cells * SOC_MAXLAUNCH));
+            c->optslot_cells = cells;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dOPTslots + (size_t)slot * cells, c->dOPT, cells * 8, hipMemcpyDeviceToDevice, c->stream));
+        S.OPT = c->dOPTslots + (size_t)slot * cells;
+    }
+    return SOC_OK;
+}
+
 int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLOBAL, int gid_first, int gid_count)
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
     int r = check_launch(c, "soc_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_hpbg) return fail(c, SOC_ERR_STATE, "soc_sim_hp: call soc_set_hpbg first");
@@ -809,7 +826,36 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     SocVariant V;
     fill_sim(c, S, V, 1, BATCH, SEED, 0.0f, TW, GLOBAL, gid_first, gid_count);
     S.NO_PS = 1;
+    // the brick sweep as for soc_sim_pb: the walk is SimRAM_PB's, only the creation of a packet differs
+    const int B = 1 << c->brick_log2;
+    const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
+    if (c->exec_mode == 1 && !bricks)
+        return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
+    const bool defer = c->batching && bricks && !V.wint;
+    if (!defer) FLUSH(c);
+    if (defer && !c->pending.empty() && ((c->pending[0].OPT != nullptr) != (V.abu != 0))) FLUSH(c);
     c->last_passes = 0;
+    if (bricks) S.SOURCE = SOC_SOURCE_HP;
+    if (defer) {
+        const int slot = (int)c->pending.size();
+        r = snapshot_inputs(c, S, V, slot);
+        if (r) return r;
+        if (!c->dHPslots) HIPCHK(c, dev_alloc(&c->dHPslots, (size_t)SOC_MAXLAUNCH * 2 * 49152));
+        float *sky = c->dHPslots + (size_t)slot * 2 * 49152;
+        HIPCHK(c, hipMemcpyAsync(sky, c->dHPBG, 49152 * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sky + 49152, c->dHPBGP, 49152 * 4, hipMemcpyDeviceToDevice, c->stream));
+        S.HPBG = sky;  S.HPBGP = sky + 49152;
+        c->pending.push_back(S);
+        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        return SOC_OK;
+    }
+    if (bricks) {
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
+        if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
+        return SOC_OK;
+    }
     HIPCHK(c, soc_launch_sim_hp(c->G, S, V, c->stream));
     return SOC_OK;
 }

@@ -53,6 +53,8 @@ struct SocSim {
     const SocRoi *ROI;         /* NULL without roisave / roiload                          */
 };
 
+#define SOC_SOURCE_HP 4        /* brick sweep only: the launch is a SimRAM_HP one (Healpix sky instead of BG) */
+
 // Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the
 // sweep's work items [first[l], first[l+1]); geometry and tallies are shared.
 #define SOC_MAXLAUNCH 8

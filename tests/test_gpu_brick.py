@@ -297,3 +297,60 @@ def test_brick_sweep_on_a_clustered_rectangular_hierarchy(cap, engine, oracle_so
     assert_tally_close(Tg, T, rtol=1e-5)
     assert (Tg[cl.DENS <= 0] == 0).all()
     engine.set_exec(-1, 4)
+
+
+HP = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 2 and "mirror" not in n]
+
+
+@pytest.mark.parametrize("name", HP)
+def test_brick_sweep_healpix_background(name, engine, oracle_soc, monkeypatch):
+    """SimRAM_HP through the brick sweep: the walk is SimRAM_PB's, the event workgroups create the packets from the
+    Healpix sky (uniform and weighted pixel selection, Cartesian and hierarchy, with the INT tally)"""
+    monkeypatch.setenv("SOC_BRICK_CAP", "300")
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    Tg, Ig, st = run_engine(engine, job, kind, exec_mode=1, brick_log2=2)
+    assert engine.last_passes() > 0
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    if job.WITH_INT:
+        assert_tally_close(Ig, I, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_deferred_healpix_launches(engine, oracle_soc):
+    """two SimRAM_HP launches with different skies (one weighted) and a SimRAM_PB one in the same sweep"""
+    cl = synth.cartesian_cloud(40, seed=21)
+    _, csc = synth.hg_scattering_table(0.6)
+    skyA, _ = cases.hp_sky(weighted=False)
+    skyB, PB = cases.hp_sky(weighted=True)
+    G = 8 * cl.AREA
+    jobs = [(2, Job(cl, csc, ABS=2e-5, SCA=6e-5, BATCH=2, SEED=0.21, TW=1.0, GLOBAL=G, HPBG=skyA)),
+            (0, Job(cl, csc, ABS=3e-5, SCA=5e-5, SOURCE=1, BATCH=1, SEED=0.43, BG=2.0, TW=0.5, GLOBAL=G)),
+            (2, Job(cl, csc, ABS=1e-5, SCA=8e-5, BATCH=1, SEED=0.65, TW=2.0, GLOBAL=G, HPBG=0.5 * skyB, HPBGP=PB))]
+    T = np.zeros(cl.CELLS, np.float32)
+    n = 0
+    for kind, j in jobs:
+        _, _, m = oracle_soc.sim(j, kind, TABS=T, nthreads=8)
+        n += m
+    engine.set_cloud(cl)
+    engine.set_features(0, 0, 0)
+    engine.set_opt(None)
+    engine.set_mirror(0)
+    engine.set_exec(-1, 4)
+    engine.set_scatter_table(None, csc)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    for kind, j in jobs:
+        engine.set_optical(j.ABS, j.SCA)
+        if kind == 2:
+            engine.set_hpbg(j.HPBG, j.HPBGP)
+            engine.sim_hp(0, j.BATCH, j.SEED, j.TW, G)
+        else:
+            engine.sim_pb(1, 0, j.BATCH, j.SEED, j.BG, j.TW, GLOBAL=G)
+    engine.batch_end()
+    engine.sync()
+    assert engine.last_passes() > 0 and engine.stats()["tally_events"] == n
+    assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
