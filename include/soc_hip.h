@@ -118,7 +118,9 @@ int soc_sim_pb(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
                int GLOBAL, int gid_first, int gid_count);
 
 /* replaces the kernel_ram_cl launch (ASOC.py:1308-1316, 1847 -> SimRAM_CL,
- * kernel_ASOC.c:1223-1256); uses EMIT/EMWEI from soc_set_emission() */
+ * kernel_ASOC.c:1223-1256); uses EMIT/EMWEI from soc_set_emission().  Executed by the direct kernel, or -- with at
+ * least 262144 work items that own a cell (GLOBAL ~ CELLS), USE_EMWEIGHT 0/1, no ALI, no roisave -- by the brick sweep;
+ * deferred inside soc_batch_begin/end with its own copy of EMIT and EMWEI */
 int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
                int GLOBAL, int gid_first, int gid_count);
 

@@ -342,6 +342,11 @@ class AbsorptionRun:
                 GLOBAL, BATCH = self.GLOBAL_0, max(1, int(self.CLPAC / CELLS))
                 first, count = self.comm.shard(GLOBAL) if self.comm else (0, GLOBAL)
                 skip = U.EMWEIGHT_SKIP - 1
+                # TABS-only iterations: the frequencies are handed to the engine together; with `global` raised to
+                # about the number of cells they share brick sweeps (include/soc_hip.h: soc_batch_begin, soc_sim_cl)
+                deferred = (not self.with_int) and (not ali) and U.USE_EMWEIGHT < 2 and hasattr(e, "batch_begin")
+                if deferred:
+                    e.batch_begin(0)
                 for IFREQ in range(NFREQ):
                     FREQ = float(FFREQ[IFREQ])
                     if self.with_int:
@@ -403,11 +408,17 @@ class AbsorptionRun:
                         e.sim_cl(2, self.CLPAC, BATCH, seed, FF, GLOBAL, gid_first=first, gid_count=count)
                     if self.with_int and self.comm:
                         self.comm.all_reduce_tally(e, 1)
-                    e.sync()
+                    if not deferred:
+                        e.sync()
                     self.timers["Tkernel"] += time.time() - t0
                     self.packets += CELLS * BATCH
                     if iteration == U.ITERATIONS - 1 and FABSORBED is not None:
                         FABSORBED[:, IFREQ] += e.read_tally(1)
+                if deferred:
+                    t0 = time.time()
+                    e.batch_end()
+                    e.sync()
+                    self.timers["Tkernel"] += time.time() - t0
                 if self.comm:
                     self.comm.all_reduce_tally(e, 0)
                     if ali:

@@ -231,7 +231,9 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
         p.A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         p.B = p.A;
         p.C = make_float4(0.0f, 0.0f, __int_as_float(l << SOC_LCH_SHIFT), __int_as_float(-1));
-        p.D = make_uint4(r.x, r.c, 0u, 0u);
+        // SimRAM_CL: the work item's cell, one GLOBAL before its first one (kernel_ASOC.c:1283)
+        const uint32_t cell0 = (K.S[l].SOURCE == SOC_SOURCE_CL) ? (uint32_t)((int)(K.S[l].gid0 + (t - K.first[l])) - K.S[l].GLOBAL) : 0u;
+        p.D = make_uint4(r.x, r.c, 0u, cell0);
         pk[t] = p;
         idq0[t] = t;
     }
@@ -257,9 +259,10 @@ __global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t cou
     if (t <= (uint32_t)(A.NB + 2 * K.n)) hist[t] = 0;
 }
 
-template <bool OCT, bool DBL, bool ABU, bool WINT>
+template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
 __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
+    constexpr bool CL = (KIND == 2);                       // SimRAM_CL: no nudge after a failed step, D.w holds the emitting cell
     if (bid >= *A.ndesc) return;
     const SocDesc D = A.desc[bid];
     if (D.brick >= A.NB) return;                           // an event queue: soc_brick_events
@@ -318,7 +321,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                         SocPk2 *q = pk + wid;
                         soc_st4(&q->A, make_float4(px, py, pz, photons));
                         soc_st4(&q->C, make_float4(tau, dens, __int_as_float(lid | (level << SOC_LVL_SHIFT) | lsh), __int_as_float(ind)));
-                        if (key >= A.NB) SOC_NT_STORE((uint32_t)mybrick, &q->D.w);   // scattering: the brick to come back to
+                        if (!CL && key >= A.NB) SOC_NT_STORE((uint32_t)mybrick, &q->D.w);   // scattering: the brick to come back to (SimRAM_CL keeps its cell there)
                         SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + slot]);
                         sPos[slot] = soc_qh_rank(sH, A.HS, key, A.hist);
                     }
@@ -435,7 +438,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             }
             SOC_PROF_T(2);                                 // climb
             if (finish) {
-                if ((level == level0) && (ind == ind0)) {                         // failed step: nudge
+                if (!CL && (level == level0) && (ind == ind0)) {                  // failed step: nudge (SimRAM_PB / HP only)
                     px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
                 }
                 nvisit++;
@@ -498,7 +501,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 ind = inside ? nind : -1;
                 dens = ndens;
                 lid = nlid;
-                const bool failed = (ind == oind);                            // failed step: nudge
+                const bool failed = !CL && (ind == oind);                     // failed step: nudge (SimRAM_PB / HP only)
                 px += failed ? (SOC_PEPS * ux) : 0.0f;
                 py += failed ? (SOC_PEPS * uy) : 0.0f;
                 pz += failed ? (SOC_PEPS * uz) : 0.0f;
@@ -544,9 +547,11 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
 }
 
 // creation and scattering, one lane per queued packet
-template <bool OCT, bool ABU, bool WINT>
+template <bool OCT, bool ABU, bool WINT, int KIND>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
+    constexpr bool CL = (KIND == 2), HP = (KIND == 1);
+    constexpr int  SRC = (KIND == 3) ? 1 : -1;             // KIND 3: SimRAM_PB with SOURCE == 1 (background) only
     // ebid counts from the first event descriptor (event queues sort last);
     // slice: blockDim.x packets of the chunk -- one packet per lane
     const int di = A.ndesc[2] + ebid;
@@ -588,6 +593,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         int III = (int)(p.D.z & 0xffffffu);
         w.scat = (int)(p.D.z >> 24);
         int key = (int)p.D.w;
+        uint32_t cl_cell = p.D.w;                              // SimRAM_CL: the cell the work item emits from
         bool create = (((D.brick - A.NB) & 1) == 0);
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
@@ -596,6 +602,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             if (ABU) { float2 o = S.OPT[oind];  kabs = o.x;  ksca = o.y; }
             else     { kabs = S.ABS;  ksca = S.SCA; }
             w.scat++;
+            if (CL && (w.scat > 20)) {                                        // SimRAM_CL drops it before the deposit (kernel_ASOC.c:1552-1553)
+                w.ind = -1;
+                create = true;
+            } else {
             float dt = w.free_path - w.tau;
             float dx = dt / (ksca * w.dens);
             float tauA = dx * w.dens * kabs;
@@ -614,18 +624,110 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             w.free_path = -soc_logf(soc_rand(&w.rng));
             soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);           // one table read per event: no staging
             w.tau = 0.0f;
-            if (w.scat > 20) { w.ind = -1;  create = true; }                  // dropped after 20 scatterings
+            if (!CL && (w.scat > 20)) { w.ind = -1;  create = true; }         // dropped after 20 scatterings
+            if (CL) {                                                        // back to the brick of its cell (D.w holds the emitting cell)
+                if (OCT) {
+                    const uint32_t si = __float_as_uint(A.DS[oind].y);
+                    key = (int)(si >> SOC_SLOT_BITS);  lid = (int)(si & SOC_SLOT_MASK);
+                } else {
+                    const int M = (1 << A.LB) - 1, ix = w.ind % G.NX, iy = (w.ind / G.NX) % G.NY, iz = w.ind / (G.NX * G.NY);
+                    key = ((iz >> A.LB) * A.NBY + (iy >> A.LB)) * A.NBX + (ix >> A.LB);
+                    lid = ((iz & M) << (2 * A.LB)) | ((iy & M) << A.LB) | (ix & M);
+                }
+            }
+            }
         }
-        if (create) {
+        if (create && CL) {
+            // SimRAM_CL (kernel_ASOC.c:1283-1432): the work item walks the cells id, id+GLOBAL, ... and sends `batch`
+            // packets from each.  Its place is kept in the record: D.w = cell, III = packets sent from it; batch and
+            // the packet weight follow from the cell (EMWEI) and are recomputed.
+            int ICELL = (int)p.D.w, IRAY = III, batch = -1;
+            float PWEI = 1.0f;
+            if (ICELL >= 0) {
+                if (S.USE_EMWEIGHT > 0) {
+                    PWEI  = S.EMWEI[ICELL];
+                    batch = (int)soc_floorf(PWEI);
+                    if (batch < 1) { batch = 1;  PWEI = (float)(1.0 / (double)(PWEI + 1.0e-30f)); }
+                    else           { PWEI = (float)(1.0 / (double)(batch + 1.0e-9f)); }
+                } else {
+                    batch = S.BATCH;
+                    PWEI  = 1.0f / (batch + 1.0e-9f);
+                }
+            }
+            key = -1;
+            if (IRAY >= batch) {                                              // next emitting cell (:1318-1355)
+                IRAY = 0;
+                long long IC = ICELL;
+                while (true) {
+                    IC += S.GLOBAL;
+                    if (IC >= G.CELLS) { key = NQ - 1;  break; }              // work item finished
+                    if (S.USE_EMWEIGHT > 0) {
+                        PWEI = S.EMWEI[IC];
+                        if ((PWEI < 1e-10f) || (G.DENS[IC] <= 0.0f)) continue;
+                        batch = (int)soc_floorf(PWEI);
+                        if (batch < 1) { batch = 1;  PWEI = (float)(1.0 / (double)(PWEI + 1.0e-30f)); }
+                        else           { PWEI = (float)(1.0 / (double)(batch + 1.0e-9f)); }
+                    } else {
+                        batch = S.BATCH;
+                        PWEI  = 1.0f / (batch + 1.0e-9f);
+                    }
+                    break;
+                }
+                ICELL = (int)IC;
+            }
+            if (key < 0) {
+                IRAY += 1;
+                int level = 0, ind = ICELL;
+                if (OCT) {
+                    for (level = 0; level < G.LEVELS - 1; level++) {
+                        if (ind < sOFF[level + 1] - sOFF[level]) break;
+                        ind -= sOFF[level + 1] - sOFF[level];
+                    }
+                }
+                float X0, Y0, Z0;
+                if (level == 0) {
+                    X0 = (float)(ind % G.NX);  Y0 = (float)((ind / G.NX) % G.NY);  Z0 = (float)(ind / (G.NX * G.NY));
+                } else {
+                    const int sid = ind % 8;
+                    X0 = (float)(sid % 2);  Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;  Z0 = (float)(sid / 4);
+                }
+                const int oabs = (OCT ? sOFF[level] : 0) + ind;
+                w.level = level;  w.ind = ind;
+                w.dens    = G.DENS[oabs];
+                w.photons = S.EMIT[oabs] * PWEI;
+                w.px = X0 + soc_rand(&w.rng);
+                w.py = Y0 + soc_rand(&w.rng);
+                w.pz = Z0 + soc_rand(&w.rng);
+                const float phi       = SOC_TWOPI * soc_rand(&w.rng);
+                const float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
+                const float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
+                float sp, cp;
+                soc_sincosf(phi, &sp, &cp);
+                w.ux = sin_theta * cp;  w.uy = sin_theta * sp;  w.uz = cos_theta;
+                n_pkt++;
+                w.begin();
+                if (OCT) {
+                    const uint32_t si = __float_as_uint(A.DS[oabs].y);
+                    key = (int)(si >> SOC_SLOT_BITS);  lid = (int)(si & SOC_SLOT_MASK);
+                } else {
+                    const int M = (1 << A.LB) - 1, ix = ind % G.NX, iy = (ind / G.NX) % G.NY, iz = ind / (G.NX * G.NY);
+                    key = ((iz >> A.LB) * A.NBY + (iy >> A.LB)) * A.NBX + (ix >> A.LB);
+                    lid = ((iz & M) << (2 * A.LB)) | ((iy & M) << A.LB) | (ix & M);
+                }
+            }
+            III = IRAY;
+            cl_cell = (uint32_t)ICELL;
+        }
+        if (create && !CL) {
             const int id = (int)(S.gid0 + (wid - K.first[lq]));
-            const SocSurfElem E = soc_surface_element(G, S, id);
+            const SocSurfElem E = soc_surface_element<SRC>(G, S, id);
             while (true) {
                 if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
-                if (S.SOURCE == SOC_SOURCE_HP) {                               // SimRAM_HP (kernel_ASOC.c:878-955)
+                if (HP) {                                                      // SimRAM_HP (kernel_ASOC.c:878-955)
                     soc_hp_create<OCT>(G, S, sOFF, w);
                     w.begin_conditioned();
                 } else {
-                    soc_pb_create<OCT>(G, S, sOFF, E, III, w);
+                    soc_pb_create<OCT, SocBrickLane, SRC>(G, S, sOFF, E, III, w);
                     w.begin();
                 }
                 III++;
@@ -644,7 +746,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         p.A = make_float4(w.px, w.py, w.pz, w.photons);
         p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
         p.C = make_float4(w.tau, w.dens, __int_as_float(lid | ((OCT ? w.level : 0) << SOC_LVL_SHIFT) | (lq << SOC_LCH_SHIFT)), __int_as_float(w.ind));
-        p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), (uint32_t)key);
+        p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), CL ? cl_cell : (uint32_t)key);
         pk[wid] = p;
         A.keyq[D.start + j] = (uint32_t)key;
         mypack = soc_qh_rank(sH, A.HS, key, A.hist);
@@ -666,15 +768,15 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
 // One launch per pass for both: blocks [0, nwalk) walk the descriptor of their index (and leave at
 // once if it belongs to an event queue), the blocks after them are the event workgroups.  The short,
 // latency-bound event work runs beside the walk instead of after it.
-template <bool OCT, bool DBL, bool ABU, bool WINT>
+template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
 __global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSimPack K, const SocBrickArgs A, const int nwalk, const int slices)
 {
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
-        soc_brick_walk<OCT, DBL, ABU, WINT>(G, K, A, b);
+        soc_brick_walk<OCT, DBL, ABU, WINT, KIND>(G, K, A, b);
     } else {
         const int e = b - nwalk;
-        soc_brick_events<OCT, ABU, WINT>(G, K, A, e / slices, e % slices);
+        soc_brick_events<OCT, ABU, WINT, KIND>(G, K, A, e / slices, e % slices);
     }
 }
 
@@ -814,8 +916,8 @@ void soc_brick_release(int device)
 }
 
 // ---------------------------------------------------------------------------------------
-// Bricks of a hierarchical grid.  A brick is a set of <= CAP leaf cells that are close in space, each with a
-// tally slot; refined cells hold no tally and belong to no brick.  Built on the host once per grid:
+// Bricks of a hierarchical grid.  A brick is a set of <= CAP cells that are close in space, each with a tally
+// slot (leaves, and the refined cells above them: see place_subtree).  Built on the host once per grid:
 //   1. leaves in every subtree, bottom-up over the levels;
 //   2. the root grid is visited in cubes of 16^3 cells; a cube (and below that: an octant of it, a root cell's
 //      subtree, a child's subtree) that holds more than CAP leaves is split into its eight parts; a part that
@@ -869,7 +971,7 @@ struct OctBuilder {
             for (int i = 0; i < G.LCELLS[l]; i++) {
                 const float d = D[o + i];
                 if (d > 0.0f) { sub[o + i] = 1;  continue; }
-                uint32_t n = 0;
+                uint32_t n = 1;                              // the refined cell itself holds a slot too (see place_subtree)
                 if (l + 1 < G.LEVELS) {
                     const size_t c = (size_t)G.OFF[l + 1] + link(d);
                     for (int k = 0; k < 8; k++) n += sub[c + k];
@@ -891,15 +993,27 @@ struct OctBuilder {
             fill++;
             return;
         }
+        // A refined cell takes no part in the transfer -- except that SimRAM_CL without emission weights sends
+        // packets from EVERY cell index (kernel_ASOC.c:1318-1355 has no leaf test there): such a packet starts "in"
+        // the refined cell, with the link as its density, and its first step is tallied there.  So it has a slot.
+        place_cell(a);
         if (l + 1 >= G.LEVELS) return;
         const int c = link(D[a]);
         for (int k = 0; k < 8; k++) place_subtree(l + 1, c + k);
+    }
+    void place_cell(size_t a)
+    {
+        slotmap[a] = ((uint32_t)(bbase.size() - 1) << SOC_SLOT_BITS) | (uint32_t)fill;
+        bcell.push_back((int)a);
+        fill++;
     }
     void assign_subtree(int l, int i)
     {
         const uint32_t n = sub[(size_t)G.OFF[l] + i];
         if (n == 0) return;
         if (n <= (uint32_t)CAP) { open(n);  place_subtree(l, i);  return; }
+        open(1);
+        place_cell((size_t)G.OFF[l] + i);                    // the refined cell itself, then its children one by one
         const int c = link(D[(size_t)G.OFF[l] + i]);
         for (int k = 0; k < 8; k++) assign_subtree(l + 1, c + k);
     }
@@ -973,25 +1087,43 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
 // (same geometry, same tallies; no INT tally when nlaunch > 1) share one sweep: more
 // packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
 // others.  Returns hipErrorNotSupported when the launches cannot use bricks.
-template <bool OCT, bool DBL>
-static void soc_brick_launch_pass(int vkey, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
-                                  const SocBrickArgs &A, int nwalk, int slices)
+template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
+static void soc_brick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+                                 const SocBrickArgs &A, int nwalk, int slices)
 {
     if (lds > 64 * 1024) {                         // more dynamic LDS than the default limit: once per kernel
-        static bool raised[4] = { false, false, false, false };
-        if (!raised[vkey]) {
-            const void *f = vkey == 0 ? (const void *)soc_brick_pass<OCT, DBL, false, false> : vkey == 1 ? (const void *)soc_brick_pass<OCT, DBL, false, true>
-                          : vkey == 2 ? (const void *)soc_brick_pass<OCT, DBL, true, false> : (const void *)soc_brick_pass<OCT, DBL, true, true>;
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised[vkey] = true;
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void *)soc_brick_pass<OCT, DBL, ABU, WINT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
         }
     }
+    soc_brick_pass<OCT, DBL, ABU, WINT, KIND><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices);
+}
+
+// vkey: bit 0 INT tally, bit 1 per-cell opacities; kind 0 SimRAM_PB, 1 SimRAM_HP, 2 SimRAM_CL, 3 SimRAM_PB with
+// background packets only (they differ in how the
+// event workgroups create a packet; separate kernels so that none carries the registers of the others)
+template <bool OCT, bool DBL, int KIND>
+static void soc_brick_launch_kind(int vkey, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+                                  const SocBrickArgs &A, int nwalk, int slices)
+{
     switch (vkey) {
-    case 0:  soc_brick_pass<OCT, DBL, false, false><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
-    case 1:  soc_brick_pass<OCT, DBL, false, true><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
-    case 2:  soc_brick_pass<OCT, DBL, true, false><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
-    default: soc_brick_pass<OCT, DBL, true, true><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); break;
+    case 0:  soc_brick_launch_one<OCT, DBL, false, false, KIND>(nblocks, T, lds, st, G, K, A, nwalk, slices); break;
+    case 1:  soc_brick_launch_one<OCT, DBL, false, true, KIND>(nblocks, T, lds, st, G, K, A, nwalk, slices); break;
+    case 2:  soc_brick_launch_one<OCT, DBL, true, false, KIND>(nblocks, T, lds, st, G, K, A, nwalk, slices); break;
+    default: soc_brick_launch_one<OCT, DBL, true, true, KIND>(nblocks, T, lds, st, G, K, A, nwalk, slices); break;
     }
+}
+
+template <bool OCT, bool DBL>
+static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+                                  const SocBrickArgs &A, int nwalk, int slices)
+{
+    if (kind == 3)      soc_brick_launch_kind<OCT, DBL, 3>(vkey, nblocks, T, lds, st, G, K, A, nwalk, slices);
+    else if (kind == 2) soc_brick_launch_kind<OCT, DBL, 2>(vkey, nblocks, T, lds, st, G, K, A, nwalk, slices);
+    else if (kind == 1) soc_brick_launch_kind<OCT, DBL, 1>(vkey, nblocks, T, lds, st, G, K, A, nwalk, slices);
+    else                soc_brick_launch_kind<OCT, DBL, 0>(vkey, nblocks, T, lds, st, G, K, A, nwalk, slices);
 }
 
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
@@ -1045,7 +1177,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             if ((long long)S.gid0 >= lim) c = 0;
             else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);
         }
-        if (S.BATCH <= 0) c = 0;
+        if (S.SOURCE == SOC_SOURCE_CL) {                              // work items beyond the cells do nothing (kernel_ASOC.c:1273)
+            if ((long long)S.gid0 >= G.CELLS) c = 0;
+            else if ((long long)S.gid0 + c > G.CELLS) c = (uint32_t)(G.CELLS - S.gid0);
+            if (S.USE_EMWEIGHT == 2 || S.XAB) return hipErrorNotSupported;
+        }
+        if (S.BATCH <= 0 && S.SOURCE != SOC_SOURCE_CL) c = 0;
         if (c == 0) continue;                                         // nothing to do for this launch
         if ((unsigned long long)count + c > 0x7fffffffull) return hipErrorNotSupported;
         K.S[K.n] = S;
@@ -1108,6 +1245,14 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
     if (lds > 160 * 1024) return hipErrorNotSupported;
     const int vkey = (V.abu ? 2 : 0) | (V.wint ? 1 : 0);
+    int kind = (K.S[0].SOURCE == SOC_SOURCE_CL) ? 2 : (K.S[0].SOURCE == SOC_SOURCE_HP) ? 1 : 0;
+    bool all_bg = (kind == 0);
+    for (int l = 0; l < K.n; l++) {
+        const int kl = (K.S[l].SOURCE == SOC_SOURCE_CL) ? 2 : (K.S[l].SOURCE == SOC_SOURCE_HP) ? 1 : 0;
+        if (kl != kind) return hipErrorInvalidValue;                  // one kind per sweep (soc_capi.hip sees to it)
+        all_bg = all_bg && (K.S[l].SOURCE == 1);
+    }
+    if (all_bg) kind = 3;                                             // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((count + A.P - 1) / A.P) + 3 * K.n) * slices;
 
@@ -1120,9 +1265,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
-            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
-            else             soc_brick_launch_pass<true, true>(vkey, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
             Q.NB = NQ - 1;
             Q.ev_brick = A.NB;

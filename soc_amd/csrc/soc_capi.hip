@@ -65,6 +65,8 @@ struct soc_ctx {
     float *dCSCslot[SOC_MAXLAUNCH] = {};
     float2 *dOPTslots = nullptr;                  // [SOC_MAXLAUNCH][CELLS] per-cell opacities of deferred launches
     float *dHPslots = nullptr;                    // [SOC_MAXLAUNCH][2][49152] Healpix skies of deferred SimRAM_HP launches
+    float *dEMITslots = nullptr;                  // [SOC_MAXLAUNCH][2][CELLS] EMIT, EMWEI of deferred SimRAM_CL launches
+    size_t emitslot_cells = 0;
     size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
     // rng
@@ -141,6 +143,10 @@ static int flush_pending(soc_ctx *c)
             SocSim S1 = todo[0];
             S1.SOURCE = 1;
             HIPCHK(c, soc_launch_sim_hp(c->G, S1, V, c->stream));
+        } else if (todo[0].SOURCE == SOC_SOURCE_CL) {
+            SocSim S1 = todo[0];
+            S1.SOURCE = 2;
+            HIPCHK(c, soc_launch_sim_cl(c->G, S1, V, c->stream));
         } else {
             HIPCHK(c, soc_launch_sim_pb(c->G, todo[0], V, c->stream));
         }
@@ -212,7 +218,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -438,7 +444,7 @@ int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BI
 int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
 {
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
+    // no flush: a deferred SimRAM_CL launch keeps its own copy of EMIT and EMWEI (soc_sim_cl)
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_emission: call soc_set_grid first");
     if (!EMIT) return fail(c, SOC_ERR_ARG, "soc_set_emission: EMIT is NULL");
     HIPCHK(c, hipSetDevice(c->device));
@@ -589,6 +595,16 @@ static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *P
 
 static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot);
 
+// a sweep runs one kernel variant: launches of one kind (SimRAM_PB, _HP or _CL), all with or all without per-cell opacities
+static bool same_sweep(const soc_ctx *c, int source, bool abu)
+{
+    if (c->pending.empty()) return true;
+    const SocSim &P = c->pending[0];
+    const int kp = (P.SOURCE == SOC_SOURCE_CL) ? 2 : (P.SOURCE == SOC_SOURCE_HP) ? 1 : 0;
+    const int kn = (source == SOC_SOURCE_CL) ? 2 : (source == SOC_SOURCE_HP) ? 1 : 0;
+    return kp == kn && ((P.OPT != nullptr) == abu);
+}
+
 int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
                const float *PSPOS, const float *PS, int NO_PS,
                const int32_t *XPS_NSIDE, const int32_t *XPS_SIDE, const float *XPS_AREA,
@@ -625,7 +641,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
     const bool defer = c->batching && bricks && !V.wint;
     if (!defer) FLUSH(c);
-    if (defer && !c->pending.empty() && ((c->pending[0].OPT != nullptr) != (V.abu != 0))) FLUSH(c);   // one kernel variant per sweep
+    if (defer && !same_sweep(c, SOURCE, V.abu != 0)) FLUSH(c);
     const int slot = defer ? (int)c->pending.size() : 0;
     if (SOURCE == 0) {
         r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false, slot);
@@ -835,7 +851,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
     const bool defer = c->batching && bricks && !V.wint;
     if (!defer) FLUSH(c);
-    if (defer && !c->pending.empty() && ((c->pending[0].OPT != nullptr) != (V.abu != 0))) FLUSH(c);
+    if (defer && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0)) FLUSH(c);
     c->last_passes = 0;
     if (bricks) S.SOURCE = SOC_SOURCE_HP;
     if (defer) {
@@ -865,7 +881,6 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
     int r = check_launch(c, "soc_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sim_cl: call soc_set_emission first");
@@ -877,6 +892,47 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     if (c->use_emweight == 2 && !c->have_emindex) return fail(c, SOC_ERR_STATE, "soc_sim_cl: USE_EMWEIGHT 2 needs soc_set_emindex");
     if (c->with_ali) S.XAB = c->dXAB;
     S.ROI = c->roi.save ? c->dRoi : nullptr;                // SimRAM_CL records too (kernel_ASOC.c:1250-1254)
+    // The brick sweep: the same walk, the event workgroups step through the work item's cells.  It needs packets in
+    // flight to sort -- one per work item that has a cell, min(GLOBAL, CELLS): with the reference's GLOBAL = 32768
+    // the direct kernel (1.5e10 steps/s at C2, the rate of the fabric atomics) stays; `global` in the ini file
+    // raises it.  Host-listed cells (USE_EMWEIGHT 2), ALI and region-of-interest records: direct kernel.
+    const int B = 1 << c->brick_log2;
+    const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
+    const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
+                  && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
+    if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
+    if (c->exec_mode == 1 && !bricks)
+        return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
+    const bool defer = c->batching && bricks && !V.wint;
+    if (!defer) FLUSH(c);
+    if (defer && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0)) FLUSH(c);
+    c->last_passes = 0;
+    if (bricks) S.SOURCE = SOC_SOURCE_CL;
+    if (defer) {
+        const int slot = (int)c->pending.size();
+        r = snapshot_inputs(c, S, V, slot);
+        if (r) return r;
+        // its own copy of the emission (and of the packet weights): the caller uploads the next frequency's
+        const size_t cells = (size_t)c->G.CELLS;
+        if (c->emitslot_cells != cells) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_alloc(&c->dEMITslots, cells * 2 * SOC_MAXLAUNCH));
+            c->emitslot_cells = cells;
+        }
+        float *em = c->dEMITslots + (size_t)slot * 2 * cells;
+        HIPCHK(c, hipMemcpyAsync(em, c->dEMIT, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(em + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+        S.EMIT = em;  S.EMWEI = em + cells;
+        c->pending.push_back(S);
+        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        return SOC_OK;
+    }
+    if (bricks) {
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
+        if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
+        return SOC_OK;
+    }
     HIPCHK(c, soc_launch_sim_cl(c->G, S, V, c->stream));
     return SOC_OK;
 }

@@ -54,6 +54,7 @@ struct SocSim {
 };
 
 #define SOC_SOURCE_HP 4        /* brick sweep only: the launch is a SimRAM_HP one (Healpix sky instead of BG) */
+#define SOC_SOURCE_CL 5        /* brick sweep only: a SimRAM_CL launch (cell emission)                        */
 
 // Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the
 // sweep's work items [first[l], first[l+1]); geometry and tallies are shared.

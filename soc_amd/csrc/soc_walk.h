@@ -481,13 +481,15 @@ struct SocSurfElem {
     float X0, Y0, Z0, DX, DY, DZ;
 };
 
+// SRC >= 0: the kind of source is known at compile time (the other one's code and registers are not carried)
+template <int SRC = -1>
 __device__ __forceinline__ SocSurfElem soc_surface_element(const SocGrid &G, const SocSim &S, int id)
 {
     const int NX = G.NX, NY = G.NY, NZ = G.NZ;
     const int AREA = 2 * (NX * NY + NY * NZ + NZ * NX);
     int   SIDE = 0;
     float X0 = 0.0f, Y0 = 0.0f, Z0 = 0.0f, DX = 1.0f, DY = 1.0f, DZ = 1.0f;
-    if (S.SOURCE == 1) {
+    if (((SRC >= 0) ? SRC : S.SOURCE) == 1) {
         int e = id % AREA;
         if (e < NY * NZ) {
             SIDE = 0;  X0 = SOC_PEPS;  Y0 = e % NY;  Z0 = e / NY;  DX = 0.0f;
@@ -524,14 +526,14 @@ __device__ __forceinline__ SocSurfElem soc_surface_element(const SocGrid &G, con
 
 // Creation of packet III of a SimRAM_PB work item: background (kernel_ASOC.c:439-464) or
 // point source (kernel_ASOC.c:202-434).  The caller then runs w.begin().
-template <bool OCT, typename W>
+template <bool OCT, typename W, int SRC = -1>
 __device__ __forceinline__ void soc_pb_create(const SocGrid &G, const SocSim &S, const int *sOFF,
                                               const SocSurfElem &E, int III, W &w)
 {
     const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
     const int   SIDE = E.SIDE;
     const float X0 = E.X0, Y0 = E.Y0, Z0 = E.Z0, DX = E.DX, DY = E.DY, DZ = E.DZ;
-    if (S.SOURCE == 1) {
+    if (((SRC >= 0) ? SRC : S.SOURCE) == 1) {
         w.px = soc_clampf(X0 + DX * soc_rand(&w.rng), SOC_PEPS, NX - SOC_PEPS);
         w.py = soc_clampf(Y0 + DY * soc_rand(&w.rng), SOC_PEPS, NY - SOC_PEPS);
         w.pz = soc_clampf(Z0 + DZ * soc_rand(&w.rng), SOC_PEPS, NZ - SOC_PEPS);

@@ -354,3 +354,67 @@ def test_deferred_healpix_launches(engine, oracle_soc):
     engine.sync()
     assert engine.last_passes() > 0 and engine.stats()["tally_events"] == n
     assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
+
+
+CLB = [n for n, (ref, kind, mk) in sorted(cases.CASES.items())
+       if kind == 1 and not any(t in n for t in ("mirror", "emw2", "ali", "roi"))]
+
+
+@pytest.mark.parametrize("name", CLB)
+def test_brick_sweep_cell_emission(name, engine, oracle_soc, monkeypatch):
+    """SimRAM_CL through the brick sweep: the event workgroups step through the work item's cells (EMWEIGHT 0 and 1),
+    no nudge after a failed step, packets dropped before the deposit of the 21st scattering"""
+    monkeypatch.setenv("SOC_BRICK_CAP", "300")
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    Tg, Ig, st = run_engine(engine, job, kind, exec_mode=1, brick_log2=2)
+    assert engine.last_passes() > 0
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("octree", [False, True])
+def test_cell_emission_large_global_and_deferred(octree, engine, oracle_soc):
+    """`global` raised to the cell count: automatic mode takes the brick sweep; two frequencies (own EMIT, optical
+    depths, scattering tables) deferred into one sweep equal the oracle's sum"""
+    cl = synth.octree_cloud(56, levels=3, frac=0.1, seed=3) if octree else synth.cartesian_cloud(64, seed=21)   # >= 262144 cells
+    rr = np.random.default_rng(6)
+    d6, csc6 = synth.hg_scattering_table(0.6)
+    d0, csc0 = synth.hg_scattering_table(0.1)
+    leaf = cl.DENS > 0
+    G = launch_fix(cl.CELLS)
+    jobs = []
+    for k, (csc, a, s) in enumerate(((csc6, 2e-5, 6e-5), (csc0, 4e-5, 3e-5))):
+        EMIT = np.where(leaf, rr.uniform(0.5, 2.0, cl.CELLS), 0.0).astype(np.float32)
+        jobs.append(Job(cl, csc, ABS=a, SCA=s, SOURCE=2, BATCH=1 + k, SEED=0.2 + 0.4 * k, TW=1.0 + k, GLOBAL=G, EMIT=EMIT))
+    T = np.zeros(cl.CELLS, np.float32)
+    n = 0
+    for j in jobs:
+        _, _, m = oracle_soc.sim(j, 1, TABS=T, nthreads=8)
+        n += m
+    engine.set_cloud(cl)
+    engine.set_features(0, 0, 0)
+    engine.set_opt(None)
+    engine.set_mirror(0)
+    engine.set_ali(0)
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    for j in jobs:
+        engine.set_scatter_table(j.DSC, j.CSC)
+        engine.set_optical(j.ABS, j.SCA)
+        engine.set_emission(j.EMIT, None)
+        engine.sim_cl(2, 0, j.BATCH, j.SEED, j.TW, G)
+    engine.batch_end()
+    engine.sync()
+    assert engine.last_passes() > 0, "cell emission with GLOBAL ~ CELLS did not take the brick sweep"
+    assert engine.stats()["tally_events"] == n
+    assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
+
+
+def launch_fix(n):
+    from soc_amd import launch
+    return launch.Fix(n, 64)
