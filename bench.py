@@ -134,8 +134,8 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)

@@ -1252,7 +1252,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (kl != kind) return hipErrorInvalidValue;                  // one kind per sweep (soc_capi.hip sees to it)
         all_bg = all_bg && (K.S[l].SOURCE == 1);
     }
-    if (all_bg) kind = 3;                                             // background packets only: the lean kernel
+    if (all_bg && !getenv("SOC_BRICK_NOLEAN")) kind = 3;               // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((count + A.P - 1) / A.P) + 3 * K.n) * slices;
 
