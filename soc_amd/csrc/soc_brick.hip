@@ -1138,8 +1138,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     // workgroup shape; overridable for experiments (measured on C2)
     A.T = 512;
     A.P = (V.octree ? 8 : 4) * A.T;                  // hierarchies: one chunk per brick queue (measured)
-    A.KCAP = 32;
-    A.FTH = 16;
+    A.KCAP = V.octree ? 32 : 48;                     // measured on C2 / on the 256^3-root hierarchy
+    A.FTH = V.octree ? 16 : 24;
     A.CAP = 6144;                                    // with P = 4096: 48 KB of LDS, three workgroups per CU (measured)
     A.TAIL = 0;
     if (const char *e = getenv("SOC_BRICK_TAIL")) A.TAIL = atoi(e);
