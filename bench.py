@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
-                         "0 = the K steps in equal sweeps of at most 8 (on Cartesian grids 3 launches' worth of packets are in "
+                         "0 = the K steps in equal sweeps of at most 8 (on Cartesian grids 2.7e6 packets are in "
                          "flight, the next launches' work items are admitted as the first finish)")
     ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
                     help="C2 = BASELINE.json configs[1] (the headline); C3 = the background part of configs[2]")

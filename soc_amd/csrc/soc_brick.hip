@@ -1231,12 +1231,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1));  BCHK(brick_alloc(&bb.admit, 1 + 3 * SOC_MAXLAUNCH)); }
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.posq = bb.posq;  A.hist = bb.hist;  A.off = bb.off;  A.total = bb.total;
     A.admit = bb.admit;
-    // packets in flight: the work items of the first `population` launches (0: all of them); the rest are admitted
-    // as those finish -- one tail per sweep instead of one per `population` launches
+    // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
+    // order, as earlier ones finish
     A.nl = K.n;
     for (int l = 0; l <= SOC_MAXLAUNCH; l++) A.first[l] = K.first[l];
     if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
-    A.target = (population > 0 && population < K.n) ? (int)K.first[population] : (int)count;
+    A.target = (population > 0 && (uint32_t)population < count) ? population : (int)count;
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
