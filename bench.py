@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
-                         "0 = the K steps in equal sweeps of at most 8 (on Cartesian grids 2.7e6 packets are in "
+                         "0 = the K steps in equal sweeps of at most 16 (on Cartesian grids 2.7e6 packets are in "
                          "flight, the next launches' work items are admitted as the first finish)")
     ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
                     help="C2 = BASELINE.json configs[1] (the headline); C3 = the background part of configs[2]")
@@ -173,8 +173,8 @@ def main():
 
     work = c3_workload() if args.workload == "C3" else c2_workload()
     if args.in_flight == 0:
-        # sweeps of equal size, at most 8 launches each (K = 10 -> 5 + 5 rather than 8 + 2)
-        args.in_flight = max(1, -(-args.steps // -(-args.steps // 8))) if args.steps > 0 else 8
+        # sweeps of equal size, at most 16 launches each (K = 20 -> 10 + 10 rather than 16 + 4)
+        args.in_flight = max(1, -(-args.steps // -(-args.steps // 16))) if args.steps > 0 else 16
     cloud, L = work["cloud"], work["launch"]
     eng = Engine(local_rank)
     eng.set_cloud(cloud)

@@ -128,8 +128,9 @@ int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
  * runs one kernel per frequency and waits for it, ASOC.py:1360-1461).  Between soc_batch_begin and
  * soc_batch_end a launch that qualifies for the brick sweep and runs without the per-frequency INT
  * tally is recorded with a snapshot of its inputs (ABS, SCA or the per-cell OPT, scattering table,
- * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default: 4 on
- * Cartesian grids, 8 on hierarchies; at most 8): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
+ * BG, TW, seed, sources) and executed together with up to max_launches-1 others (0 = default = at most: 16;
+ * on Cartesian grids 2.7e6 packets are in flight at a time and the later launches' work items are admitted as earlier
+ * ones finish): the same packets, the same per-launch RNG streams, the same tallies -- more packets in
  * flight per pass.  Any other call that reads or changes engine state executes what is pending
  * first; launches that do not qualify run immediately as always. */
 int soc_batch_begin(soc_ctx *ctx, int max_launches);

@@ -219,8 +219,9 @@ struct SocBrickLane {
 // Packet record (64 B): A = position, photons | B = direction, free_path | C = tau, density of
 // the current cell, tally slot, cell index | D = RNG state, III | scat << 24, brick.
 // ---------------------------------------------------------------------------------------
-__global__ void soc_brick2_init(const SocSimPack K, SocBrickArgs A, uint32_t count, uint32_t *idq0, SocDesc *desc0, int *ndesc0, int *hist)
+__global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t count, uint32_t *idq0, SocDesc *desc0, int *ndesc0, int *hist)
 {
+    const SocSimPack &K = *Kp;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     SocPk2 *pk = A.pk;
     if (t < count) {
@@ -769,8 +770,9 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
 // once if it belongs to an event queue), the blocks after them are the event workgroups.  The short,
 // latency-bound event work runs beside the walk instead of after it.
 template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
-__global__ __launch_bounds__(512) void soc_brick_pass(const SocGrid G, const SocSimPack K, const SocBrickArgs A, const int nwalk, const int slices)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void soc_brick_pass(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
 {
+    const SocSimPack &K = *Kp;
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
         soc_brick_walk<OCT, DBL, ABU, WINT, KIND>(G, K, A, b);
@@ -884,6 +886,7 @@ struct SocBrickBuffers {
     int    cap_nq = 0, cap_desc = 0;
     SocPk2 *pk = nullptr;
     uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr, *posq = nullptr;
+    SocSimPack *pack = nullptr;
     int *hist = nullptr, *off = nullptr, *ndesc = nullptr, *total = nullptr, *admit = nullptr;
     SocDesc *desc[2] = { nullptr, nullptr };
 };
@@ -909,7 +912,7 @@ void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
     SocBrickBuffers &b = g_bb[device];
-    void *ptrs[] = { b.pk, b.idq[0], b.idq[1], b.keyq, b.posq, b.hist, b.off, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
+    void *ptrs[] = { b.pack, b.pk, b.idq[0], b.idq[1], b.keyq, b.posq, b.hist, b.off, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     b = SocBrickBuffers();
     soc_oct_release(device);
@@ -1088,7 +1091,7 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
 // packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
 // others.  Returns hipErrorNotSupported when the launches cannot use bricks.
 template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
-static void soc_brick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+static void soc_brick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                  const SocBrickArgs &A, int nwalk, int slices)
 {
     if (lds > 64 * 1024) {                         // more dynamic LDS than the default limit: once per kernel
@@ -1105,7 +1108,7 @@ static void soc_brick_launch_one(int nblocks, int T, size_t lds, hipStream_t st,
 // background packets only (they differ in how the
 // event workgroups create a packet; separate kernels so that none carries the registers of the others)
 template <bool OCT, bool DBL, int KIND>
-static void soc_brick_launch_kind(int vkey, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+static void soc_brick_launch_kind(int vkey, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                   const SocBrickArgs &A, int nwalk, int slices)
 {
     switch (vkey) {
@@ -1117,7 +1120,7 @@ static void soc_brick_launch_kind(int vkey, int nblocks, int T, size_t lds, hipS
 }
 
 template <bool OCT, bool DBL>
-static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack &K,
+static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                   const SocBrickArgs &A, int nwalk, int slices)
 {
     if (kind == 3)      soc_brick_launch_kind<OCT, DBL, 3>(vkey, nblocks, T, lds, st, G, K, A, nwalk, slices);
@@ -1201,7 +1204,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             if ((long long)(K.S[l].OPT - K.S[0].OPT) != l * A.opt_stride) return hipErrorInvalidValue;
     }
     const int NQ = A.NB + 2 * K.n + 1;
-    const int maxdesc = (int)((count + A.P - 1) / A.P) + NQ + K.n;
+    // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
+    // order, as earlier ones finish.  Queues, descriptors and the grids of the passes are sized for that many.
+    if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
+    A.target = (population > 0 && (uint32_t)population < count) ? population : (int)count;
+    const uint32_t live = (uint32_t)A.target;
+    const int maxdesc = (int)((live + A.P - 1) / A.P) + NQ + K.n;
     A.HS = (NQ > 4096) ? 1024 : 0;
     if (const char *e = getenv("SOC_BRICK_HS")) A.HS = atoi(e);
     if (A.HS & (A.HS - 1)) return hipErrorInvalidValue;
@@ -1228,15 +1236,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         BCHK(brick_alloc(&bb.desc[1], maxdesc));
         bb.cap_desc = maxdesc;
     }
+    if (!bb.pack) BCHK(brick_alloc(&bb.pack, 1));
     if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1));  BCHK(brick_alloc(&bb.admit, 1 + 3 * SOC_MAXLAUNCH)); }
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.posq = bb.posq;  A.hist = bb.hist;  A.off = bb.off;  A.total = bb.total;
     A.admit = bb.admit;
-    // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
-    // order, as earlier ones finish
     A.nl = K.n;
     for (int l = 0; l <= SOC_MAXLAUNCH; l++) A.first[l] = K.first[l];
-    if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
-    A.target = (population > 0 && (uint32_t)population < count) ? population : (int)count;
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
@@ -1254,9 +1259,11 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     }
     if (all_bg && !getenv("SOC_BRICK_NOLEAN")) kind = 3;               // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
-    const int nev = ((int)((count + A.P - 1) / A.P) + 3 * K.n) * slices;
+    const int nev = ((int)((live + A.P - 1) / A.P) + 3 * K.n) * slices;
 
-    soc_brick2_init<<<(max(count, (uint32_t)NQ) + 255) / 256, 256, 0, st>>>(K, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
+    BCHK(hipMemcpyAsync(bb.pack, &K, sizeof(SocSimPack), hipMemcpyHostToDevice, st));
+    BCHK(hipStreamSynchronize(st));                                   // K is on this stack
+    soc_brick2_init<<<(max(count, (uint32_t)NQ) + 255) / 256, 256, 0, st>>>(bb.pack, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
     BCHK(hipGetLastError());
     int passes = 0, total = 1;
     while (total > 0) {
@@ -1265,9 +1272,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
-            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
-            else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, K, A, maxdesc, slices);
+            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
             Q.NB = NQ - 1;
             Q.ev_brick = A.NB;

@@ -57,8 +57,9 @@ struct SocSim {
 #define SOC_SOURCE_CL 5        /* brick sweep only: a SimRAM_CL launch (cell emission)                        */
 
 // Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the
-// sweep's work items [first[l], first[l+1]); geometry and tallies are shared.
-#define SOC_MAXLAUNCH 8
+// sweep's work items [first[l], first[l+1]); geometry and tallies are shared.  Lives in device memory
+// (16 launches exceed the 4 KB of kernel arguments).
+#define SOC_MAXLAUNCH 16
 struct SocSimPack {
     int      n;
     uint32_t first[SOC_MAXLAUNCH + 1];
