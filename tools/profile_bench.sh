@@ -10,11 +10,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 4 --warmup 0 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 4 --warmup 0 --no-cpu-baseline > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline > $OUT/bench_write.log 2>&1
 cd $ROOT
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) profiles/${TAG}_kernel_stats.csv
-python3 tools/summarize_pmc.py $TAG 4 $OUT/fetch $OUT/write
+python3 tools/summarize_pmc.py $TAG 16 $OUT/fetch $OUT/write
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_summary.csv profiles/traffic.json $OUT/
 tail -1 $OUT/bench_stats.log
