@@ -103,3 +103,36 @@ def test_two_rank_scattering_run_equals_single(tmp_path):
     _, data = files.read_outcoming(os.path.join(d, "s0", "outcoming.socs"), 2)
     assert np.allclose(data, O1, rtol=1e-5, atol=1e-7 * np.abs(O1).max())
     assert not os.path.exists(os.path.join(d, "s1", "outcoming.socs"))       # only rank 0 writes
+
+
+def test_two_rank_roi_record_equals_single(tmp_path):
+    """roisave with two ranks: every rank records the packets of its work items, the per-frequency records are
+    summed over the ranks (Comm.all_reduce_host) and rank 0 writes the file"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_host import _write_model
+    from oracle_engine import OracleEngine
+    from soc_amd import synth
+    from soc_amd.ini import User
+    from soc_amd.asoc import AbsorptionRun
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(8, seed=3)
+    ini = _write_model(d, cloud, extra="gridlength 5e-7\nroi 2 5 2 5 3 4\nroisave %s/roi.save 1\nroinside 2\n" % d)
+    for r in (0, 1):
+        os.makedirs(os.path.join(d, "r%d" % r))
+    os.makedirs(os.path.join(d, "single"))
+    os.chdir(os.path.join(d, "single"))
+    AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    single = np.fromfile(os.path.join(d, "roi.save"), np.float32, offset=20)
+    assert (single > 0).sum() > 100
+    os.remove(os.path.join(d, "roi.save"))
+    script = os.path.join(d, "worker.py")
+    with open(script, "w") as fp:
+        fp.write(WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29535", script, ini, d],
+                          env=env, timeout=600)
+    assert list(np.fromfile(os.path.join(d, "roi.save"), np.int32, 5)) == [4, 4, 2, 2, 3]
+    both = np.fromfile(os.path.join(d, "roi.save"), np.float32, offset=20)
+    assert np.array_equal(both > 0, single > 0)
+    assert np.allclose(both, single, rtol=1e-5, atol=1e-7 * single.max())
