@@ -117,7 +117,7 @@ class OracleEngine:
                gid_first=0, gid_count=None):
         job = self._roi(self._job(SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS, PS, XPS), SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     def set_hpbg(self, BG, HPBGP=None):
@@ -127,7 +127,7 @@ class OracleEngine:
         job = self._job(1, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
         job.HPBG, job.HPBGP = self.HPBG, self.HPBGP
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 2, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        _, _, n = self.orc.sim(job, 2, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
@@ -135,7 +135,7 @@ class OracleEngine:
         job.WITH_ALI, job.XAB, job.EMINDEX = self.ali, self.T[2], self.EMINDEX
         self._roi(job, SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1])
+        _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     # ---- temperature and emission ----

@@ -182,3 +182,41 @@ def test_host_temperature_solve_matches_device_formula_away_from_its_quirk():
     leaf = o8.DENS > 0
     assert (Th[~leaf] == 0).all()
     assert np.abs(Th[leaf] - Td[leaf]).max() < 1.2 * np.diff(TTT).max()
+
+
+@pytest.mark.gpu
+def test_iteration_loop_end_to_end_with_cell_emission_in_the_brick_sweep(engine, tmp_path):
+    """`global` = number of cells on a 64^3 model: the dust-emission launches of asoc.py are deferred per frequency
+    and run through the brick sweep (SimRAM_CL kind); temperatures equal the oracle engine's run"""
+    from oracle_engine import OracleEngine
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(64, seed=9)
+    extra = ("gridlength 2e-6\nnoabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal %d\n"
+             "bgpackets 400000\n" % (cloud.CELLS, d, d, cloud.CELLS))
+    ini = _write_model(d, cloud, extra=extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+
+    class Counting(OracleEngine):
+        threads = 8
+
+    want = AbsorptionRun(User(ini), Counting("soc"), verbose=0)
+    want.run()
+    os.remove(os.path.join(d, "em.bin"))
+    passes = []
+    real_batch_end = engine.batch_end
+
+    def spy():
+        real_batch_end()
+        passes.append(engine.last_passes())
+    engine.batch_end = spy
+    try:
+        got = AbsorptionRun(User(ini), engine, verbose=0)
+        got.run()
+    finally:
+        engine.batch_end = real_batch_end
+    assert max(passes) > 0, "no launch of the run went through the brick sweep"
+    assert np.abs(got.TNEW / want.TNEW - 1).max() < 5e-5
+    assert np.allclose(got.EMITTED, want.EMITTED, rtol=5e-3)
