@@ -90,26 +90,65 @@ def run(engine, sol, ABSORBED, NSTOCH=999, IFREQ=-1, batch=65536, verbose=True):
     return EMITTED, tker
 
 
+def cell_range(CELLS, rank, world):
+    """cells [c0, c1) of rank `rank`: the cells of a grid are independent in A2E, so N GPUs split them"""
+    per = (CELLS + world - 1) // world
+    return min(rank * per, CELLS), min((rank + 1) * per, CELLS)
+
+
+def run_sharded(engine_factory, solver, absorbed, emitted, NSTOCH=999, IFREQ=-1, comm=None, verbose=True):
+    """The whole program for one rank of `comm` (or alone): memory-map the absorbed file, solve this rank's cells,
+    write them into this rank's part of the emitted file.  No collective on the data path -- the ranks only wait
+    for rank 0 to have created the file, and for each other at the end.  Returns (cells solved, kernel seconds)."""
+    rank, world = (comm.rank, comm.world) if comm else (0, 1)
+    sol = files.read_solver(solver)
+    dims = np.fromfile(absorbed, np.int32, 2)
+    CELLS, NFREQ = int(dims[0]), int(dims[1])
+    ABS = np.memmap(absorbed, dtype=np.float32, mode='r', offset=8, shape=(CELLS, NFREQ))
+    nout = 1 if IFREQ >= 0 else NFREQ
+    if rank == 0:
+        with open(emitted, 'wb') as fp:
+            np.asarray([CELLS, nout], np.int32).tofile(fp)
+            fp.truncate(8 + 4 * CELLS * nout)
+    if comm:
+        comm.barrier()
+    c0, c1 = cell_range(CELLS, rank, world)
+    tker = 0.0
+    if c1 > c0:
+        eng = engine_factory()
+        try:
+            EM, tker = run(eng, sol, ABS[c0:c1, :], NSTOCH, IFREQ, verbose=verbose and rank == 0)
+        finally:
+            if hasattr(eng, "close"):
+                eng.close()
+        out = np.memmap(emitted, dtype=np.float32, mode='r+', offset=8, shape=(CELLS, nout))
+        out[c0:c1, :] = EM
+        out.flush()
+        del out
+    if comm:
+        comm.barrier()
+    return c1 - c0, tker
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 4:
         print("Usage:  python -m soc_amd.a2e  solver absorbed emitted [GPU [NSTOCH [IFREQ]]]")
+        print("        (N GPUs: python -m torch.distributed.run --nproc-per-node N -m soc_amd.a2e ...)")
         return 1
     from .lib import Engine
+    from .dist import Comm
     NSTOCH = int(argv[5]) if len(argv) > 5 else 999
     IFREQ = int(argv[6]) if len(argv) > 6 else -1
     t0 = time.time()
-    sol = files.read_solver(argv[1])
-    ABSORBED = files.read_absorbed(argv[2])
-    eng = Engine(0)
-    try:
-        EMITTED, tker = run(eng, sol, ABSORBED, NSTOCH, IFREQ)
-    finally:
-        eng.close()
-    files.write_emitted(argv[3], EMITTED)
+    comm = Comm()
+    n, tker = run_sharded(lambda: Engine(comm.local_rank), argv[1], argv[2], argv[3], NSTOCH, IFREQ,
+                          comm if comm.world > 1 else None)
     DT = time.time() - t0
-    print('@@  a2e %.3f SECONDS   (solver calls %.3f s)' % (DT, tker))
-    print('  %4d  -- %.3e SECONDS PER CELL  -- %8.3f CELLS PER SECOND' % (len(EMITTED), DT / len(EMITTED), len(EMITTED) / DT))
+    if comm.rank == 0:
+        print('@@  a2e %.3f SECONDS   (solver calls %.3f s on rank 0, %d ranks)' % (DT, tker, comm.world))
+        print('  %4d  -- %.3e SECONDS PER CELL  -- %8.3f CELLS PER SECOND' % (n * comm.world, DT / max(n * comm.world, 1), n * comm.world / DT))
+    comm.close()
     return 0
 
 

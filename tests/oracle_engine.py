@@ -212,3 +212,21 @@ class OracleEngine:
 
     def close(self):
         pass
+
+
+class OracleA2E:
+    """the A2E entry points of soc_amd.lib.Engine on the CPU oracle (multi-process tests of soc_amd.a2e)"""
+
+    def __init__(self, mode="soc"):
+        self.orc = Oracle(mode)
+
+    def a2e_set_size(self, NE, NFREQ, size, AF):
+        self.NE, self.NFREQ, self.size, self.AF = NE, NFREQ, size, np.asarray(AF, np.float32)
+
+    def a2e_solve(self, AABS):
+        from oracle.pyoracle import a2e_oracle_dosolve
+        return a2e_oracle_dosolve(self.orc, self.NE, self.NFREQ, self.size, self.AF, np.ascontiguousarray(AABS, np.float32))
+
+    def a2e_eqtemp(self, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+        from oracle.pyoracle import a2e_oracle_eqtemp
+        return a2e_oracle_eqtemp(self.orc, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS)

@@ -147,3 +147,19 @@ def test_gpu_a2e_host_program(engine, oracle_soc, tmp_path):
                               np.asarray(A * AF, np.float32))
     want += e2 * (sol["GD"] * sol["S_FRAC"][2])
     assert np.allclose(E, want, rtol=5e-5, atol=1e-30 * want.max())
+
+
+@pytest.mark.gpu
+def test_gpu_a2e_sharded_program_equals_in_memory_run(engine, tmp_path):
+    """python -m soc_amd.a2e: memory-mapped absorbed file, this rank's cell range, its part of the emitted file"""
+    from soc_amd import a2e, files
+    from soc_amd.lib import Engine
+    d = str(tmp_path)
+    sol = synth.synth_solver(NFREQ=12, NE=16, NSIZE=3, seed=2)
+    synth.write_solver(os.path.join(d, "x.solver"), sol)
+    ABS = (np.random.default_rng(3).lognormal(0, 1, (300, 12)) * 1e-3).astype(np.float32)
+    files.write_absorbed(os.path.join(d, "abs.bin"), ABS)
+    n, _ = a2e.run_sharded(lambda: Engine(0), os.path.join(d, "x.solver"), os.path.join(d, "abs.bin"),
+                           os.path.join(d, "em.bin"), NSTOCH=2, verbose=False)
+    want, _ = a2e.run(engine, files.read_solver(os.path.join(d, "x.solver")), ABS, NSTOCH=2, verbose=False)
+    assert n == 300 and np.array_equal(files.read_absorbed(os.path.join(d, "em.bin")), want)

@@ -136,3 +136,44 @@ def test_two_rank_roi_record_equals_single(tmp_path):
     both = np.fromfile(os.path.join(d, "roi.save"), np.float32, offset=20)
     assert np.array_equal(both > 0, single > 0)
     assert np.allclose(both, single, rtol=1e-5, atol=1e-7 * single.max())
+
+
+A2E_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+from soc_amd import a2e
+from soc_amd.dist import Comm
+from oracle_engine import OracleA2E
+comm = Comm(backend="gloo")
+a2e.run_sharded(OracleA2E, sys.argv[1], sys.argv[2], sys.argv[3], NSTOCH=2, comm=comm, verbose=False)
+comm.close()
+"""
+
+
+def test_two_rank_a2e_equals_single(tmp_path):
+    """A2E on N GPUs: the cells are split over the ranks, every rank writes its part of the emitted file"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle_engine import OracleA2E
+    from soc_amd import a2e, files, synth
+    d = str(tmp_path)
+    sol = synth.synth_solver(NFREQ=12, NE=16, NSIZE=3, seed=2)
+    synth.write_solver(os.path.join(d, "x.solver"), sol)
+    ABS = (np.random.default_rng(3).lognormal(0, 1, (301, 12)) * 1e-3).astype(np.float32)
+    files.write_absorbed(os.path.join(d, "abs.bin"), ABS)
+    assert a2e.cell_range(301, 0, 2) == (0, 151) and a2e.cell_range(301, 1, 2) == (151, 301) and a2e.cell_range(3, 3, 8) == (3, 3)
+    n, _ = a2e.run_sharded(OracleA2E, os.path.join(d, "x.solver"), os.path.join(d, "abs.bin"), os.path.join(d, "em1.bin"),
+                           NSTOCH=2, verbose=False)
+    assert n == 301
+    E1 = files.read_absorbed(os.path.join(d, "em1.bin"))
+    want, _ = a2e.run(OracleA2E(), files.read_solver(os.path.join(d, "x.solver")), ABS, NSTOCH=2, verbose=False)
+    assert E1.shape == (301, 12) and np.array_equal(E1, want) and (E1 > 0).any()
+    script = os.path.join(d, "worker.py")
+    with open(script, "w") as fp:
+        fp.write(A2E_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29537", script,
+                           os.path.join(d, "x.solver"), os.path.join(d, "abs.bin"), os.path.join(d, "em2.bin")],
+                          env=env, timeout=600)
+    E2 = files.read_absorbed(os.path.join(d, "em2.bin"))
+    assert np.array_equal(E2, E1)                      # cells are independent: bit-identical
