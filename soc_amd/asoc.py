@@ -209,7 +209,7 @@ class AbsorptionRun:
             e.zero(0)
             # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
             # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
-            deferred = (not self.with_int) and II < 2 and self.ROI_SAVE is None and hasattr(e, "batch_begin")
+            deferred = (not self.with_int) and self.ROI_SAVE is None and hasattr(e, "batch_begin")   # the engine decides per launch
             if deferred:
                 e.batch_begin(0)
             for IFREQ in range(NFREQ):
