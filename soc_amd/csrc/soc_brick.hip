@@ -1,5 +1,5 @@
-// soc_brick.hip -- "brick sweep" execution of SimRAM_PB on Cartesian grids: absorption
-// tallies live in LDS, not on the fabric.
+// soc_brick.hip -- "brick sweep" execution of SimRAM_PB / SimRAM_HP / SimRAM_CL, on Cartesian grids and on
+// hierarchies: absorption tallies live in LDS, not on the fabric.
 //
 // Why: the direct kernel issues one scattered global float atomic per cell step.  On
 // MI355X those execute at the memory side at ~2e10 64-B requests/s chip-wide whatever the
@@ -7,7 +7,8 @@
 // tally events, kernel pinned at 1.94e10 steps/s while the same walk without tallies runs
 // at 1.2e11 steps/s).  No scope or cache policy moves them into L2.
 //
-// How: the grid is cut into bricks of B^3 root cells.  In-flight packets (one per logical
+// How: the grid is cut into bricks (B^3 root cells; on a hierarchy sets of <= CAP neighbouring cells, see
+// soc_oct_build).  In-flight packets (one per logical
 // work item -- a work item's packets are sequential in its RNG stream, so one is in
 // flight at a time) are kept sorted by the queue they wait in: one queue per brick, plus
 // one for work items whose packet has left the cloud and one for packets whose free path
@@ -20,7 +21,9 @@
 //                     creation of the work item's next packet (all RNG use is here);
 //   soc_brick_scan    exclusive scan of the arrival histogram -> next queue offsets and
 //                     workgroup descriptors (one workgroup, exact sizes, no capacity guess);
-//   soc_brick_scatter counting-sort placement of the packet ids into the next queues.
+//                     and admission of waiting work items (population control);
+//   soc_brick_scatter permutation of the packet ids into the next queues (every packet's place was settled
+//                     in the pass: its rank in the workgroup's LDS count + what the histogram add returned).
 // A kernel boundary separates the phases, so no in-launch inter-workgroup hand-off exists.
 // Several launches (frequencies of a run, steps of the benchmark) can share one sweep: their
 // work items are one population, each launch with its own pair of event queues.
