@@ -30,6 +30,9 @@ def _newer(target, sources):
 
 def build_oracle(force=False):
     """Compile both math modes of the CPU restatement.  Returns {mode: path}."""
+    if os.environ.get("SOC_ORACLE_LIB_DIR"):
+        # prebuilt variants of the two libraries, e.g. an -fsanitize=address,undefined build (tools/oracle_sanitize.sh)
+        return {m: os.path.join(os.environ["SOC_ORACLE_LIB_DIR"], "liborc_%s.so" % m) for m in ("soc", "libm")}
     os.makedirs(BUILD_DIR, exist_ok=True)
     srcs = [os.path.join(HERE, "soc_oracle.c"), os.path.join(HERE, "a2e_oracle.c"),
             os.path.join(HERE, "soc_oracle_index.inc"), os.path.join(REPO, "soc_amd", "csrc", "soc_math.h")]
