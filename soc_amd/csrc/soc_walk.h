@@ -543,13 +543,14 @@ __device__ __forceinline__ void soc_pb_create(const SocGrid &G, const SocSim &S,
         float sp, cp;
         soc_sincosf(phi, &sp, &cp);
         float v1 = sin_theta * cp, v2 = sin_theta * sp;
-        switch (SIDE) {
-        case 0: w.ux =  cos_theta; w.uy = v1; w.uz = v2; break;
-        case 1: w.ux = -cos_theta; w.uy = v1; w.uz = v2; break;
-        case 2: w.uy =  cos_theta; w.ux = v1; w.uz = v2; break;
-        case 3: w.uy = -cos_theta; w.ux = v1; w.uz = v2; break;
-        case 4: w.uz =  cos_theta; w.ux = v1; w.uy = v2; break;
-        default: w.uz = -cos_theta; w.ux = v1; w.uy = v2; break;
+        // kernel_ASOC.c:449-456: sides 0/1 (c,v1,v2), 2/3 (v1,c,v2), 4/5 (v1,v2,c) with c = -+cos_theta on the
+        // odd side.  Written as selects (a switch on SIDE becomes a private array in scratch memory).
+        {
+            const float c = (SIDE & 1) ? -cos_theta : cos_theta;
+            const int   axis = SIDE >> 1;
+            w.ux = (axis == 0) ? c : v1;
+            w.uy = (axis == 0) ? v1 : ((axis == 1) ? c : v2);
+            w.uz = (axis >= 2) ? c : v2;
         }
         w.photons = S.BG;
         soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
