@@ -86,6 +86,7 @@ __device__ __forceinline__ void soc_st4(float4 *p, float4 a) { soc_f4v v = { a.x
 struct SocBrickArgs {
     int LB, NBX, NBY, NBZ, NB;   // brick edge = 1 << LB root cells; NB bricks
     int T, P, KCAP, FTH;         // step-kernel threads, packets per chunk, max steps per packet per pass, fetch threshold
+    int CTH;                     // lanes waiting for the deferred Index() before that arm is entered (hierarchies)
     int TAIL;                    // a wave with this many lanes out of work sends its last packets back to the queue (0: never)
     SocPk2 *pk;
     const uint32_t *idq;         // current queue (ids sorted by brick)
@@ -429,7 +430,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             SOC_PROF_T(1);                                 // step
             {
                 const unsigned long long mc = __ballot(mode == SOC_BM_CLIMB);
-                if (mc != 0ull && (__popcll(mc) >= A.FTH || __ballot(mode == SOC_BM_STEP) == 0ull)) {
+                if (mc != 0ull && (__popcll(mc) >= A.CTH || __ballot(mode == SOC_BM_STEP) == 0ull)) {
                     SOC_PROF(2, 1);  SOC_PROF(3, __popcll(mc));
                     if (mode == SOC_BM_CLIMB) {
                         if (DBL) soc_index<true, double>(G, sOFF, px, py, pz, level, ind, dens);
@@ -1153,6 +1154,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     if (const char *e = getenv("SOC_BRICK_P")) A.P = atoi(e);
     if (const char *e = getenv("SOC_BRICK_KCAP")) A.KCAP = atoi(e);
     if (const char *e = getenv("SOC_BRICK_FTH")) A.FTH = atoi(e);
+    A.CTH = A.FTH;
+    if (const char *e = getenv("SOC_BRICK_CTH")) A.CTH = atoi(e);
     if (const char *e = getenv("SOC_BRICK_CAP")) A.CAP = atoi(e);
     if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
     if (A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS)) return hipErrorInvalidValue;
