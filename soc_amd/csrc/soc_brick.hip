@@ -1212,6 +1212,13 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     const int NQ = A.NB + 2 * K.n + 1;
     // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
     // order, as earlier ones finish.  Queues, descriptors and the grids of the passes are sized for that many.
+    if (population < 0) {
+        // measured: about 5300 packets per brick on Cartesian grids (C2, 512 bricks: 2.7e6 -> 8.5e8 packets/s, 2.1e6 and
+        // 3.1e6 -> 8.1e8; 256^3, 4096 bricks: 2.6e7 -> 1.09e11 steps/s, 2.7e6 -> 8.1e10), 2.6e7 on the 256^3-root
+        // hierarchy (1.3e7 -> 3.7e10 steps/s, 5.0e7 -> 4.0e10)
+        const long long p = V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NB);
+        population = (int)std::min(p, 2000000000LL);
+    }
     if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
     A.target = (population > 0 && (uint32_t)population < count) ? population : (int)count;
     const uint32_t live = (uint32_t)A.target;

@@ -152,11 +152,8 @@ static int flush_pending(soc_ctx *c)
         }
         return SOC_OK;
     }
-    // Cartesian grids: 2.7e6 packets in flight (173 MB of packet records) was measured best on C2 -- 8.5e8 packets/s;
-    // 2.1e6: 8.1e8, 3.1e6: 8.1e8, 3.9e6: 7.6e8, 6.3e6: 7.7e8 (the records spill the 256 MB last-level cache) --
-    // hierarchies (latency-bound, nothing fits a cache): 2.6e7 was measured best on the 256^3-root one -- 4.5e10 steps/s;
-    // 1.3e7: 3.7e10, 5.0e7: 4.0e10
-    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, V.octree ? 26000000 : 2700000, c->stream, &c->last_passes);
+    // packets in flight: chosen by the sweep from the number of bricks (-1)
+    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->stream, &c->last_passes);
     if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
     return SOC_OK;
 }
@@ -660,7 +657,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -870,7 +867,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -931,7 +928,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, 0, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }

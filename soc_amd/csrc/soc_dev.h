@@ -146,7 +146,8 @@ hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st);
 hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
 
 // brick-sweep execution (soc_brick.hip): LDS-resident tallies, packets sorted by brick
-// population: packets in flight (0 = all work items at once): the other work items are admitted as earlier ones finish
+// population: packets in flight (0 = all work items at once, -1 = chosen from the number of bricks): the other work
+// items are admitted as earlier ones finish
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *S, int nlaunch, const SocVariant &V, int LB,
                             int population, hipStream_t st, int *passes_out);
 void soc_brick_release(int device);
