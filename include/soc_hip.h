@@ -135,6 +135,12 @@ int soc_sim_cl(soc_ctx *ctx, int SOURCE, int PACKETS, int BATCH, float SEED, flo
  * first; launches that do not qualify run immediately as always. */
 int soc_batch_begin(soc_ctx *ctx, int max_launches);
 int soc_batch_end(soc_ctx *ctx);
+/* The same for runs that keep the per-frequency INT tally (the absorbed file, ASOC.py:1482-1498): every deferred
+ * launch gets its own, zeroed INT tally instead of the shared one (TABS stays shared).  At most max_launches (<= 16)
+ * launches of one kind per batch; after soc_batch_end, soc_batch_read_int(k) copies the INT tally of the k-th launch of
+ * the batch (n = CELLS).  Replaces K x [kernel launch + enqueue_copy(INT)] by K launches + K copies. */
+int soc_batch_begin_int(soc_ctx *ctx, int max_launches);
+int soc_batch_read_int(soc_ctx *ctx, int k, float *out, long n);
 
 /* ---- region of interest of nested runs (ini keys roi, roisave, roiload, roipac, roinside) ---- */
 

@@ -210,15 +210,28 @@ class AbsorptionRun:
             # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
             # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
             deferred = (not self.with_int) and self.ROI_SAVE is None and hasattr(e, "batch_begin")   # the engine decides per launch
+            # runs that keep the per-frequency absorptions: up to 16 frequencies per batch, every launch with its own
+            # INT tally, read after the batch (one process, Cartesian grids: there the shared sweep pays)
+            int_batched = (self.with_int and FABSORBED is not None and self.ROI_SAVE is None and II != 3 and c.LEVELS == 1
+                           and (self.comm is None or self.world == 1) and hasattr(e, "batch_begin_int"))
+            group = []
+
+            def end_group():
+                e.batch_end()
+                for k, f in enumerate(group):
+                    FABSORBED[:, f] += e.batch_read_int(k)
+                del group[:]
             if deferred:
                 e.batch_begin(0)
+            if int_batched:
+                e.batch_begin_int(16)
             for IFREQ in range(NFREQ):
                 FREQ = float(FFREQ[IFREQ])
                 if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
                     continue
                 t0 = time.time()
                 ABS, SCA = self._optical_for(IFREQ)
-                if self.with_int:
+                if self.with_int and not int_batched:
                     e.zero(1)
                 PS = (self.LPS[:, IFREQ] * np.float32(WPS)) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
                 BG = np.float32(float(self.IBG[IFREQ]) * WBG / FREQ) if len(self.IBG) == NFREQ else np.float32(0.0)
@@ -264,12 +277,17 @@ class AbsorptionRun:
                              GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
                 if self.with_int and self.comm:
                     self.comm.all_reduce_tally(e, 1)      # one all-reduce of the per-cell buffer per frequency
-                if not deferred:
+                if int_batched:
+                    group.append(IFREQ)
+                    if len(group) == 16:
+                        end_group()
+                        e.batch_begin_int(16)
+                elif not deferred:
                     e.sync()
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
                 t0 = time.time()
-                if FABSORBED is not None:
+                if FABSORBED is not None and not int_batched:
                     FABSORBED[:, IFREQ] += e.read_tally(1)
                 if self.ROI_SAVE is not None:
                     # += : point sources, background and a loaded record all pass here; GL^2 scales away the
@@ -286,6 +304,10 @@ class AbsorptionRun:
                 t0 = time.time()
                 e.batch_end()
                 e.sync()
+                self.timers["Tkernel"] += time.time() - t0
+            if int_batched:
+                t0 = time.time()
+                end_group()
                 self.timers["Tkernel"] += time.time() - t0
             if self.comm:
                 self.comm.all_reduce_tally(e, 0)          # TABS: integrated over frequency on the device

@@ -85,6 +85,8 @@ __device__ __forceinline__ void soc_st4(float4 *p, float4 a) { soc_f4v v = { a.x
 
 struct SocBrickArgs {
     int LB, NBX, NBY, NBZ, NB;   // brick edge = 1 << LB root cells; NB bricks
+    int NBQ;                     // brick queues: NB, or NB per launch (launches with the INT tally: a workgroup's LDS
+                                 // tallies then belong to one launch; queue = launch * NB + brick)
     int T, P, KCAP, FTH;         // step-kernel threads, packets per chunk, max steps per packet per pass, fetch threshold
     int CTH;                     // lanes waiting for the deferred Index() before that arm is entered (hierarchies)
     int TAIL;                    // a wave with this many lanes out of work sends its last packets back to the queue (0: never)
@@ -252,7 +254,7 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
         if (t >= dbase && t < dbase + nd) {
             const uint32_t k = t - dbase;
             SocDesc d;
-            d.brick = A.NB + 2 * l;
+            d.brick = A.NBQ + 2 * l;
             d.start = (int)(K.first[l] + k * A.P);
             d.count = (int)min((uint32_t)A.P, cnt - k * A.P);
             d.pad = 0;
@@ -261,7 +263,7 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
         dbase += nd;
     }
     if (t == 0) { ndesc0[0] = (int)dbase;  ndesc0[2] = 0;  A.admit[0] = (int)active;  *A.total = (int)active; }
-    if (t <= (uint32_t)(A.NB + 2 * K.n)) hist[t] = 0;
+    if (t <= (uint32_t)(A.NBQ + 2 * K.n)) hist[t] = 0;
 }
 
 template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
@@ -270,7 +272,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     constexpr bool CL = (KIND == 2);                       // SimRAM_CL: no nudge after a failed step, D.w holds the emitting cell
     if (bid >= *A.ndesc) return;
     const SocDesc D = A.desc[bid];
-    if (D.brick >= A.NB) return;                           // an event queue: soc_brick_events
+    if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
     const int BV = OCT ? A.CAP : (1 << (3 * A.LB));        // tally slots in LDS
     const int nthr = (int)blockDim.x;
     SocPk2 *pk = A.pk;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + BV;                                 // [BV] INT (WINT)
-    const int NQ = A.NB + 2 * K.n + 1;                     // bricks, (creation, scattering) per launch, finished
+    const int NQ = A.NBQ + 2 * K.n + 1;                    // brick queues, (creation, scattering) per launch, finished
     int   *sH   = (int *)(sI + (WINT ? BV : 0));           // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0] next packet, [1] tally events
     float *sL   = (float *)(sCtl + 2);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
@@ -289,7 +291,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
         sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
     }
     if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
-    const int nslot = OCT ? (A.bbase[D.brick + 1] - A.bbase[D.brick]) : BV;
+    const int brick0 = (A.NBQ > A.NB) ? (D.brick % A.NB) : D.brick;         // the brick of this queue
+    const int nslot = OCT ? (A.bbase[brick0 + 1] - A.bbase[brick0]) : BV;
     for (int i = threadIdx.x; i < nslot; i += nthr) { sT[i] = 0.0f; if (WINT) sI[i] = 0.0f; }
     soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
@@ -297,7 +300,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
 
     const int   NX = G.NX, NY = G.NY;
     const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
-    const int   mybrick = D.brick, LB = A.LB, M = (1 << A.LB) - 1;
+    const int   mybrick = brick0, LB = A.LB, M = (1 << A.LB) - 1;
+    const int   qbase = D.brick - mybrick;                 // first brick queue of this workgroup's launch (0 when the launches share queues)
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
@@ -316,7 +320,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
             // the chunk has run out and most of the wave idles behind its longest walks: those continue in the next
             // pass, from this brick's queue, among a full wave again (between steps the packet state is complete)
-            if (A.TAIL > 0 && __popcll(__ballot(mode == SOC_BM_IDLE)) >= A.TAIL && mode == SOC_BM_STEP) { mode = SOC_BM_SWAP;  key = mybrick; }
+            if (A.TAIL > 0 && __popcll(__ballot(mode == SOC_BM_IDLE)) >= A.TAIL && mode == SOC_BM_STEP) { mode = SOC_BM_SWAP;  key = D.brick; }
             const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
             const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
             if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
@@ -326,7 +330,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                         SocPk2 *q = pk + wid;
                         soc_st4(&q->A, make_float4(px, py, pz, photons));
                         soc_st4(&q->C, make_float4(tau, dens, __int_as_float(lid | (level << SOC_LVL_SHIFT) | lsh), __int_as_float(ind)));
-                        if (!CL && key >= A.NB) SOC_NT_STORE((uint32_t)mybrick, &q->D.w);   // scattering: the brick to come back to (SimRAM_CL keeps its cell there)
+                        if (!CL && key >= A.NBQ) SOC_NT_STORE((uint32_t)D.brick, &q->D.w);   // scattering: the brick to come back to (SimRAM_CL keeps its cell there)
                         SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + slot]);
                         sPos[slot] = soc_qh_rank(sH, A.HS, key, A.hist);
                     }
@@ -388,7 +392,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 const float dtau = ds * d0 * ksca;
                 if (free_path < (tau + dtau)) {
                     px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                    mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT) + 1;
+                    mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT) + 1;
                 } else {
                     const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                     const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
@@ -448,11 +452,11 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 }
                 nvisit++;
                 if (ind < 0) {
-                    mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT);                          // -> creation queue
+                    mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT);                          // -> creation queue
                 } else {
                     const int nb = (int)(sl >> SOC_SLOT_BITS);
                     lid = (int)(sl & SOC_SLOT_MASK);
-                    if (nb != mybrick || nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = nb; }
+                    if (nb != mybrick || nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = qbase + nb; }
                 }
             }
         } else
@@ -493,7 +497,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             const float dtau = ds * d0 * ksca;
             if (free_path < (tau + dtau)) {
                 px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT) + 1;   // -> scattering queue of its launch
+                mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT) + 1;   // -> scattering queue of its launch
             } else {
                 // every lane of the wave in the interval where soc_expf_small == soc_expf (the common case)
                 const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
@@ -511,8 +515,8 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 py += failed ? (SOC_PEPS * uy) : 0.0f;
                 pz += failed ? (SOC_PEPS * uz) : 0.0f;
                 nvisit++;
-                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NB + 2 * (lsh >> SOC_LCH_SHIFT); }   // -> creation queue
-                else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = nb; }
+                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT); }   // -> creation queue
+                else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = qbase + nb; }
             }
         }
     }
@@ -528,7 +532,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             if (v != 0.0f || vi != 0.0f) {
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(S.INT, cell, vi);
+                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
             }
         }
     } else {
@@ -541,7 +545,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 const int ix = bx * B + (i & M), iy = by * B + ((i >> A.LB) & M), iz = bz * B + (i >> (2 * A.LB));
                 const int cell = iz * NX * NY + iy * NX + ix;
                 soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(S.INT, cell, vi);
+                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
             }
         }
     }
@@ -562,7 +566,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
     const int di = A.ndesc[2] + ebid;
     if (di >= *A.ndesc) return;
     SocDesc D = A.desc[di];
-    if (D.brick < A.NB) return;
+    if (D.brick < A.NBQ) return;
     {
         const int first = (int)(slice * blockDim.x);
         if (first >= D.count) return;
@@ -570,9 +574,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         D.count = min((int)blockDim.x, D.count - first);
     }
     SocPk2 *pk = A.pk;
-    const int NQ = A.NB + 2 * K.n + 1;
-    const int lq = (D.brick - A.NB) >> 1;                  // the launch this queue belongs to (workgroup-uniform)
+    const int NQ = A.NBQ + 2 * K.n + 1;
+    const int lq = (D.brick - A.NBQ) >> 1;                  // the launch this queue belongs to (workgroup-uniform)
     const SocSim &S = K.S[lq];
+    const int qbase = (A.NBQ > A.NB) ? lq * A.NB : 0;      // first brick queue of this launch
     extern __shared__ float lds[];
     int   *sH   = (int *)lds;                              // arrivals per queue
     int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0..2] stats
@@ -599,7 +604,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         w.scat = (int)(p.D.z >> 24);
         int key = (int)p.D.w;
         uint32_t cl_cell = p.D.w;                              // SimRAM_CL: the cell the work item emits from
-        bool create = (((D.brick - A.NB) & 1) == 0);
+        bool create = (((D.brick - A.NBQ) & 1) == 0);
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
             const int oind = (OCT ? sOFF[w.level] : 0) + w.ind;
@@ -639,6 +644,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                     key = ((iz >> A.LB) * A.NBY + (iy >> A.LB)) * A.NBX + (ix >> A.LB);
                     lid = ((iz & M) << (2 * A.LB)) | ((iy & M) << A.LB) | (ix & M);
                 }
+                key += qbase;
             }
             }
         }
@@ -719,6 +725,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                     key = ((iz >> A.LB) * A.NBY + (iy >> A.LB)) * A.NBX + (ix >> A.LB);
                     lid = ((iz & M) << (2 * A.LB)) | ((iy & M) << A.LB) | (ix & M);
                 }
+                key += qbase;
             }
             III = IRAY;
             cl_cell = (uint32_t)ICELL;
@@ -744,6 +751,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                     } else {
                         soc_cell_brick(A, w.px, w.py, w.pz, key, lid);
                     }
+                    key += qbase;
                     break;
                 }
             }
@@ -1137,7 +1145,6 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
                             int population, hipStream_t st, int *passes_out)
 {
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
-    if (nlaunch > 1 && V.wint) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
@@ -1209,14 +1216,17 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         for (int l = 1; l < K.n; l++)
             if ((long long)(K.S[l].OPT - K.S[0].OPT) != l * A.opt_stride) return hipErrorInvalidValue;
     }
-    const int NQ = A.NB + 2 * K.n + 1;
+    // launches with the INT tally: brick queues per launch, so that a workgroup's LDS tallies belong to one launch
+    A.NBQ = (V.wint && K.n > 1) ? A.NB * K.n : A.NB;
+    if ((long long)A.NB * K.n > (1 << 20)) return hipErrorNotSupported;
+    const int NQ = A.NBQ + 2 * K.n + 1;
     // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
     // order, as earlier ones finish.  Queues, descriptors and the grids of the passes are sized for that many.
     if (population < 0) {
         // measured: about 5300 packets per brick on Cartesian grids (C2, 512 bricks: 2.7e6 -> 8.5e8 packets/s, 2.1e6 and
         // 3.1e6 -> 8.1e8; 256^3, 4096 bricks: 2.6e7 -> 1.09e11 steps/s, 2.7e6 -> 8.1e10), 2.6e7 on the 256^3-root
         // hierarchy (1.3e7 -> 3.7e10 steps/s, 5.0e7 -> 4.0e10)
-        const long long p = V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NB);
+        const long long p = V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
         population = (int)std::min(p, 2000000000LL);
     }
     if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
@@ -1290,7 +1300,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
             Q.NB = NQ - 1;
-            Q.ev_brick = A.NB;
+            Q.ev_brick = A.NBQ;
             soc_brick_scan<<<1, 1024, 0, st>>>(Q);
             soc_brick_scatter<<<maxdesc + 16 * K.n, SOC_BRICK_T, 0, st>>>(Q, maxdesc);
         }

@@ -66,6 +66,10 @@ struct soc_ctx {
     float2 *dOPTslots = nullptr;                  // [SOC_MAXLAUNCH][CELLS] per-cell opacities of deferred launches
     float *dHPslots = nullptr;                    // [SOC_MAXLAUNCH][2][49152] Healpix skies of deferred SimRAM_HP launches
     float *dEMITslots = nullptr;                  // [SOC_MAXLAUNCH][2][CELLS] EMIT, EMWEI of deferred SimRAM_CL launches
+    float *dINTslots = nullptr;                   // [SOC_MAXLAUNCH][CELLS] INT tallies of deferred launches (soc_batch_read_int)
+    size_t intslot_cells = 0;
+    int    int_slots_done = 0;                    // launches of the last executed sweep whose INT can be read
+    bool   batch_keep_int = false;                // soc_batch_begin_int: deferred launches keep their own INT tally
     size_t emitslot_cells = 0;
     size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
@@ -134,7 +138,8 @@ static int flush_pending(soc_ctx *c)
     todo.swap(c->pending);
     SocVariant V;
     V.octree = c->G.LEVELS > 1;  V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
-    V.abu = todo[0].OPT != nullptr;  V.wint = 0;             // what makes a launch deferrable (see soc_sim_pb)
+    V.abu = todo[0].OPT != nullptr;                          // what makes a launch deferrable (see soc_sim_pb)
+    V.wint = (c->batch_keep_int && c->with_int) ? 1 : 0;
     HIPCHK(c, hipSetDevice(c->device));
     if (V.octree && todo.size() == 1 && c->exec_mode < 0) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
@@ -217,7 +222,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dINTslots, c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -595,6 +600,24 @@ static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *P
 static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot);
 
 // a sweep runs one kernel variant: launches of one kind (SimRAM_PB, _HP or _CL), all with or all without per-cell opacities
+// soc_batch_begin_int: the next launch of the batch -- deferred or not -- gets its own, zeroed INT tally
+static int take_int_slot(soc_ctx *c, const char *who, SocSim &S)
+{
+    if (!(c->batching && c->batch_keep_int && c->with_int)) return SOC_OK;
+    if (c->int_slots_done >= c->batch_max)
+        return fail(c, SOC_ERR_STATE, "%s: %d launches of this batch hold an INT tally; soc_batch_end and soc_batch_read_int first", who, c->batch_max);
+    const size_t cells = (size_t)c->G.CELLS;
+    if (c->intslot_cells != cells) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_alloc(&c->dINTslots, cells * SOC_MAXLAUNCH));
+        c->intslot_cells = cells;
+    }
+    S.INT = c->dINTslots + (size_t)c->int_slots_done * cells;
+    HIPCHK(c, hipMemsetAsync(S.INT, 0, cells * 4, c->stream));
+    c->int_slots_done++;
+    return SOC_OK;
+}
+
 static bool same_sweep(const soc_ctx *c, int source, bool abu)
 {
     if (c->pending.empty()) return true;
@@ -633,14 +656,18 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
-    const bool defer = c->batching && bricks && !V.wint;
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
     if (!defer) FLUSH(c);
+    if (defer && c->batch_keep_int && !same_sweep(c, SOURCE, V.abu != 0))
+        return fail(c, SOC_ERR_STATE, "soc_sim_pb: a batch with the INT tally holds launches of one kind");
     if (defer && !same_sweep(c, SOURCE, V.abu != 0)) FLUSH(c);
+    r = take_int_slot(c, "soc_sim_pb", S);
+    if (r) return r;
     const int slot = defer ? (int)c->pending.size() : 0;
     if (SOURCE == 0) {
         r = upload_sources(c, "soc_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, false, slot);
@@ -653,7 +680,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         r = snapshot_inputs(c, S, V, slot);
         if (r) return r;
         c->pending.push_back(S);
-        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {
@@ -672,8 +699,30 @@ int soc_batch_begin(soc_ctx *c, int max_launches)
         return fail(c, SOC_ERR_ARG, "soc_batch_begin: max_launches %d (1..%d, 0 = default)", max_launches, SOC_MAXLAUNCH);
     FLUSH(c);
     c->batching = true;
+    c->batch_keep_int = false;
+    c->int_slots_done = 0;
     // default: as many as one sweep takes (the packets in flight are limited separately, see flush_pending)
     c->batch_max = max_launches ? max_launches : SOC_MAXLAUNCH;
+    return SOC_OK;
+}
+
+int soc_batch_begin_int(soc_ctx *c, int max_launches)
+{
+    int r = soc_batch_begin(c, max_launches);
+    if (r) return r;
+    c->batch_keep_int = true;
+    return SOC_OK;
+}
+
+int soc_batch_read_int(soc_ctx *c, int k, float *out, long n)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (c->batching || !c->pending.empty()) return fail(c, SOC_ERR_STATE, "soc_batch_read_int: call soc_batch_end first");
+    if (k < 0 || k >= c->int_slots_done) return fail(c, SOC_ERR_ARG, "soc_batch_read_int: launch %d of %d deferred with the INT tally", k, c->int_slots_done);
+    if (!out || n != (long)c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_batch_read_int: the tally has %d cells, buffer %ld", c->G.CELLS, n);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->dINTslots + (size_t)k * c->G.CELLS, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
 }
 
@@ -845,12 +894,16 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && !V.wint;
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
     if (!defer) FLUSH(c);
+    if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0))
+        return fail(c, SOC_ERR_STATE, "soc_sim_hp: a batch with the INT tally holds launches of one kind");
     if (defer && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0)) FLUSH(c);
+    r = take_int_slot(c, "soc_sim_hp", S);
+    if (r) return r;
     c->last_passes = 0;
     if (bricks) S.SOURCE = SOC_SOURCE_HP;
     if (defer) {
@@ -863,7 +916,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         HIPCHK(c, hipMemcpyAsync(sky + 49152, c->dHPBGP, 49152 * 4, hipMemcpyDeviceToDevice, c->stream));
         S.HPBG = sky;  S.HPBGP = sky + 49152;
         c->pending.push_back(S);
-        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {
@@ -900,12 +953,16 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
-    if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8 && (!V.octree || (c->batching && !V.wint));
+    if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && !V.wint;
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
     if (!defer) FLUSH(c);
+    if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0))
+        return fail(c, SOC_ERR_STATE, "soc_sim_cl: a batch with the INT tally holds launches of one kind");
     if (defer && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0)) FLUSH(c);
+    r = take_int_slot(c, "soc_sim_cl", S);
+    if (r) return r;
     c->last_passes = 0;
     if (bricks) S.SOURCE = SOC_SOURCE_CL;
     if (defer) {
@@ -924,7 +981,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         HIPCHK(c, hipMemcpyAsync(em + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
         S.EMIT = em;  S.EMWEI = em + cells;
         c->pending.push_back(S);
-        if ((int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {

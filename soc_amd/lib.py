@@ -43,6 +43,8 @@ API = {
                              C.c_int, C.c_int, C.c_int]),
     "soc_batch_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_batch_end": (C.c_int, [C.c_void_p]),
+    "soc_batch_begin_int": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_batch_read_int": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_long]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
     "soc_set_abundances": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _F]),
@@ -179,6 +181,16 @@ class Engine:
     def batch_begin(self, max_launches=0):
         """Defer the following sim_pb launches and run them together (brick sweep, TABS only)."""
         self._chk(self.lib.soc_batch_begin(self.h, int(max_launches)))
+
+    def batch_begin_int(self, max_launches=0):
+        """like batch_begin, for launches that keep the per-frequency INT tally: each deferred launch gets its own;
+        read them with batch_read_int(k) after batch_end"""
+        self._chk(self.lib.soc_batch_begin_int(self.h, int(max_launches)))
+
+    def batch_read_int(self, k):
+        out = np.zeros(self.CELLS, np.float32)
+        self._chk(self.lib.soc_batch_read_int(self.h, int(k), _f(out), out.size))
+        return out
 
     def batch_end(self):
         self._chk(self.lib.soc_batch_end(self.h))

@@ -100,6 +100,30 @@ class OracleEngine:
             job.ROI_DIM, job.ROI_NSIDE, job.ROI_LOAD = self.roi_load
         return job
 
+    # batches (the CPU stand-in executes every launch at once)
+    def batch_begin(self, max_launches=0):
+        self._int_batch = None
+
+    def batch_begin_int(self, max_launches=0):
+        self._int_batch = []
+        self._int_max = max_launches or 16
+
+    def batch_end(self):
+        pass
+
+    def batch_read_int(self, k):
+        return self._int_batch[k].copy()
+
+    def _int_target(self):
+        """the INT array of the next launch: its own inside batch_begin_int, else the shared one"""
+        b = getattr(self, "_int_batch", None)
+        if b is None or not self.feat["with_int"]:
+            return self.T[1]
+        if len(b) >= self._int_max:
+            raise RuntimeError("soc_batch_end and soc_batch_read_int first")
+        b.append(np.zeros(self.cloud.CELLS, np.float32))
+        return b[-1]
+
     def bind_tally(self, which, ptr):
         raise NotImplementedError
 
@@ -117,7 +141,7 @@ class OracleEngine:
                gid_first=0, gid_count=None):
         job = self._roi(self._job(SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS, PS, XPS), SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
+        _, _, n = self.orc.sim(job, 0, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self._int_target(), nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     def set_hpbg(self, BG, HPBGP=None):
@@ -127,7 +151,7 @@ class OracleEngine:
         job = self._job(1, PACKETS, BATCH, SEED, 0.0, TW, GLOBAL)
         job.HPBG, job.HPBGP = self.HPBG, self.HPBGP
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 2, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
+        _, _, n = self.orc.sim(job, 2, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self._int_target(), nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     def sim_cl(self, SOURCE, PACKETS, BATCH, SEED, TW, GLOBAL, gid_first=0, gid_count=None):
@@ -135,7 +159,7 @@ class OracleEngine:
         job.WITH_ALI, job.XAB, job.EMINDEX = self.ali, self.T[2], self.EMINDEX
         self._roi(job, SOURCE)
         gid_count = GLOBAL - gid_first if gid_count is None else gid_count
-        _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self.T[1], nthreads=getattr(self, 'threads', 1))
+        _, _, n = self.orc.sim(job, 1, gid_first, gid_first + gid_count, TABS=self.T[0], INT=self._int_target(), nthreads=getattr(self, 'threads', 1))
         self.events += n
 
     # ---- temperature and emission ----

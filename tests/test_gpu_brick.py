@@ -418,3 +418,85 @@ def test_cell_emission_large_global_and_deferred(octree, engine, oracle_soc):
 def launch_fix(n):
     from soc_amd import launch
     return launch.Fix(n, 64)
+
+
+@pytest.mark.parametrize("octree", [False, True])
+def test_deferred_launches_with_int_tally(octree, engine, oracle_soc):
+    """soc_batch_begin_int: launches that keep the per-frequency INT tally share a sweep -- brick queues per launch, an
+    INT tally per launch, TABS shared; every INT equals the oracle's for that launch"""
+    cl = synth.octree_cloud(40, levels=3, frac=0.1, seed=3) if octree else synth.cartesian_cloud(40, seed=21)
+    d6, csc6 = synth.hg_scattering_table(0.6)
+    d0, csc0 = synth.hg_scattering_table(0.1)
+    G = 8 * cl.AREA
+    jobs = [Job(cl, csc6, ABS=2e-5, SCA=6e-5, SOURCE=1, BATCH=2, SEED=0.3711, BG=1.0, TW=1.0, WITH_INT=1),
+            Job(cl, csc0, ABS=5e-5, SCA=2e-5, SOURCE=1, BATCH=1, SEED=0.11, BG=2.5, TW=0.5, WITH_INT=1),
+            Job(cl, csc6, ABS=1e-5, SCA=9e-5, SOURCE=1, BATCH=2, SEED=0.77, BG=0.7, TW=2.0, WITH_INT=1)]
+    T = np.zeros(cl.CELLS, np.float32)
+    INT, n = [], 0
+    for j in jobs:
+        I = np.zeros(cl.CELLS, np.float32)
+        _, _, m = oracle_soc.sim(j, 0, TABS=T, INT=I, nthreads=8)
+        INT.append(I)
+        n += m
+    engine.set_cloud(cl)
+    engine.set_features(1, 0, 0)
+    engine.set_opt(None)
+    engine.set_mirror(0)
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.zero(1)
+    engine.stats(reset=True)
+    engine.batch_begin_int(3)
+    for j in jobs:
+        engine.set_scatter_table(j.DSC, j.CSC)
+        engine.set_optical(j.ABS, j.SCA)
+        engine.sim_pb(1, j.PACKETS, j.BATCH, j.SEED, j.BG, j.TW, GLOBAL=G)
+    from soc_amd.lib import SocError
+    with pytest.raises(SocError, match="read"):            # a fourth launch would have no INT slot to keep
+        engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=G)
+    engine.batch_end()
+    engine.sync()
+    assert engine.last_passes() > 0 and engine.stats()["tally_events"] == n
+    assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
+    for k in range(3):
+        assert_tally_close(engine.batch_read_int(k), INT[k], rtol=1e-5)
+    assert not engine.read_tally(1).any()                   # the shared INT tally was not touched
+    engine.set_features(0, 0, 0)
+
+
+def test_absorbed_file_run_with_int_batches(engine, tmp_path):
+    """asoc.py with an absorbed file (per-frequency INT tallies) on a Cartesian model: the frequencies of a source
+    block go through soc_batch_begin_int; file and tallies equal the oracle engine's run"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_host import _write_model
+    from oracle_engine import OracleEngine
+    from soc_amd import files
+    from soc_amd.asoc import AbsorptionRun
+    from soc_amd.ini import User
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(40, seed=5)
+    ini = _write_model(d, cloud, extra="gridlength 2e-6\nbgpackets 300000\n")
+    os.chdir(d)
+
+    class Threaded(OracleEngine):
+        threads = 8
+    Cw, Fw = AbsorptionRun(User(ini), Threaded("soc"), verbose=0).run()
+    want = files.read_absorbed(os.path.join(d, "abs.data")).copy()
+    passes = []
+    real = engine.batch_end
+
+    def spy():
+        real()
+        passes.append(engine.last_passes())
+    engine.batch_end = spy
+    try:
+        Cg, Fg = AbsorptionRun(User(ini), engine, verbose=0).run()
+    finally:
+        engine.batch_end = real
+    assert passes and max(passes) > 0, "the INT batches did not go through the brick sweep"
+    got = files.read_absorbed(os.path.join(d, "abs.data"))
+    assert_tally_close(Cg, Cw, rtol=1e-5)
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
+    engine.set_features(0, 0, 0)
