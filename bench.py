@@ -4,19 +4,30 @@
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input = the
-per-frequency body of the reference's simulation loop (ASOC.py:1120-1461) for the workload:
+One "step" = one pass of the hot path over one batch of synthetic input = one kernel launch of the
+reference's simulation loop (source block II x frequency IFREQ, ASOC.py:1028-1461) for the workload:
 
-  C2 (BASELINE.json configs[1]): 128^3 Cartesian cloud (lognormal density, seed 1234),
-  one frequency (tmp.dust row 33, 4.677e14 Hz, GL = 0.01 pc), `bgpackets 1e8` ->
-  GLOBAL = 8*AREA = 786432 work items x BATCH 127 = 99 876 864 packets of isotropic
-  background (ASOC.py:1061-1064), HG(g=0.6) scattering table with 2500 bins, noabsorbed.
+  C3 (default; BASELINE.json configs[2]): 256^3-root octree with 3 refinement levels
+  (LEVELS = 4; the densest 10 % of the cells of every level refined: 4.95e7 cells), GL = 0.02 pc, the
+  50-frequency optical table soc_amd/data/c3_dust50.txt (1.5e11 .. 2e15 Hz, log-log interpolation of the
+  reference's example dust; per-frequency ABS, SCA and a Henyey-Greenstein scattering table of the row's g),
+  `pspackets 1e9` from one point source at (128.3, 128.3, 128.3) (SimRAM_PB SOURCE 0, ASOC.py:1036-1044) and
+  `diffpack 1e9` of diffuse emission 1e-30 * density photons/Hz/cm3 (SimRAM_CL, ASOC.py:1086-1090), noabsorbed.
+  Step i simulates frequency (i // 2) % 50; even steps are the point-source launch, odd steps the diffuse one.
+  Launch size: the reference hard-codes GLOBAL_0 = 32768 work items for both (ASOC.py:86) -- 512 wavefronts,
+  half a wavefront per SIMD of an MI355X.  The ini key `global` (parsed by the reference, ASOC_aux.py:400)
+  sets GLOBAL_0 here; the bench uses --global work items (same packets, same sources, other partition into
+  RNG streams; identical to a reference run with that GLOBAL_0).  The rate at the reference's own launch
+  shape is measured beside it on a shortened launch (config.reference_launch_shape).
 
-Multi-GPU (weak scaling): every rank simulates the full launch with its own stream seed
--- the reference's vestigial DEVICES/ID seed term, ASOC.py:1247 -- and the per-cell
-absorption buffer is summed with ONE RCCL all-reduce per step (= per frequency).
-`--scaling strong` instead splits the work items of one logical launch across ranks
-(identical result to one GPU).
+  C2 (--workload C2; BASELINE.json configs[1]): 128^3 Cartesian cloud, one frequency, `bgpackets 1e8` ->
+  786432 work items x BATCH 127 of isotropic background, noabsorbed.
+
+The K steps are handed to the engine together (soc_batch_begin/end): launches of one kind share brick sweeps.
+
+Multi-GPU: --scaling strong (default for N > 1) splits the work items of every launch across the ranks
+(identical result to one GPU) with one RCCL all-reduce of the per-cell absorption buffer per
+sweep; --scaling weak runs one replica per rank with the reference's per-device seed term (ASOC.py:1247).
 
 Inputs are resident in HBM before the timed region.  Rank 0 prints one JSON line.
 """
@@ -31,7 +42,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from soc_amd import launch, synth           # noqa: E402
+from soc_amd import files, launch, synth    # noqa: E402
 from soc_amd.lib import Engine               # noqa: E402
 
 # tmp.dust row 33 (4.677e14 Hz) at gridlength 0.01 pc: optical depth per unit density per
@@ -40,28 +51,59 @@ C2_ABS, C2_SCA = 8.9084e-7, 5.4552e-6
 C2_FREQ = 4.677e14
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_TALLY_EVENT = 12                   # 4 B density read + 8 B tally read-modify-write
+C3_GL = 0.02                                 # pc
+C3_CELLS = 49526352                          # synth.octree_cloud(256, levels=4, frac=0.10, seed=1234); oracle/build.py ref "oct256"
+R_SUN, T_SUN = 6.957e10, 5800.0
 
 
 def c2_workload():
     cloud = synth.cartesian_cloud(128, seed=1234)
     dsc, csc = synth.hg_scattering_table(0.6, 2500)
     L = launch.bg_launch(100000000, cloud.AREA)
+    FF = [C2_FREQ * 0.9, C2_FREQ, C2_FREQ * 1.1]
+    step = dict(kind="bg", L=L, ABS=np.float32(C2_ABS), SCA=np.float32(C2_SCA), CSC=csc, DSC=dsc,
+                TW=np.float32(launch.trapezoid_weight(FF, 1)), BG=np.float32(1.0e-12 * L["WBG"] / C2_FREQ), IFREQ=0)
     return dict(name="C2: 128^3 Cartesian cloud, 1 frequency, bgpackets 1e8 (786432 work items x BATCH 127 = "
                      "99876864 packets), isotropic background, HG g=0.6 2500-bin scattering table, noabsorbed",
-                cloud=cloud, DSC=dsc, CSC=csc, ABS=C2_ABS, SCA=C2_SCA, launch=L, SEED=0.7853981634)
+                cloud=cloud, step=lambda i: step, SEED=0.7853981634, ref_tag="c128", kinds=("bg",))
 
 
-def c3_workload():
-    """BASELINE.json configs[2], the background part: 256^3-root octree with 3 refinement levels (the densest
-    10 % of the cells of every level refined: 4.95e7 cells, 4.54e7 leaves), `bgpackets 1e9` -> 3 145 728 work
-    items x BATCH 318, same dust row at GL = 0.005 pc (same optical depth across the model as C2)."""
+def c3_workload(GLOBAL_0):
     cloud = synth.octree_cloud(256, levels=4, frac=0.10, seed=1234)
-    dsc, csc = synth.hg_scattering_table(0.6, 2500)
-    L = launch.bg_launch(1000000000, cloud.AREA)
-    return dict(name="C3 (background part): 256^3-root octree, 4 levels (49.5e6 cells), 1 frequency per step, bgpackets 1e9 "
-                     "(%d work items x BATCH %d = %d packets), isotropic background, HG g=0.6 2500-bin scattering table, "
-                     "noabsorbed" % (L["GLOBAL"], L["BATCH"], L["GLOBAL"] * L["BATCH"]),
-                cloud=cloud, DSC=dsc, CSC=csc, ABS=0.5 * C2_ABS, SCA=0.5 * C2_SCA, launch=L, SEED=0.7853981634)
+    FFREQ, AFG, AFABS, AFSCA = files.read_dust([os.path.join(REPO, "soc_amd", "data", "c3_dust50.txt")], C3_GL)
+    NFREQ = len(FFREQ)
+    tables = [synth.hg_scattering_table(float(g), 2500) for g in AFG[0]]
+    LOCAL = launch.LOCAL_GPU
+    pc = launch.packet_counts(0, 1000000000, 0, 1000000000, cloud.AREA, cloud.CELLS, LOCAL, 0)     # ASOC.py:234-250
+    LPS = launch.ps_launch(pc["PSPAC"], 1, C3_GL, GLOBAL_0)
+    LCL = launch.cl_launch(pc["DFPAC"], cloud.CELLS, GLOBAL_0)
+    # point source: L_nu = 4 pi R^2 pi B_nu(5800 K) -> photons per package (ASOC.py:1236)
+    f64 = np.asarray(FFREQ, np.float64)
+    Bnu = 2.0 * launch.PLANCK * f64 ** 3 / launch.C_LIGHT ** 2 / np.expm1(np.clip(launch.H_K * f64 / T_SUN, 1e-10, 600.0))
+    Lnu = 4.0 * np.pi * R_SUN ** 2 * np.pi * Bnu
+    PS = np.asarray(Lnu * LPS["WPS"] / f64, np.float32)
+    PSPOS = np.asarray([[128.3, 128.3, 128.3]], np.float32)
+    # diffuse emission 1e-30 * density photons / Hz / cm3, flat spectrum -> photons per cell (ASOC.py:1262-1276)
+    EMIT = np.zeros(cloud.CELLS, np.float32)
+    for level in range(cloud.LEVELS):
+        a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+        d = cloud.DENS[a:b]
+        EMIT[a:b] = np.where(d > 0.0, 1.0e-30 * d, 0.0) * (C3_GL * launch.PARSEC / (8.0 ** level))
+
+    def step(i):
+        f = (i // 2) % NFREQ
+        kind = "ps" if (i % 2) == 0 else "cl"
+        dsc, csc = tables[f]
+        return dict(kind=kind, L=LPS if kind == "ps" else LCL, ABS=AFABS[0][f], SCA=AFSCA[0][f], CSC=csc, DSC=dsc,
+                    TW=np.float32(launch.trapezoid_weight(FFREQ, f)), BG=np.float32(0.0), IFREQ=f,
+                    PS=PS[f:f + 1], PSPOS=PSPOS, EMIT=EMIT)
+    name = ("C3: 256^3-root octree, LEVELS 4 (%d cells), GL 0.02 pc, 50 frequencies 1.5e11-2e15 Hz (own ABS, SCA, HG(g) "
+            "table each), noabsorbed; step i = frequency (i//2)%%50, even: point source at (128.3,128.3,128.3) pspackets 1e9 "
+            "= %d work items x BATCH %d = %d packets; odd: diffuse emission diffpack 1e9 = BATCH %d per cell = %d packets, "
+            "%d work items; GLOBAL_0 = %d via the ini key `global` (reference default 32768)"
+            % (cloud.CELLS, LPS["GLOBAL"], LPS["BATCH"], LPS["PACKETS"], LCL["BATCH"], LCL["BATCH"] * cloud.CELLS,
+               min(LCL["GLOBAL"], cloud.CELLS), GLOBAL_0))
+    return dict(name=name, cloud=cloud, step=step, SEED=0.7853981634, ref_tag="oct256", kinds=("ps", "cl"))
 
 
 def host_cores():
@@ -81,51 +123,66 @@ def host_cores():
 
 
 def cpu_baseline(work, budget_s=15.0):
-    """Time the reference's own kernel (x86 build of kernel_ASOC.c, oracle/_ref) -- or, where
-    that build is absent, the C restatement -- on an evenly strided sample of the work items
-    of the same launch, on all host cores available to this process."""
+    """Time the reference's own kernel (x86 build of kernel_ASOC.c, oracle/_ref) -- or, where that build is
+    absent, the C restatement -- on an evenly strided sample of the work items of the workload's launches
+    (C3: half the budget on the point-source launch, half on the diffuse one), on all host cores available."""
     from oracle.pyoracle import Job, Oracle, Ref
     ncores = host_cores()
-    L = work["launch"]
-    job = Job(work["cloud"], work["CSC"], ABS=work["ABS"], SCA=work["SCA"], SOURCE=1, BATCH=L["BATCH"],
-              SEED=launch.launch_seed(work["SEED"], 0), BG=1.0, TW=1.0, GLOBAL=L["GLOBAL"], DSC=work["DSC"])
+    cloud = work["cloud"]
     kind = "reference"
     try:
-        if work["cloud"].LEVELS > 1:
-            raise RuntimeError("reference builds bake the geometry in; only the C2 one is kept")
-        runner = Ref("c128")
-        run = lambda stride: runner.sim(job, 0, 0, L["GLOBAL"], nthreads=ncores, stride=stride)      # noqa: E731
+        runner = Ref(work["ref_tag"])
+        if runner.model["CELLS"] != cloud.CELLS:
+            raise RuntimeError("reference build %s is for another hierarchy" % work["ref_tag"])
     except Exception:
         kind = "port"
         runner = Oracle("libm")
-        run = lambda stride: runner.sim(job, 0, 0, L["GLOBAL"], nthreads=ncores, stride=stride)      # noqa: E731
-    # calibrate on 1/512 of the work items, then size the sample for ~budget_s
-    t0 = time.time()
-    run(512)
-    t_cal = max(time.time() - t0, 1e-3)
-    n_cal = (L["GLOBAL"] + 511) // 512
-    rate_items = n_cal / t_cal
-    stride = max(1, int(L["GLOBAL"] / max(rate_items * budget_s, 1)))
-    t0 = time.time()
-    run(stride)
-    dt = time.time() - t0
-    n_items = (L["GLOBAL"] + stride - 1) // stride
-    packets = n_items * L["BATCH"]
-    return dict(value=packets / dt, unit="packets/s", cores=ncores, kind=kind,
-                sample="every %d-th of the %d work items of the same launch (%d packets) in %.1f s; "
-                       "x86 build of the reference kernel_ASOC.c SimRAM_PB, %d threads"
-                       % (stride, L["GLOBAL"], packets, dt, ncores) if kind == "reference" else
-                       "every %d-th of the %d work items (%d packets) in %.1f s; C restatement, %d threads"
-                       % (stride, L["GLOBAL"], packets, dt, ncores))
+    packets, seconds, parts = 0, 0.0, []
+    for k, which in enumerate(work["kinds"]):
+        s = work["step"](k if len(work["kinds"]) > 1 else 0)
+        L = s["L"]
+        seed = launch.launch_seed(work["SEED"], s["IFREQ"])
+        if which == "cl":
+            job = Job(cloud, s["CSC"], ABS=s["ABS"], SCA=s["SCA"], SOURCE=2, BATCH=L["BATCH"], SEED=seed, TW=s["TW"],
+                      GLOBAL=L["GLOBAL"], DSC=s["DSC"], EMIT=s["EMIT"])
+            okind, nitems, per_item = 1, min(L["GLOBAL"], cloud.CELLS), L["BATCH"] * max(1.0, cloud.CELLS / L["GLOBAL"])
+        elif which == "ps":
+            job = Job(cloud, s["CSC"], ABS=s["ABS"], SCA=s["SCA"], SOURCE=0, BATCH=L["BATCH"], SEED=seed, BG=0.0, TW=s["TW"],
+                      GLOBAL=L["GLOBAL"], DSC=s["DSC"], PSPOS=s["PSPOS"], PS=s["PS"])
+            okind, nitems, per_item = 0, L["GLOBAL"], L["BATCH"]
+        else:
+            job = Job(cloud, s["CSC"], ABS=s["ABS"], SCA=s["SCA"], SOURCE=1, BATCH=L["BATCH"], SEED=seed, BG=1.0, TW=1.0,
+                      GLOBAL=L["GLOBAL"], DSC=s["DSC"])
+            okind, nitems, per_item = 0, L["GLOBAL"], L["BATCH"]
+        run = lambda stride: runner.sim(job, okind, 0, nitems, nthreads=ncores, stride=stride)      # noqa: E731
+        # calibrate on a thin sample of the work items, then size the sample for its share of the budget
+        cal = max(512, nitems // (64 * ncores))
+        t0 = time.time()
+        run(cal)
+        t_cal = max(time.time() - t0, 1e-3)
+        rate_items = ((nitems + cal - 1) // cal) / t_cal
+        stride = max(1, int(nitems / max(rate_items * budget_s / len(work["kinds"]), 1)))
+        t0 = time.time()
+        run(stride)
+        dt = time.time() - t0
+        n_items = (nitems + stride - 1) // stride
+        packets += n_items * per_item
+        seconds += dt
+        parts.append("%s: every %d-th of %d work items (%d packets) in %.1f s" % (which, stride, nitems, n_items * per_item, dt))
+    what = "x86 build of the reference kernel_ASOC.c (SimRAM_PB / SimRAM_CL)" if kind == "reference" else "C restatement"
+    return dict(value=packets / seconds, unit="packets/s", cores=ncores, kind=kind,
+                sample="; ".join(parts) + "; %s, %d threads" % (what, ncores))
 
 
-def measured_traffic():
+def measured_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed
     under profiles/ (collected separately, as the profiling guide prescribes)."""
     p = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
+            t = json.load(open(p))
+            t = t.get(workload, t) if isinstance(t.get(workload), dict) else (t if workload == "C2" else {})
+            return t.get("hbm_bytes_per_launch")
         except Exception:
             return None
     return None
@@ -134,17 +191,20 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=["weak", "strong", "auto"], default="auto",
+                    help="auto = strong for N > 1 (work-item ranges of every launch), weak = replicas with per-rank seeds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-reference-shape", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=16.0)
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="steps executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
-                         "0 = the K steps in equal sweeps of at most 16 (on Cartesian grids 2.7e6 packets are in "
-                         "flight, the next launches' work items are admitted as the first finish)")
-    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
-                    help="C2 = BASELINE.json configs[1] (the headline); C3 = the background part of configs[2]")
+                    help="launches executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
+                         "0 = the launches of one kind in equal sweeps of at most 16")
+    ap.add_argument("--workload", choices=["C2", "C3"], default="C3",
+                    help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]")
+    ap.add_argument("--global", dest="global0", type=int, default=4194304,
+                    help="C3: GLOBAL_0, work items of the point-source and diffuse launches (ini key `global`; reference: 32768)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +214,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.scaling == "auto":
+        args.scaling = "strong" if world > 1 else "weak"
 
     dist = None
     torch = None
@@ -171,72 +233,89 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    work = c3_workload() if args.workload == "C3" else c2_workload()
-    if args.in_flight == 0:
-        # sweeps of equal size, at most 16 launches each (K = 20 -> 10 + 10 rather than 16 + 4)
-        args.in_flight = max(1, -(-args.steps // -(-args.steps // 16))) if args.steps > 0 else 16
-    cloud, L = work["cloud"], work["launch"]
+    work = c3_workload(args.global0) if args.workload == "C3" else c2_workload()
+    cloud = work["cloud"]
     eng = Engine(local_rank)
     eng.set_cloud(cloud)
     eng.set_features(with_int=0, ps_method=0, use_emweight=0)      # noabsorbed: TABS only
-    eng.set_scatter_table(work["DSC"], work["CSC"])
-    eng.set_optical(work["ABS"], work["SCA"])
 
     tabs = None
+    stream = None
     if world > 1:
-        # tally lives in a torch tensor so RCCL reduces it in place; kernels run on torch's stream
+        # the tally lives in a torch tensor so RCCL reduces it in place; the kernels run on a torch stream that is
+        # made current, so the collective is ordered behind them (and the next sweep behind the collective)
         tabs = torch.zeros(cloud.CELLS, dtype=torch.float32, device="cuda")
         eng.bind_tally(0, tabs.data_ptr())
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        if not os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU"):
+            stream = torch.cuda.Stream()
+            torch.cuda.set_stream(stream)
+            eng.set_stream(stream.cuda_stream)
     eng.zero(0)
 
-    FFREQ = [C2_FREQ * 0.9, C2_FREQ, C2_FREQ * 1.1]
-    TW = np.float32(launch.trapezoid_weight(FFREQ, 1))
-    KDEV = 1.0 / world if args.scaling == "weak" else 1.0            # ASOC.py:180,1501
-    BG = np.float32(1.0e-12 * L["WBG"] / C2_FREQ * KDEV)             # I_bg = 1e-12 cgs (ASOC.py:1194)
-    if args.scaling == "weak":
-        first, count = 0, L["GLOBAL"]
-    else:
-        first, count = launch.shard_range(L["GLOBAL"], rank, world)
+    weak = args.scaling == "weak"
+    KDEV = 1.0 / world if weak else 1.0                              # ASOC.py:180,1501
 
-    def steps(i0, n):
-        """n steps = n launches of the workload with the seeds of (frequency i, device): the per-frequency
-        body of the reference's loop.  They are handed to the engine together (deferred launches), which
-        runs up to --in-flight of them per brick sweep; then one all-reduce of TABS."""
-        dev_id = rank if args.scaling == "weak" else 0
-        ndev = world if args.scaling == "weak" else 1
+    def run_steps(i0, n, in_flight):
+        """Steps i0 .. i0+n-1, grouped by kind; every group in sweeps of at most `in_flight` launches; one all-reduce
+        of TABS per sweep when several ranks share the launches.  Returns the HIP-event time of the kernels [ms]."""
+        dev_id, ndev = (rank, world) if weak else (0, 1)
         eng.timer_start()
-        eng.batch_begin(args.in_flight)
-        for i in range(i0, i0 + n):
-            seed = launch.launch_seed(work["SEED"], i, DEVICES=ndev, ID=dev_id)
-            eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, BG, TW, GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-        eng.batch_end()
-        ms = eng.timer_stop()
-        if world > 1:
-            dist.all_reduce(tabs)
-        return ms
+        for kind in work["kinds"]:
+            todo = [i for i in range(i0, i0 + n) if work["step"](i)["kind"] == kind]
+            if not todo:
+                continue
+            nsw = -(-len(todo) // 16) if in_flight == 0 else -(-len(todo) // in_flight)
+            per = -(-len(todo) // nsw)
+            for a in range(0, len(todo), per):
+                eng.batch_begin(min(16, per))
+                for i in todo[a:a + per]:
+                    s = work["step"](i)
+                    L = s["L"]
+                    first, count = (0, L["GLOBAL"]) if weak else launch.shard_range(L["GLOBAL"], rank, world)
+                    seed = launch.launch_seed(work["SEED"], s["IFREQ"], DEVICES=ndev, ID=dev_id)
+                    eng.set_optical(s["ABS"], s["SCA"])
+                    eng.set_scatter_table(s["DSC"], s["CSC"])
+                    if kind == "cl":
+                        eng.sim_cl(2, L["PACKETS"], L["BATCH"], seed, np.float32(s["TW"] * KDEV), L["GLOBAL"], gid_first=first, gid_count=count)
+                    elif kind == "ps":
+                        eng.sim_pb(0, L["PACKETS"], L["BATCH"], seed, 0.0, s["TW"], PSPOS=s["PSPOS"], PS=s["PS"] * np.float32(KDEV),
+                                   GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+                    else:
+                        eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, np.float32(s["BG"] * KDEV), s["TW"],
+                                   GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+                eng.batch_end()
+                if world > 1:
+                    if stream is None:
+                        eng.sync()
+                    dist.all_reduce(tabs)
+        return eng.timer_stop()
 
     def fence():
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
         else:
             eng.sync()
 
+    if "cl" in work["kinds"]:
+        eng.set_emission(work["step"](1)["EMIT"], None)           # resident before the timed region (same for every frequency)
     if args.warmup:
-        steps(0, args.warmup)
+        run_steps(0, args.warmup, args.in_flight)
     eng.stats(reset=True)
     fence()
     t0 = time.perf_counter()
-    kernel_ms = [steps(args.warmup, args.steps) / max(args.steps, 1)]      # HIP-event span of all K steps / K
+    kernel_ms = run_steps(args.warmup, args.steps, args.in_flight)
     fence()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
+    passes = eng.last_passes()
 
     packets_rank = st["packets"]
     events_rank = st["tally_events"]
     if world > 1:
-        t = torch.tensor([elapsed, float(packets_rank), float(events_rank)], dtype=torch.float64, device="cuda")
+        dev = "cpu" if os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU") else "cuda"
+        t = torch.tensor([elapsed, float(packets_rank), float(events_rank)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -245,14 +324,31 @@ def main():
     else:
         packets_total = packets_rank
 
-    passes = eng.last_passes()
-    kernel_name = ("soc_brick_pass<scalar-opacity,TABS-only> (+ soc_brick_scan, soc_brick_scatter), %d passes in the last "
-                   "sweep of up to %d steps: time is the HIP-event span of all kernels of the K steps / K" % (passes, args.in_flight)) if passes else \
-        "soc_sim_pb_kernel<Cartesian,float,scalar-opacity,TABS-only>"
+    # the reference's own launch shape (GLOBAL_0 = 32768), shortened: BATCH cut so that it takes about a second
+    ref_shape = None
+    if rank == 0 and world == 1 and args.workload == "C3" and not args.no_reference_shape:
+        try:
+            s = work["step"](0)
+            L = launch.ps_launch(32768 * 2000, 1, C3_GL, launch.GLOBAL_0)
+            eng.stats(reset=True)
+            eng.set_optical(s["ABS"], s["SCA"])
+            eng.set_scatter_table(s["DSC"], s["CSC"])
+            eng.timer_start()
+            eng.sim_pb(0, L["PACKETS"], L["BATCH"], launch.launch_seed(work["SEED"], 0), 0.0, s["TW"], PSPOS=s["PSPOS"], PS=s["PS"], GLOBAL=L["GLOBAL"])
+            ms = eng.timer_stop()
+            ref_shape = {"packets_per_s": eng.stats()["packets"] / ms * 1e3,
+                         "what": "point-source launch with the reference's GLOBAL_0 = 32768 work items, BATCH cut from 30517 to %d "
+                                 "(one launch, not deferred)" % L["BATCH"]}
+        except Exception as e:
+            ref_shape = {"packets_per_s": None, "what": "failed: %s" % e}
+
     if rank == 0:
-        kavg_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
+        kavg_s = kernel_ms * 1e-3 / max(args.steps, 1)
         alg_bytes = events_rank / max(args.steps, 1) * BYTES_PER_TALLY_EVENT
         achieved = alg_bytes / kavg_s / 1e9
+        kernel_name = ("soc_brick_pass<%s,scalar-opacity,TABS-only> (+ soc_brick_scan, soc_brick_scatter), %d passes in the last sweep: "
+                       "time is the HIP-event span of all kernels of the K steps / K"
+                       % ("octree,double-Index" if cloud.LEVELS > 1 else "Cartesian", passes)) if passes else "soc_sim_pb_kernel / soc_sim_cl_kernel (direct)"
         out = {
             "metric": "photon packets/sec",
             "value": packets_total / elapsed,
@@ -268,16 +364,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": work["name"], "packets_per_step_per_gpu": packets_rank // max(args.steps, 1),
                        "cells": cloud.CELLS, "tally_events_per_packet": events_rank / max(packets_rank, 1),
-                       "steps_in_flight": args.in_flight,
+                       "launches_per_sweep": args.in_flight if args.in_flight else "the launches of one kind, at most 16",
                        "parallelism": "1 process per GPU; %s" % (
-                           "replicas with per-rank seeds + 1 RCCL all-reduce of TABS after the K steps (TABS integrates over frequency on the device)" if args.scaling == "weak"
-                           else "work-item ranges of one launch + 1 RCCL all-reduce of TABS after the K steps")},
+                           "replicas with per-rank seeds, weight 1/N + 1 RCCL all-reduce of TABS per sweep" if weak
+                           else "work-item ranges of every launch + 1 RCCL all-reduce of TABS per sweep (TABS integrates over frequency on the device)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic() if args.workload == "C2" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
                          "kernel": kernel_name,
                          "kernel_ms": kavg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if ref_shape is not None:
+            out["config"]["reference_launch_shape"] = ref_shape
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(work, args.cpu_budget)

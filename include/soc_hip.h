@@ -71,6 +71,14 @@ int soc_set_mirror(soc_ctx *ctx, int mask);
  *           otherwise (reflecting faces, region-of-interest records, SOURCE 3)                     */
 int soc_set_exec(soc_ctx *ctx, int mode, int brick_log2);
 
+/* Shape of the brick sweep (no counterpart in the reference; results are the same packets whatever the values).
+ * value 0 = the built-in choice for the grid.  Names: "threads" (workgroup size of the walk, 64..512), "chunk" (packets
+ * per workgroup, <= 4096), "steps_per_visit" (cell steps before a packet goes back to its queue), "swap_lanes" /
+ * "climb_lanes" (lanes of a wave that must wait before the packet swap / the deferred Index() runs), "brick_cells"
+ * (cells per brick on hierarchies, <= 16384), "tail_lanes", "population" (packets in flight), "hash_slots" (per-workgroup
+ * arrival table, power of two), "general_kernel" (1: no background-only kernel), "oversubscribe", "verbose". */
+int soc_set_tuning(soc_ctx *ctx, const char *name, int value);
+
 /* replaces the per-frequency uploads of ABS, SCA (ASOC.py:1171-1175); ndust must be 1
  * (the host sums the species, ASOC.py:1166-1170) */
 int soc_set_optical(soc_ctx *ctx, const float *ABS, const float *SCA, int ndust);

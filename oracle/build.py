@@ -280,6 +280,9 @@ def ref_models():
     for k in (1, 2, 4, 5):
         m["c8ps%d" % k] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=k, NO_PS=2)
     m["c8ps0"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=0, NO_PS=2)
+    # config 3 of BASELINE.json (bench.py's cpu_baseline): synth.octree_cloud(256, levels=4, frac=0.10, seed=1234);
+    # the cell count is written out (the cloud takes a second and 400 MB to generate) and checked by bench.py
+    m["oct256"] = dict(NX=256, NY=256, NZ=256, LEVELS=4, CELLS=49526352, GL=0.02)
     return m
 
 

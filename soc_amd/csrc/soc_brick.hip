@@ -1071,7 +1071,7 @@ struct OctBuilder {
 };
 }  // namespace
 
-static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream_t st)
+static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream_t st, bool verbose)
 {
     SocOctBricks &ob = g_ob[device];
     if (ob.valid && ob.CAP == CAP && ob.cells == (size_t)G.CELLS && ob.dens_key == G.DENS) return hipSuccess;
@@ -1092,7 +1092,7 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
     BCHK(hipMemcpy(ob.bbase, B.bbase.data(), B.bbase.size() * 4, hipMemcpyHostToDevice));
     ob.NB = NB;  ob.CAP = CAP;  ob.cells = (size_t)G.CELLS;  ob.leaves = B.bcell.size();  ob.dens_key = G.DENS;
     ob.valid = true;
-    if (getenv("SOC_BRICK_VERBOSE"))
+    if (verbose)
         fprintf(stderr, "soc_brick: hierarchy of %d cells, %zu leaves -> %d bricks of <= %d leaves (mean %.0f)\n",
                 G.CELLS, ob.leaves, NB, CAP, (double)ob.leaves / NB);
     return hipSuccess;
@@ -1142,33 +1142,33 @@ static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t
 }
 
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
-                            int population, hipStream_t st, int *passes_out)
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out)
 {
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
     A.LB = LB;
     A.ev_brick = -1;
-    // workgroup shape; overridable for experiments (measured on C2)
+    // workgroup shape; soc_set_tuning overrides (measured on C2 and on the 256^3-root hierarchy)
     A.T = 512;
     A.P = (V.octree ? 8 : 4) * A.T;                  // hierarchies: one chunk per brick queue (measured)
     A.KCAP = V.octree ? 32 : 48;                     // measured on C2 / on the 256^3-root hierarchy
     A.FTH = V.octree ? 16 : 24;
     A.CAP = 6144;                                    // with P = 4096: 48 KB of LDS, three workgroups per CU (measured)
     A.TAIL = 0;
-    if (const char *e = getenv("SOC_BRICK_TAIL")) A.TAIL = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_T")) A.T = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_P")) A.P = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_KCAP")) A.KCAP = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_FTH")) A.FTH = atoi(e);
+    if (tune.TAIL > 0) A.TAIL = tune.TAIL;
+    if (tune.T > 0)    A.T = tune.T;
+    if (tune.P > 0)    A.P = tune.P;
+    if (tune.KCAP > 0) A.KCAP = tune.KCAP;
+    if (tune.FTH > 0)  A.FTH = tune.FTH;
     A.CTH = A.FTH;
-    if (const char *e = getenv("SOC_BRICK_CTH")) A.CTH = atoi(e);
-    if (const char *e = getenv("SOC_BRICK_CAP")) A.CAP = atoi(e);
+    if (tune.CTH > 0)  A.CTH = tune.CTH;
+    if (tune.CAP > 0)  A.CAP = tune.CAP;
     if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
     if (A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS)) return hipErrorInvalidValue;
     if (V.octree) {
         if (G.LEVELS > 15) return hipErrorNotSupported;                  // the level shares a packet word with slot and launch
-        BCHK(soc_oct_build(device, G, A.CAP, st));
+        BCHK(soc_oct_build(device, G, A.CAP, st, tune.verbose != 0));
         const SocOctBricks &ob = g_ob[device];
         A.NBX = A.NBY = A.NBZ = 0;
         A.NB = ob.NB;
@@ -1188,7 +1188,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         const SocSim &S = Sin[l];
         if (S.BATCH >= (1 << 24)) return hipErrorNotSupported;       // III shares a word with the scattering count
         uint32_t c = S.gid_count;
-        if ((S.SOURCE == 1 || S.SOURCE == SOC_SOURCE_HP) && !getenv("SOC_EXPERIMENT_OVERSUB")) {
+        if ((S.SOURCE == 1 || S.SOURCE == SOC_SOURCE_HP) && !tune.oversub) {
             const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
             if ((long long)S.gid0 >= lim) c = 0;
             else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);
@@ -1229,12 +1229,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         const long long p = V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
         population = (int)std::min(p, 2000000000LL);
     }
-    if (const char *e = getenv("SOC_BRICK_POP")) population = atoi(e);
+    if (tune.POP > 0) population = tune.POP;
     A.target = (population > 0 && (uint32_t)population < count) ? population : (int)count;
     const uint32_t live = (uint32_t)A.target;
     const int maxdesc = (int)((live + A.P - 1) / A.P) + NQ + K.n;
     A.HS = (NQ > 4096) ? 1024 : 0;
-    if (const char *e = getenv("SOC_BRICK_HS")) A.HS = atoi(e);
+    if (tune.HS > 0) A.HS = tune.HS;
     if (A.HS & (A.HS - 1)) return hipErrorInvalidValue;
 
     SocBrickBuffers &bb = g_bb[device];
@@ -1280,7 +1280,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (kl != kind) return hipErrorInvalidValue;                  // one kind per sweep (soc_capi.hip sees to it)
         all_bg = all_bg && (K.S[l].SOURCE == 1);
     }
-    if (all_bg && !getenv("SOC_BRICK_NOLEAN")) kind = 3;               // background packets only: the lean kernel
+    if (all_bg && !tune.nolean) kind = 3;               // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((live + A.P - 1) / A.P) + 3 * K.n) * slices;
 

@@ -80,6 +80,7 @@ struct soc_ctx {
     int with_int = 0, ps_method = 0, use_emweight = 0, mirror = 0;
     // execution
     int exec_mode = -1, brick_log2 = 4, last_passes = 0;
+    SocBrickTune tune{};
     // equilibrium temperature / emission (soc_emit.hip)
     float *dT = nullptr, *dTTT = nullptr, *dEbuf = nullptr, *dEF = nullptr;
     int    ttt_cap = 0, ef_cap = 0;
@@ -158,7 +159,7 @@ static int flush_pending(soc_ctx *c)
         return SOC_OK;
     }
     // packets in flight: chosen by the sweep from the number of bricks (-1)
-    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->stream, &c->last_passes);
+    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
     if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
     return SOC_OK;
 }
@@ -343,6 +344,24 @@ int soc_set_exec(soc_ctx *c, int mode, int brick_log2)
     c->exec_mode = mode;
     c->brick_log2 = brick_log2;
     return SOC_OK;
+}
+
+int soc_set_tuning(soc_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (value < 0) return fail(c, SOC_ERR_ARG, "soc_set_tuning: %s = %d (0 = built-in choice)", name, value);
+    struct { const char *n; int *p; } tab[] = {
+        { "threads", &c->tune.T }, { "chunk", &c->tune.P }, { "steps_per_visit", &c->tune.KCAP }, { "swap_lanes", &c->tune.FTH },
+        { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "population", &c->tune.POP },
+        { "hash_slots", &c->tune.HS }, { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
+    for (auto &t : tab)
+        if (!strcmp(name, t.n)) {
+            if (t.p == &c->tune.CAP && value != c->tune.CAP) soc_brick_invalidate(c->device);
+            *t.p = value;
+            return SOC_OK;
+        }
+    return fail(c, SOC_ERR_ARG, "soc_set_tuning: unknown parameter '%s'", name);
 }
 
 int soc_last_passes(soc_ctx *c) { return c ? c->last_passes : 0; }
@@ -684,7 +703,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -920,7 +939,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -985,7 +1004,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }

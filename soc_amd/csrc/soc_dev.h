@@ -145,11 +145,20 @@ struct SocEqTArgs {
 hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st);
 hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
 
+// Shape of the brick sweep; 0 = the built-in choice for the grid (measured).  Set per context with
+// soc_set_tuning (include/soc_hip.h); the parity tests use small CAP / HS values to exercise brick boundaries.
+struct SocBrickTune {
+    int T, P, KCAP, FTH, CTH, CAP, TAIL, POP, HS;
+    int nolean;                // keep the general SimRAM_PB kernel for background-only sweeps
+    int oversub;               // experiment: background work items beyond 8*AREA are not clipped
+    int verbose;
+};
+
 // brick-sweep execution (soc_brick.hip): LDS-resident tallies, packets sorted by brick
 // population: packets in flight (0 = all work items at once, -1 = chosen from the number of bricks): the other work
 // items are admitted as earlier ones finish
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *S, int nlaunch, const SocVariant &V, int LB,
-                            int population, hipStream_t st, int *passes_out);
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out);
 void soc_brick_release(int device);
 void soc_brick_invalidate(int device);      // the grid changed: bricks of a hierarchy are rebuilt at the next sweep
 

@@ -29,6 +29,7 @@ API = {
     "soc_set_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _I, _F]),
     "soc_set_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "soc_set_exec": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "soc_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "soc_last_passes": (C.c_int, [C.c_void_p]),
     "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
     "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
@@ -202,6 +203,12 @@ class Engine:
     def set_exec(self, mode=-1, brick_log2=4):
         """0 direct kernel, 1 brick sweep (LDS tallies), -1 automatic."""
         self._chk(self.lib.soc_set_exec(self.h, int(mode), int(brick_log2)))
+
+    def set_tuning(self, **params):
+        """shape of the brick sweep (soc_set_tuning): threads, chunk, steps_per_visit, swap_lanes, climb_lanes,
+        brick_cells, tail_lanes, population, hash_slots, general_kernel, oversubscribe, verbose; 0 = built-in"""
+        for k, v in params.items():
+            self._chk(self.lib.soc_set_tuning(self.h, k.encode(), int(v)))
 
     def last_passes(self):
         return int(self.lib.soc_last_passes(self.h))

@@ -31,3 +31,15 @@ def engine():
     eng = Engine(0)
     yield eng
     eng.close()
+
+
+@pytest.fixture
+def tuned(engine):
+    """Set brick-sweep shape parameters (Engine.set_tuning) for one test; the built-in choices come back afterwards."""
+    used = set()
+
+    def set_(**kw):
+        used.update(kw)
+        engine.set_tuning(**kw)
+    yield set_
+    engine.set_tuning(**{k: 0 for k in used})

@@ -46,12 +46,11 @@ def test_brick_sweep_c32_and_sharding(lb, engine, oracle_soc):
 
 @pytest.mark.parametrize("name", ["bg_oct8", "bg_oct4"])
 @pytest.mark.parametrize("cap,hs", [(8, 0), (100, 0), (8192, 0), (100, 64), (8, 8)])
-def test_brick_sweep_octree_matches_oracle(name, cap, hs, engine, oracle_soc, monkeypatch):
+def test_brick_sweep_octree_matches_oracle(name, cap, hs, engine, oracle_soc, tuned):
     """hierarchies: bricks of <= cap leaves (cap 8 splits the subtree of a refined root cell of the
     known-answer tree), tally slots from the cell -> slot map; hs: hash-table form of the arrival counts
     (8 entries: overflows into the direct global count)"""
-    monkeypatch.setenv("SOC_BRICK_CAP", str(cap))
-    monkeypatch.setenv("SOC_BRICK_HS", str(hs))
+    tuned(brick_cells=cap, hash_slots=hs)
     ref, kind, mk = cases.CASES[name]
     job = mk()
     T, I, n = oracle_soc.sim(job, kind)
@@ -62,9 +61,9 @@ def test_brick_sweep_octree_matches_oracle(name, cap, hs, engine, oracle_soc, mo
     engine.set_exec(-1, 4)
 
 
-def test_brick_sweep_octree_abu_int_point_sources(engine, oracle_soc, monkeypatch):
+def test_brick_sweep_octree_abu_int_point_sources(engine, oracle_soc, tuned):
     """per-cell opacities, INT tally and point sources (inside and outside) on a hierarchy"""
-    monkeypatch.setenv("SOC_BRICK_CAP", "200")
+    tuned(brick_cells=200)
     oct8 = cases._oct8()
     job = Job(oct8, cases._CSC, SOURCE=0, BATCH=25, SEED=0.2, GLOBAL=512, PSPOS=cases._PS_EXT, PS=[1.0, 2.0], PS_METHOD=0,
               XPS=cases._XPS2, OPT=cases._opt(oct8.CELLS), WITH_INT=1, TW=1.5)
@@ -284,10 +283,10 @@ def _clustered_hierarchy(NX, NY, NZ, levels, seed=2):
 
 
 @pytest.mark.parametrize("cap", [8, 40, 700])
-def test_brick_sweep_on_a_clustered_rectangular_hierarchy(cap, engine, oracle_soc, monkeypatch):
+def test_brick_sweep_on_a_clustered_rectangular_hierarchy(cap, engine, oracle_soc, tuned):
     """brick builder: root grid not a multiple of the 16-cell cube, subtrees far above the cap (split level by
     level), bricks spanning several cubes"""
-    monkeypatch.setenv("SOC_BRICK_CAP", str(cap))
+    tuned(brick_cells=cap)
     cl = _clustered_hierarchy(19, 7, 5, 4)
     assert cl.LEVELS == 4 and cl.LCELLS[2] == 1728 and cl.LCELLS[3] == 1728
     job = Job(cl, cases._CSC, ABS=2e-5, SCA=6e-5, SOURCE=1, BATCH=3, SEED=0.3711)
@@ -303,10 +302,10 @@ HP = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 2 and "
 
 
 @pytest.mark.parametrize("name", HP)
-def test_brick_sweep_healpix_background(name, engine, oracle_soc, monkeypatch):
+def test_brick_sweep_healpix_background(name, engine, oracle_soc, tuned):
     """SimRAM_HP through the brick sweep: the walk is SimRAM_PB's, the event workgroups create the packets from the
     Healpix sky (uniform and weighted pixel selection, Cartesian and hierarchy, with the INT tally)"""
-    monkeypatch.setenv("SOC_BRICK_CAP", "300")
+    tuned(brick_cells=300)
     ref, kind, mk = cases.CASES[name]
     job = mk()
     T, I, n = oracle_soc.sim(job, kind)
@@ -361,10 +360,10 @@ CLB = [n for n, (ref, kind, mk) in sorted(cases.CASES.items())
 
 
 @pytest.mark.parametrize("name", CLB)
-def test_brick_sweep_cell_emission(name, engine, oracle_soc, monkeypatch):
+def test_brick_sweep_cell_emission(name, engine, oracle_soc, tuned):
     """SimRAM_CL through the brick sweep: the event workgroups step through the work item's cells (EMWEIGHT 0 and 1),
     no nudge after a failed step, packets dropped before the deposit of the 21st scattering"""
-    monkeypatch.setenv("SOC_BRICK_CAP", "300")
+    tuned(brick_cells=300)
     ref, kind, mk = cases.CASES[name]
     job = mk()
     T, I, n = oracle_soc.sim(job, kind)
