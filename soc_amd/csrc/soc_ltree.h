@@ -1,0 +1,172 @@
+// soc_ltree.h -- neighbour search on a brick-local copy of the hierarchy: Index() (kernel_ASOC_aux.c:198-278) for
+// runs that evaluate it in double (NX > DIMLIM), without parent links and without fp64.
+//
+// The reference keeps a packet's place as (level, ind, pos): pos is local to the octet of the cell, in [0,2]^3 plus
+// a small overstep.  After a step Index() climbs -- POS = POS/2 + octant, through PAR -- until POS lies inside an
+// octet (or the root grid), takes the cell there and descends with POS = 2*fmod(POS,1) to a leaf; the result is
+// rounded to float once, at the end.  With double3 POS every one of those operations is exact as long as no
+// coordinate is tiny (below 2^(k+L-30) for a root grid of < 2^k cells and a cell of level L), so what Index()
+// returns is
+//     the leaf that contains the point, and  pos' = RN_float(pos * 2^(l-L) + B)
+// with l the leaf's level and B the (dyadic, exactly representable) distance between the two octet origins in
+// units of the new level.  That is what soc_lt_step() computes, from integers:
+//   * the packet carries the integer coordinates (cx, cy, cz) of its cell on the cell's own level instead of ind;
+//   * the cell that holds the point has coordinates t = (c & ~1) + floor(pos) on level L, its ancestors t >> j;
+//   * the brick's cells sit in LDS (`tree`: a leaf holds its density, a refined cell the link to the slots of its
+//     eight children, as in the cloud file but with brick-local slots), root cells of the brick's box first, so the
+//     leaf is found by a descent through at most LEVELS reads of LDS;
+//   * one fused multiply-add gives pos'.
+// Cases in which the reference's own arithmetic is not the exact one -- a coordinate exactly on a cell face (the
+// inclusive tests of :264 pick a cell by rule, not by geometry) or tiny -- are recognised (soc_lt_degenerate) and
+// left to soc_index<double> itself (the "slow step" queue of the brick sweep).
+//
+// Shared by the device walk (soc_brick.hip) and the host (tests/ltree_host.cpp follows rays through bricks built
+// by soc_lbricks.h and is compared with the oracle's Index step by step).
+#ifndef SOC_LTREE_H
+#define SOC_LTREE_H
+
+#include "soc_math.h"
+
+struct SocLBrick {
+    int x0, y0, z0;            // first root cell of the box
+    int bx, by, bz;            // root cells per edge
+    int base, nslot;           // first entry in btree / bcell, cells (leaves and refined cells) of the brick
+};
+
+enum { SOC_LT_INSIDE = 0, SOC_LT_LEAVE = 1, SOC_LT_EXIT = 2, SOC_LT_SLOW = 3 };
+
+SOC_HD int soc_lt_link(float d) { return (int)(soc_f2u(d) ^ 0x80000000u); }
+
+// exact 2^k for -126 <= k <= 127
+SOC_HD float soc_lt_pow2(int k) { return soc_u2f((uint32_t)(127 + k) << 23); }
+
+// Is the step one that Index() (double) would not resolve by exact geometry?  level > 0, pos after the step.
+// thr = 2^(k + level - 30): below it pos/2^level + root coordinate has more than 53 significant bits.
+SOC_HD bool soc_lt_degenerate(float px, float py, float pz, float flx, float fly, float flz, float thr)
+{
+    const float m = soc_fminf(soc_fabsf(px), soc_fminf(soc_fabsf(py), soc_fabsf(pz)));
+    return !(m >= thr) || (px == flx) || (py == fly) || (pz == flz);
+}
+
+// The brick's slot of the cell with integer coordinates (tx, ty, tz) on level L -- or of the leaf above it, if the
+// hierarchy ends earlier: descent from the root cell of the box.  Returns false (and the root cell of the point in
+// R) when that root cell lies outside the box of this brick.
+template <typename TREE>
+SOC_HD bool soc_lt_descend(const TREE tree, const SocLBrick &K, const int L, const int tx, const int ty, const int tz,
+                           int &s, float &rec, int &l, int &Rx, int &Ry, int &Rz)
+{
+    Rx = tx >> L;  Ry = ty >> L;  Rz = tz >> L;
+    const int rx = Rx - K.x0, ry = Ry - K.y0, rz = Rz - K.z0;
+    if (((unsigned)rx >= (unsigned)K.bx) | ((unsigned)ry >= (unsigned)K.by) | ((unsigned)rz >= (unsigned)K.bz)) return false;
+    s = (rz * K.by + ry) * K.bx + rx;
+    rec = tree[s];
+    l = 0;
+    while (!(rec > 0.0f) && (l < L)) {                       // the ancestors of t, from the root cell down
+        l++;
+        const int sh = L - l;
+        s = soc_lt_link(rec) + (((tx >> sh) & 1) | (((ty >> sh) & 1) << 1) | (((tz >> sh) & 1) << 2));
+        rec = tree[s];
+    }
+    return true;
+}
+
+// A packet of level L (cell c, pos local to c's octet) whose point lies in the level-L cell t has been traced down
+// to slot s (record rec) on level l <= L.  Go on to the leaf if t itself is refined -- octants from the position
+// inside t, as Index() does with 2*fmod(POS,1), exactly -- and re-express pos in the leaf's octet:
+//     pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)),   O = octet origin on the cell's level (0 on the root grid).
+template <typename TREE>
+SOC_HD void soc_lt_settle(const TREE tree, const int tx, const int ty, const int tz, int s, float rec, int l,
+                          float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens)
+{
+    const int L = level;
+    int nx = tx >> (L - l), ny = ty >> (L - l), nz = tz >> (L - l);          // the cell found so far, on its level l
+    if (!(rec > 0.0f)) {
+        float fx = px - soc_floorf(px), fy = py - soc_floorf(py), fz = pz - soc_floorf(pz);
+        while (!(rec > 0.0f)) {
+            l++;
+            fx *= 2.0f;  fy *= 2.0f;  fz *= 2.0f;
+            const int bx = (fx >= 1.0f) ? 1 : 0, by = (fy >= 1.0f) ? 1 : 0, bz = (fz >= 1.0f) ? 1 : 0;
+            fx -= (float)bx;  fy -= (float)by;  fz -= (float)bz;
+            nx = 2 * nx + bx;  ny = 2 * ny + by;  nz = 2 * nz + bz;
+            s = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
+            rec = tree[s];
+        }
+    }
+    const int ox = (L > 0) ? (cx & ~1) : 0, oy = (L > 0) ? (cy & ~1) : 0, oz = (L > 0) ? (cz & ~1) : 0;
+    const int qx = (l > 0) ? (nx & ~1) : 0, qy = (l > 0) ? (ny & ~1) : 0, qz = (l > 0) ? (nz & ~1) : 0;
+    const int k = l - L;
+    const float sc = soc_lt_pow2(k);
+    if (k <= 0) {
+        if ((k < 0) | (ox != qx) | (oy != qy) | (oz != qz)) {
+            const float Bx = (float)(ox - (qx << (-k))) * sc, By = (float)(oy - (qy << (-k))) * sc, Bz = (float)(oz - (qz << (-k))) * sc;
+            px = SOC_FMA(px, sc, Bx);  py = SOC_FMA(py, sc, By);  pz = SOC_FMA(pz, sc, Bz);
+        }
+    } else {
+        px = SOC_FMA(px, sc, (float)((ox << k) - qx));  py = SOC_FMA(py, sc, (float)((oy << k) - qy));  pz = SOC_FMA(pz, sc, (float)((oz << k) - qz));
+    }
+    cx = nx;  cy = ny;  cz = nz;
+    level = l;
+    slot = s;
+    dens = rec;
+}
+
+// Index() after a step, for a packet inside the brick: pos has been advanced by GetStep's arithmetic.
+//   SOC_LT_INSIDE: the packet's place is the new leaf (slot, level, c, pos, dens updated);
+//   SOC_LT_LEAVE : the point lies in root cell (Rx, Ry, Rz) of another brick -- nothing changed: the packet keeps its
+//                  old cell and the advanced pos, and the brick of that root cell completes the step (soc_lt_arrive);
+//   SOC_LT_EXIT  : the point lies outside the model (level > 0; a root-level packet is tested by the caller with the
+//                  reference's float comparisons, kernel_ASOC_aux.c:214);
+//   SOC_LT_SLOW  : not a step exact geometry decides (see the file header): nothing changed.
+// thr: 2^(k+level-30) for this level, sib_thr = 2^(k-29) (the bound of the sibling case: POS/2 + octant only).
+template <typename TREE>
+SOC_HD int soc_lt_step(const TREE tree, const SocLBrick &K, const int NX, const int NY, const int NZ, const float thr, const float sib_thr,
+                       float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens,
+                       int &Rx, int &Ry, int &Rz)
+{
+    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
+    const int   fx = (int)flx, fy = (int)fly, fz = (int)flz;
+    const int   L = level;
+    int   tx = fx, ty = fy, tz = fz, s = 0, l = L;
+    float rec = 0.0f;
+    if (L > 0) {
+        tx += cx & ~1;  ty += cy & ~1;  tz += cz & ~1;
+        if ((((fx | fy | fz) & ~1) == 0)) {
+            // a sibling in the same octet: Index() climbs one level and comes back to the same position
+            if (!(soc_fminf(px, soc_fminf(py, pz)) >= sib_thr)) return SOC_LT_SLOW;
+            s = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (fx | (fy << 1) | (fz << 2));
+            rec = tree[s];
+            soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
+            return SOC_LT_INSIDE;
+        }
+        if (soc_lt_degenerate(px, py, pz, flx, fly, flz, thr)) return SOC_LT_SLOW;
+    }
+    if (!soc_lt_descend(tree, K, L, tx, ty, tz, s, rec, l, Rx, Ry, Rz)) {
+        if (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ)) return SOC_LT_EXIT;
+        return SOC_LT_LEAVE;
+    }
+    soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
+    return SOC_LT_INSIDE;
+}
+
+// The second half of a step that crossed into this brick (the sender returned SOC_LT_LEAVE and kept old cell + advanced pos).
+template <typename TREE>
+SOC_HD bool soc_lt_arrive(const TREE tree, const SocLBrick &K, float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz,
+                          int &slot, float &dens)
+{
+    int tx = (int)soc_floorf(px), ty = (int)soc_floorf(py), tz = (int)soc_floorf(pz), s = 0, l = 0, Rx, Ry, Rz;
+    float rec = 0.0f;
+    if (level > 0) { tx += cx & ~1;  ty += cy & ~1;  tz += cz & ~1; }
+    if (!soc_lt_descend(tree, K, level, tx, ty, tz, s, rec, l, Rx, Ry, Rz)) return false;
+    soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
+    return true;
+}
+
+// The slot of the packet's own cell (a leaf, or the refined cell a SimRAM_CL packet starts "in"); pos is not used.
+template <typename TREE>
+SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, const int cx, const int cy, const int cz, int &slot, float &dens)
+{
+    int l = 0, Rx, Ry, Rz;
+    return soc_lt_descend(tree, K, level, cx, cy, cz, slot, dens, l, Rx, Ry, Rz) && (l == level);
+}
+
+#endif  // SOC_LTREE_H

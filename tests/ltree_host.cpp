@@ -1,0 +1,125 @@
+// ltree_host.cpp -- host harness for soc_amd/csrc/soc_ltree.h + soc_lbricks.h (TEST CODE): follows rays through the
+// brick-local hierarchies exactly as the device walk does (GetStep's float arithmetic, then soc_lt_step / soc_lt_arrive)
+// and reports every step, so that tests/test_ltree.py can compare it with the oracle's IndexG/GetStep/Index
+// (oracle/soc_oracle.c, double Index) step by step.  Built by tests/util.py with g++ (optionally with sanitizers).
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "../soc_amd/csrc/soc_lbricks.h"
+
+#define PEPS 1.0e-4f
+
+struct Harness {
+    int NX, NY, NZ, LEVELS;
+    std::vector<int> LCELLS, OFF;
+    SocLBricksHost B;
+    float thr[16], sib_thr;
+};
+
+extern "C" {
+
+void *lt_build(int NX, int NY, int NZ, int LEVELS, const int *LCELLS, const int *OFF, const float *DENS, int cap)
+{
+    Harness *H = new Harness();
+    H->NX = NX;  H->NY = NY;  H->NZ = NZ;  H->LEVELS = LEVELS;
+    H->LCELLS.assign(LCELLS, LCELLS + LEVELS);
+    H->OFF.assign(OFF, OFF + LEVELS);
+    if (!soc_lbricks_build(NX, NY, NZ, LEVELS, LCELLS, OFF, DENS, cap, H->B)) { delete H;  return nullptr; }
+    int k = 1;
+    const int n = NX > NY ? (NX > NZ ? NX : NZ) : (NY > NZ ? NY : NZ);
+    while ((1 << k) <= n) k++;
+    for (int l = 0; l < 16; l++) H->thr[l] = ldexpf(1.0f, k + l - 30);
+    H->sib_thr = ldexpf(1.0f, k - 29);
+    return H;
+}
+
+void lt_free(void *h) { delete (Harness *)h; }
+
+int lt_info(void *h, int *nbricks, int *max_slots, long *nslots)
+{
+    Harness *H = (Harness *)h;
+    *nbricks = (int)H->B.bricks.size();  *max_slots = H->B.max_slots;  *nslots = (long)H->B.btree.size();
+    return 0;
+}
+
+// consistency of the bricks with the hierarchy: every cell has exactly one slot, links and densities are those of DENS
+int lt_check(void *h, const float *DENS, long cells)
+{
+    Harness *H = (Harness *)h;
+    std::vector<unsigned char> seen((size_t)cells, 0);
+    for (size_t b = 0; b < H->B.bricks.size(); b++) {
+        const SocLBrick &K = H->B.bricks[b];
+        for (int s = 0; s < K.nslot; s++) {
+            const int g = H->B.bcell[K.base + s];
+            if (g < 0 || g >= cells || seen[g]) return -1;
+            seen[g] = 1;
+            const float d = DENS[g], t = H->B.btree[K.base + s];
+            if (d > 0.0f) { if (t != d) return -2; }
+            else {
+                if (t > 0.0f) return -3;
+                const int ls = soc_lt_link(t);
+                if (ls < 0 || ls + 8 > K.nslot) return -4;
+                int lev = 0;
+                while (lev + 1 < H->LEVELS && g >= H->OFF[lev + 1]) lev++;
+                const int child = H->OFF[lev + 1] + soc_lb::link_of(d);
+                for (int k = 0; k < 8; k++) if (H->B.bcell[K.base + ls + k] != child + k) return -5;
+            }
+        }
+    }
+    for (long i = 0; i < cells; i++) if (!seen[i]) return -6;
+    return 0;
+}
+
+// Follow one ray.  Per step: level, global cell index, step length (root units), as orc_trace reports them.
+// Returns the number of steps; *status: 0 left the model, 1 maxsteps, 2 stopped at a step that needs the generic Index.
+int lt_trace(void *h, const float *pos, const float *dir, int maxsteps, int *levels, int *cells, float *dss, float *endpos, int *status)
+{
+    Harness *H = (Harness *)h;
+    const int NX = H->NX, NY = H->NY, NZ = H->NZ;
+    float px = pos[0], py = pos[1], pz = pos[2];
+    const float ux = dir[0], uy = dir[1], uz = dir[2];
+    int level = 0, cx = 0, cy = 0, cz = 0, slot = 0, n = 0, Rx, Ry, Rz;
+    float dens = 0.0f;
+    *status = 0;
+    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
+    if ((px <= 0.0f) || (py <= 0.0f) || (pz <= 0.0f) || (px >= NX) || (py >= NY) || (pz >= NZ)) return 0;      // IndexG
+    int brick = H->B.rbrick[((int)floorf(pz) * NY + (int)floorf(py)) * NX + (int)floorf(px)];
+    {
+        const SocLBrick &K = H->B.bricks[brick];
+        if (!soc_lt_arrive(H->B.btree.data() + K.base, K, px, py, pz, level, cx, cy, cz, slot, dens)) { *status = -1;  return 0; }
+    }
+    while (n < maxsteps) {
+        const SocLBrick &K = H->B.bricks[brick];
+        const float *tree = H->B.btree.data() + K.base;
+        levels[n] = level;
+        cells[n]  = H->B.bcell[K.base + slot];
+        // GetStep (kernel_ASOC_aux.c:300-308)
+        const float ax = (ux > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(px)) / ux) : ((-PEPS - soc_fmod1f(px)) / ux);
+        const float ay = (uy > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(py)) / uy) : ((-PEPS - soc_fmod1f(py)) / uy);
+        const float az = (uz > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(pz)) / uz) : ((-PEPS - soc_fmod1f(pz)) / uz);
+        float s = soc_fminf(ax, soc_fminf(ay, az));
+        px += s * ux;  py += s * uy;  pz += s * uz;
+        dss[n] = soc_scale_down(s, level);
+        n++;
+        if (level == 0 && ((px <= 0.0f) || (px >= NX) || (py <= 0.0f) || (py >= NY) || (pz <= 0.0f) || (pz >= NZ))) break;
+        const int r = soc_lt_step(tree, K, NX, NY, NZ, H->thr[level], H->sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+        if (r == SOC_LT_EXIT) {
+            // Index() leaves the root-grid position behind (kernel_ASOC_aux.c:238-241); the device walk has no use for it
+            const float sc = soc_lt_pow2(-level);
+            px = SOC_FMA(px, sc, (float)(cx & ~1) * sc);  py = SOC_FMA(py, sc, (float)(cy & ~1) * sc);  pz = SOC_FMA(pz, sc, (float)(cz & ~1) * sc);
+            break;
+        }
+        if (r == SOC_LT_SLOW) { *status = 2;  break; }
+        if (r == SOC_LT_LEAVE) {
+            brick = H->B.rbrick[(Rz * NY + Ry) * NX + Rx];
+            const SocLBrick &K2 = H->B.bricks[brick];
+            if (!soc_lt_arrive(H->B.btree.data() + K2.base, K2, px, py, pz, level, cx, cy, cz, slot, dens)) { *status = -2;  break; }
+        }
+    }
+    if (n >= maxsteps && *status == 0) *status = 1;
+    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
+    return n;
+}
+
+}  // extern "C"
