@@ -203,7 +203,7 @@ def main():
                          "0 = the launches of one kind in equal sweeps of at most 16")
     ap.add_argument("--workload", choices=["C2", "C3"], default="C3",
                     help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]")
-    ap.add_argument("--global", dest="global0", type=int, default=4194304,
+    ap.add_argument("--global", dest="global0", type=int, default=16777216,
                     help="C3: GLOBAL_0, work items of the point-source and diffuse launches (ini key `global`; reference: 32768)")
     args = ap.parse_args()
 

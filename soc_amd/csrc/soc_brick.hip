@@ -33,12 +33,15 @@
 // identical to the direct kernel and to the oracle; only the order of fp32 tally additions
 // differs (as it already does between any two runs of the atomic version).
 #include "soc_walk.h"
+#include "soc_ltree.h"
 
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include "soc_lbricks.h"
 
 #define SOC_BRICK_T 256          // threads per workgroup (scatter kernel; step kernel uses A.T)
 
@@ -62,7 +65,9 @@ extern "C" __attribute__((visibility("default"))) void soc_prof_read(unsigned lo
 #define SOC_PROF(i, n) do { } while (0)
 #define SOC_PROF_FLUSH do { } while (0)
 #endif
-#define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk
+#define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk (walks that keep the chunk's ranks in LDS)
+#define SOC_RANK_BITS 16         // a packet's rank among its workgroup's packets for one queue; the table entry sits above (<= 4096 queues or 1024 hash entries)
+#define SOC_LBRICK_PMAX 32768    // ... of soc_lbrick_walk, whose chunk lives in global memory only
 
 enum { SOC_BM_STEP = 0, SOC_BM_CLIMB = 1, SOC_BM_SWAP = 3, SOC_BM_IDLE = 4 };
 
@@ -80,6 +85,7 @@ struct SocDesc { int brick, start, count, pad; };
 #define SOC_NT_STORE(v, p)  (*(p) = (v))
 #endif
 typedef float soc_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t soc_u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 soc_ld4(const float4 *p) { const soc_f4v v = SOC_NT_LOAD((const soc_f4v *)p);  return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void soc_st4(float4 *p, float4 a) { soc_f4v v = { a.x, a.y, a.z, a.w };  SOC_NT_STORE(v, (soc_f4v *)p); }
 
@@ -116,6 +122,15 @@ struct SocBrickArgs {
     float sib_thr;               // coordinates from here up climb to the parent exactly in double (see the walk)
     const int *bcell;            // cells of every brick in slot order
     const int *bbase;            // [NB+1] first entry of a brick in bcell
+    // brick-local hierarchies (soc_ltree.h): the brick's cells live in LDS, the packet carries integer cell coordinates
+    int LT;                      // 1: this form of the walk
+    int EQ;                      // event queues per launch: creation, scattering (+ slow steps with LT)
+    int slow_every;              // test knob: every n-th step below the root grid takes the slow-step queue (0: only the degenerate ones)
+    int lean_step;               // experiment: only root-leaf and sibling-leaf moves are settled in the step arm
+    const SocLBrick *lbr;        // [NB] boxes
+    const float *btree;          // slots of every brick: density or link to the octet's slots
+    const int *rbrick;           // [NX*NY*NZ] brick of every root cell
+    float lt_thr[SOC_MAXL];      // 2^(k + level - 30), see soc_lt_degenerate
 };
 
 #define SOC_SLOT_BITS 14
@@ -144,16 +159,16 @@ __device__ __forceinline__ int soc_qh_find(int *sH, int HS, int key)
     return -1;
 }
 // The place of a packet in its destination queue is settled in the pass itself: the LDS count a packet bumps
-// is its rank among the workgroup's packets for that queue (returned as entry << 12 | rank); at the end the
+// is its rank among the workgroup's packets for that queue (returned as entry << SOC_RANK_BITS | rank); at the end the
 // workgroup adds its counts to the global histogram, and what the add returns is where its packets start in
 // the queue.  The sort is then a plain permutation (soc_brick_scatter).  SOC_POS_FINAL: counted in global
 // memory directly (hash table full around that key), the value is the place itself.
 #define SOC_POS_FINAL 0x80000000u
 __device__ __forceinline__ uint32_t soc_qh_rank(int *sH, int HS, int key, int *ghist)
 {
-    if (HS == 0) return ((uint32_t)key << 12) | (uint32_t)atomicAdd(&sH[key], 1);
+    if (HS == 0) return ((uint32_t)key << SOC_RANK_BITS) | (uint32_t)atomicAdd(&sH[key], 1);
     const int h = soc_qh_find(sH, HS, key);
-    if (h >= 0) return ((uint32_t)h << 12) | (uint32_t)atomicAdd(&sH[HS + h], 1);
+    if (h >= 0) return ((uint32_t)h << SOC_RANK_BITS) | (uint32_t)atomicAdd(&sH[HS + h], 1);
     return SOC_POS_FINAL | (uint32_t)atomicAdd(&ghist[key], 1);
 }
 // counts -> first places (all threads of the workgroup; barrier before and after by the caller)
@@ -168,7 +183,7 @@ __device__ __forceinline__ void soc_qh_bases(int *sH, int HS, int NQ, int *ghist
 __device__ __forceinline__ uint32_t soc_qh_place(const int *sH, int HS, uint32_t pack)
 {
     if (pack & SOC_POS_FINAL) return pack & ~SOC_POS_FINAL;
-    return (uint32_t)sH[(HS ? HS : 0) + (pack >> 12)] + (pack & 4095u);
+    return (uint32_t)sH[(HS ? HS : 0) + (pack >> SOC_RANK_BITS)] + (pack & ((1u << SOC_RANK_BITS) - 1u));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -254,7 +269,7 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
         if (t >= dbase && t < dbase + nd) {
             const uint32_t k = t - dbase;
             SocDesc d;
-            d.brick = A.NBQ + 2 * l;
+            d.brick = A.NBQ + A.EQ * l;
             d.start = (int)(K.first[l] + k * A.P);
             d.count = (int)min((uint32_t)A.P, cnt - k * A.P);
             d.pad = 0;
@@ -263,7 +278,7 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
         dbase += nd;
     }
     if (t == 0) { ndesc0[0] = (int)dbase;  ndesc0[2] = 0;  A.admit[0] = (int)active;  *A.total = (int)active; }
-    if (t <= (uint32_t)(A.NBQ + 2 * K.n)) hist[t] = 0;
+    if (t <= (uint32_t)(A.NBQ + A.EQ * K.n)) hist[t] = 0;
 }
 
 template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
@@ -280,7 +295,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + BV;                                 // [BV] INT (WINT)
-    const int NQ = A.NBQ + 2 * K.n + 1;                    // brick queues, (creation, scattering) per launch, finished
+    const int NQ = A.NBQ + A.EQ * K.n + 1;                 // brick queues, (creation, scattering) per launch, finished
     int   *sH   = (int *)(sI + (WINT ? BV : 0));           // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0] next packet, [1] tally events
     float *sL   = (float *)(sCtl + 2);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
@@ -392,7 +407,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 const float dtau = ds * d0 * ksca;
                 if (free_path < (tau + dtau)) {
                     px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                    mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT) + 1;
+                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * (lsh >> SOC_LCH_SHIFT) + 1;
                 } else {
                     const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                     const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
@@ -452,7 +467,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 }
                 nvisit++;
                 if (ind < 0) {
-                    mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT);                          // -> creation queue
+                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * (lsh >> SOC_LCH_SHIFT);                          // -> creation queue
                 } else {
                     const int nb = (int)(sl >> SOC_SLOT_BITS);
                     lid = (int)(sl & SOC_SLOT_MASK);
@@ -497,7 +512,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             const float dtau = ds * d0 * ksca;
             if (free_path < (tau + dtau)) {
                 px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT) + 1;   // -> scattering queue of its launch
+                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * (lsh >> SOC_LCH_SHIFT) + 1;   // -> scattering queue of its launch
             } else {
                 // every lane of the wave in the interval where soc_expf_small == soc_expf (the common case)
                 const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
@@ -515,7 +530,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 py += failed ? (SOC_PEPS * uy) : 0.0f;
                 pz += failed ? (SOC_PEPS * uz) : 0.0f;
                 nvisit++;
-                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NBQ + 2 * (lsh >> SOC_LCH_SHIFT); }   // -> creation queue
+                if (!inside)                          { mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * (lsh >> SOC_LCH_SHIFT); }   // -> creation queue
                 else if (!stay || nvisit >= A.KCAP)   { mode = SOC_BM_SWAP;  key = qbase + nb; }
             }
         }
@@ -555,8 +570,349 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
     if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
 }
 
+// ---------------------------------------------------------------------------------------
+// The walk on brick-local hierarchies (soc_ltree.h): hierarchies whose Index() the reference evaluates in double.
+// The workgroup copies its brick's cells into LDS (sD: density, or the link to the octet's slots), so a cell step
+// reads and writes LDS only: GetStep's arithmetic, the tally (ds_add_f32), then the new cell from the packet's
+// integer cell coordinates -- a sibling by slot arithmetic, anything else by a descent from the brick's root cells
+// (soc_lt_step) -- and the new local position from one fma.  Global memory is touched when a packet is taken from
+// the queue or put back, and for the brick of the root cell a leaving packet goes to (rbrick).
+// Packet record here: A = position, photons | B = direction, free path | C = tau, cell coordinates (cx, cy, cz on the
+// cell's level) | D = RNG state, III | scatterings << 24 | level << 29, SimRAM_CL: emitting cell; bit 31: the step
+// into the next brick is not finished (old cell + advanced position: soc_lt_arrive completes it there).
+// ---------------------------------------------------------------------------------------
+#define SOC_LT_ARRIVE 0x80000000u
+
+// integer coordinates of cell (level, ind) on its level: octants on the way up through PAR, then the root cell
+__device__ __forceinline__ void soc_cell_coords(const SocGrid &G, const int *sOFF, int level, int ind, int &cx, int &cy, int &cz)
+{
+    int x = 0, y = 0, z = 0;
+    for (int j = 0; j < level; j++) {
+        x |= (ind & 1) << j;  y |= ((ind >> 1) & 1) << j;  z |= ((ind >> 2) & 1) << j;
+        ind = G.PAR[sOFF[level - j] + ind - G.NXYZ];
+    }
+    cx = x | ((ind % G.NX) << level);
+    cy = y | (((ind / G.NX) % G.NY) << level);
+    cz = z | ((ind / (G.NX * G.NY)) << level);
+}
+
+// the inverse: index within its level of the cell with coordinates (cx, cy, cz) on `level` (descent through DENS)
+__device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int cx, int cy, int cz, float &dens)
+{
+    int ind = ((cz >> level) * G.NY + (cy >> level)) * G.NX + (cx >> level);
+    dens = G.DENS[ind];
+    for (int l = 1; l <= level; l++) {
+        const int sh = level - l;
+        ind = soc_link_index(dens) + (((cx >> sh) & 1) | (((cy >> sh) & 1) << 1) | (((cz >> sh) & 1) << 2));
+        dens = G.DENS[G.OFF[l] + ind];
+    }
+    return ind;
+}
+
+template <bool WINT, int KIND>
+__device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
+{
+    constexpr bool CL = (KIND == 2);
+    if (bid >= *A.ndesc) return;
+    SocDesc D = A.desc[bid];
+    D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
+    if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
+    const int BV = A.CAP;                                  // slots in LDS
+    const int nthr = (int)blockDim.x;
+    SocPk2 *pk = A.pk;
+
+    extern __shared__ float lds[];
+    float *sT   = lds;                                     // [BV] TABS of this brick
+    float *sI   = sT + BV;                                 // [BV] INT (WINT)
+    float *sD   = sI + (WINT ? BV : 0);                    // [BV] density | link of every cell of the brick
+    const int NQ = A.NBQ + A.EQ * A.nl + 1;
+    int   *sH   = (int *)(sD + BV);                        // arrivals per queue, next pass
+    int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));   // [0] next packet, [1] tally events
+    float *sL   = (float *)(sCtl + 4);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
+    float *sThr = sL + 3 * SOC_MAXLAUNCH;                  // [SOC_MAXL] soc_lt_degenerate's bound per level
+    uint32_t *sFirst = (uint32_t *)(sThr + SOC_MAXL) + 3;  // [MAXLAUNCH + 1] first work item of every launch; entry 1 on a 16-byte boundary
+    const SocSim &S = K.S[0];
+    if ((int)threadIdx.x < K.n) {
+        sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
+    }
+    if (threadIdx.x < SOC_MAXL) sThr[threadIdx.x] = A.lt_thr[threadIdx.x];
+    if (threadIdx.x <= SOC_MAXLAUNCH) sFirst[threadIdx.x] = ((int)threadIdx.x < A.nl) ? K.first[threadIdx.x] : 0xffffffffu;
+    const int mybrick = (A.NBQ > A.NB) ? (D.brick % A.NB) : D.brick;
+    const int qbase = D.brick - mybrick;                   // first brick queue of this workgroup's launch (0 when the launches share queues)
+    const int nl = A.nl;                                   // launches in the sweep (a kernel argument: K lives in global memory)
+    SocLBrick KB = A.lbr[mybrick];
+    // workgroup-uniform values that came from global memory go to scalar registers now: a use inside the loop would
+    // otherwise wait for every load in flight (s_waitcnt vmcnt(0)), the prefetched packets included
+    KB.x0 = __builtin_amdgcn_readfirstlane(KB.x0);  KB.y0 = __builtin_amdgcn_readfirstlane(KB.y0);  KB.z0 = __builtin_amdgcn_readfirstlane(KB.z0);
+    KB.bx = __builtin_amdgcn_readfirstlane(KB.bx);  KB.by = __builtin_amdgcn_readfirstlane(KB.by);  KB.bz = __builtin_amdgcn_readfirstlane(KB.bz);
+    KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
+    {
+        const float *src = A.btree + KB.base;
+        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
+    }
+    soc_qh_init(sH, A.HS, NQ);
+    if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
+    const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
+    float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+    float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
+    float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;                 // GetStep's target inside the cell per axis: 1 + PEPS or -PEPS
+    float lsc = 1.0f;                                      // 2^-level
+    float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
+    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;
+    uint32_t dz = 0, dw = 0, wid = 0;
+    int   mode = SOC_BM_SWAP;
+    int   r = SOC_LT_SLOW + 2, Rx = 0, Ry = 0, Rz = 0, slot0 = 0;            // outcome of Index() for the step in hand (> SOC_LT_SLOW: none)
+    bool  have = false, nhave = false;                                       // the packet in hand, the prefetched one
+    soc_f4v na = { 0.0f, 0.0f, 0.0f, 0.0f }, nb = na, nc = na;
+    soc_u2v ndzw = { 0u, 0u };
+    uint32_t nwid = 0, nnwid = 0;
+    int   nslot = 0, nnslot = 0, kraw = 0;
+    bool  nnhave = false;                                                    // the packet after the prefetched one: its id is on the way
+    unsigned int n_tally = 0;
+    SOC_PROF_DECL;
+
+    while (true) {
+        {
+            SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
+            // the end of the chunk: when no lane of the wave has a packet waiting and few still walk, those go back to
+            // the brick's queue (between steps their state is complete) and continue in the next pass among a full wave
+            if ((A.TAIL > 0) && (__ballot(nhave | nnhave) == 0ull)) {
+                const unsigned long long ms = __ballot(mode == SOC_BM_STEP);
+                if ((ms != 0ull) && (__popcll(ms) <= A.TAIL) && (mode == SOC_BM_STEP) && (nvisit > 0)) { mode = SOC_BM_SWAP;  key = D.brick; }
+            }
+            const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
+            const bool nobody_steps = (__ballot((mode == SOC_BM_STEP) | (mode == SOC_BM_CLIMB)) == 0ull);
+            if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
+                SOC_PROF(4, 1);  SOC_PROF(5, __popcll(m));
+                if (mode == SOC_BM_SWAP) {
+                    // A lane holds three packets: the one it walks, the next one, whose record was asked for when the
+                    // current one was taken up, and the one after that, of which the id has been asked for -- each a
+                    // visit ahead of its use, so nothing in this arm waits for global memory (the brick a leaving packet
+                    // goes to was asked for when it left: kraw).  The chunk itself is never copied: ids, queues and
+                    // places stay in global memory (idq, keyq, posq), so a chunk may be the whole queue of the brick.
+                    asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed: no later use waits behind the stores below
+                    if (have) {
+                        SocPk2 *q = pk + wid;
+                        if (key < 0) key = qbase + kraw;
+                        soc_st4(&q->A, make_float4(px, py, pz, photons));
+                        soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
+                        q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
+                        q->D.w = dw;
+                        SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + cslot]);    // its rank in that queue is settled after the walk, for all packets at once
+                    }
+                    // the prefetched packet becomes the current one
+                    have = nhave;
+                    wid = nwid;  cslot = nslot;
+                    if (have) {
+                        dz = ndzw.x;  dw = ndzw.y;
+                        px = na.x;  py = na.y;  pz = na.z;  photons = na.w;
+                        ux = nb.x;  uy = nb.y;  uz = nb.z;  free_path = nb.w;
+                        rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
+                        gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;
+                        tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = __float_as_int(nc.w);
+                        level = (int)(dz >> 29);
+                        lsc = soc_lt_pow2(-level);
+                        lq = 0;                                                   // the launch of the work item (first[] is a kernel argument: scalar compares)
+                        for (int j = 1; j < nl; j++) lq += (wid >= A.first[j]) ? 1 : 0;
+                        kabs = sL[3 * lq];  ksca = sL[3 * lq + 1];  tw = sL[3 * lq + 2];
+                        nvisit = 0;
+                        mode = SOC_BM_STEP;
+                        if (dw & SOC_LT_ARRIVE) {
+                            // the step that brought the packet here is completed by the Index() arms below: the common case --
+                            // a root-level packet into a root cell that is a leaf -- here, the others in the deferred arm
+                            dw &= ~SOC_LT_ARRIVE;
+                            slot = -1;                                            // (no cell of this brick: not a failed step)
+                            r = SOC_LT_SLOW + 1;
+                            mode = SOC_BM_CLIMB;
+                            if (level == 0) {
+                                const int ix = (int)soc_floorf(px), iy = (int)soc_floorf(py), iz = (int)soc_floorf(pz);
+                                const int s2 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
+                                const float rec = sD[s2];
+                                if (rec > 0.0f) { slot = s2;  dens = rec;  cx = ix;  cy = iy;  cz = iz;  r = SOC_LT_SLOW + 2;  mode = SOC_BM_STEP; }
+                            }
+                        } else if (level == 0) {
+                            slot = ((cz - KB.z0) * KB.by + (cy - KB.y0)) * KB.bx + (cx - KB.x0);
+                            dens = sD[slot];
+                        } else if (!soc_lt_place(sD, KB, level, cx, cy, cz, slot, dens)) {
+                            mode = SOC_BM_SWAP;  key = NQ - 1;                    // cannot happen (the sender looked the brick up): retire rather than walk off the tree
+                        }
+                    }
+                    // the record of the packet after it (its id has arrived)
+                    nhave = nnhave;
+                    nwid = nnwid;  nslot = nnslot;
+                    if (nhave) {
+                        // (vector-typed loop variables: the loads land in the registers that carry the values around the loop)
+                        const SocPk2 *q = pk + nwid;
+                        na = SOC_NT_LOAD((const soc_f4v *)&q->A);  nb = SOC_NT_LOAD((const soc_f4v *)&q->B);  nc = SOC_NT_LOAD((const soc_f4v *)&q->C);
+                        ndzw = *(const soc_u2v *)&q->D.z;
+                    }
+                    {   // and the lane reserves the one after that: one LDS atomic per wave, neighbouring lanes read neighbouring ids
+                        const unsigned long long am = __ballot(true);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                        int base = 0;
+                        if (rank == 0) base = atomicAdd(&sCtl[0], __popcll(am));
+                        nnslot = __builtin_amdgcn_readfirstlane(base) + rank;
+                    }
+                    nnhave = nnslot < D.count;
+                    if (nnhave) nnwid = SOC_NT_LOAD(&A.idq[D.start + nnslot]);
+                    if (!have) mode = (nhave | nnhave) ? SOC_BM_SWAP : SOC_BM_IDLE;      // (the first two turns of a lane only reserve)
+                }
+            }
+        }
+        SOC_PROF_T(0);                                     // swap
+        if (__ballot(mode != SOC_BM_IDLE) == 0ull) break;
+        // ---- one cell step (kernel_ASOC.c:565-683) ----
+        if (mode == SOC_BM_STEP) {
+            const int   level0 = level;
+            const float p0x = px, p0y = py, p0z = pz, d0 = dens;
+            slot0 = slot;
+            float fx, fy, fz;
+            if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
+                fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
+            } else {
+                fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
+            }
+            const float ax = soc_div_by_rcp(gx - fx, ux, rux);
+            const float ay = soc_div_by_rcp(gy - fy, uy, ruy);
+            const float az = soc_div_by_rcp(gz - fz, uz, ruz);
+            float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
+            px += ds * ux;
+            py += ds * uy;
+            pz += ds * uz;
+            ds = ds * lsc;                                                    // ldexp(ds, -level)
+            const float tauA = ds * d0 * kabs;
+            const float dtau = ds * d0 * ksca;
+            if (free_path < (tau + dtau)) {
+                px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
+                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 1;             // -> scattering queue of its launch
+            } else {
+                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
+                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+                atomicAdd(&sT[slot0], delta * tw);
+                if (WINT) atomicAdd(&sI[slot0], delta);
+                n_tally++;
+                photons *= e;
+                tau += dtau;
+                // Index (kernel_ASOC_aux.c:198-278).  The common moves are settled here, each with the results soc_lt_step
+                // would give (soc_ltree.h): root cell -> root cell that is a leaf, or one level down into a refined one;
+                // sibling leaf in the same octet; level-1 cell -> neighbouring root cell that is a leaf.  The rest (deeper
+                // changes of level or octet, degenerate positions) waits for the deferred arm below.
+                r = SOC_LT_SLOW + 1;                                          // "not settled yet"
+                if ((A.slow_every > 0) && (level0 > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
+                    r = SOC_LT_SLOW;
+                } else {
+                    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
+                    const int   ix = (int)flx, iy = (int)fly, iz = (int)flz;
+                    const bool  sib = (level0 > 0) && (((ix | iy | iz) & ~1) == 0);
+                    bool root = (level0 == 0);
+                    Rx = ix;  Ry = iy;  Rz = iz;
+                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, A.lt_thr[1])) {
+                        Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
+                        root = true;
+                    }
+                    if (root) {
+                        const bool out = (level0 == 0) ? !((px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ))
+                                                       : (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ));
+                        const int rx = Rx - KB.x0, ry = Ry - KB.y0, rz = Rz - KB.z0;
+                        if (out) {
+                            r = SOC_LT_EXIT;
+                        } else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) {
+                            r = SOC_LT_LEAVE;
+                        } else {
+                            const int   s2 = (rz * KB.by + ry) * KB.bx + rx;
+                            const float rec = sD[s2];
+                            if (rec > 0.0f) {
+                                if (level0 == 1) {                            // up to the root grid: pos' = RN(pos/2 + octet origin/2)
+                                    px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
+                                    level = 0;  lsc = 1.0f;
+                                }
+                                slot = s2;  dens = rec;  cx = Rx;  cy = Ry;  cz = Rz;  r = SOC_LT_INSIDE;
+                            } else if (!A.lean_step && (level0 == 0)) {
+                                // one level down: octant and position from 2*fmod(pos,1), exact
+                                const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
+                                const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
+                                const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
+                                const float rec3 = sD[s3];
+                                if (rec3 > 0.0f) {
+                                    px = hx;  py = hy;  pz = hz;
+                                    level = 1;  lsc = 0.5f;
+                                    slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
+                                }
+                            }
+                        }
+                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
+                        const int   s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
+                        const float rec = sD[s2];
+                        if (rec > 0.0f) { slot = s2;  dens = rec;  cx = (cx & ~1) + ix;  cy = (cy & ~1) + iy;  cz = (cz & ~1) + iz;  r = SOC_LT_INSIDE; }
+                    }
+                }
+                if (r > SOC_LT_SLOW) mode = SOC_BM_CLIMB;
+            }
+        }
+        SOC_PROF_T(1);                                     // step
+        {
+            const unsigned long long mc = __ballot(mode == SOC_BM_CLIMB);
+            if (mc != 0ull && (__popcll(mc) >= A.CTH || __ballot(mode == SOC_BM_STEP) == 0ull)) {
+                SOC_PROF(2, 1);  SOC_PROF(3, __popcll(mc));
+                if (mode == SOC_BM_CLIMB) {
+                    slot0 = slot;
+                    r = soc_lt_step(sD, KB, NX, NY, NZ, sThr[level], A.sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+                    lsc = soc_lt_pow2(-level);
+                    mode = SOC_BM_STEP;
+                }
+            }
+        }
+        SOC_PROF_T(2);                                     // deferred Index
+        if (r <= SOC_LT_SLOW) {
+            if (r == SOC_LT_INSIDE) {
+                if (!CL && (slot == slot0)) {                                 // failed step: nudge (SimRAM_PB / HP only)
+                    px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
+                }
+                nvisit++;
+                if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
+            } else if (r == SOC_LT_LEAVE) {
+                mode = SOC_BM_SWAP;  key = -1;  kraw = A.rbrick[(Rz * NY + Ry) * NX + Rx];  dw |= SOC_LT_ARRIVE;      // (the value is used in the swap arm)
+            } else if (r == SOC_LT_EXIT) {
+                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
+            } else {
+                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE;          // -> slow-step queue: old cell, advanced position
+            }
+            r = SOC_LT_SLOW + 2;                                              // handled
+        }
+    }
+
+    SOC_PROF_FLUSH;
+    atomicAdd(&sCtl[1], (int)n_tally);
+    __syncthreads();
+    {
+        const int *cells = A.bcell + KB.base;
+        for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
+            const float v = sT[i];
+            const float vi = WINT ? sI[i] : 0.0f;
+            if (v != 0.0f || vi != 0.0f) {
+                const int cell = cells[i];
+                soc_tally(S.TABS, cell, v);
+                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
+            }
+        }
+    }
+    // every packet of the chunk: its queue -> its rank among the workgroup's packets for that queue (kept in posq
+    // meanwhile; the barrier above made the workgroup's keyq stores visible to all its threads)
+    for (int j = threadIdx.x; j < D.count; j += nthr)
+        A.posq[D.start + j] = soc_qh_rank(sH, A.HS, (int)A.keyq[D.start + j], A.hist);
+    __syncthreads();
+    soc_qh_bases(sH, A.HS, NQ, A.hist);
+    __syncthreads();
+    for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, A.posq[D.start + j]);
+    if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
+}
+
 // creation and scattering, one lane per queued packet
-template <bool OCT, bool ABU, bool WINT, int KIND>
+template <bool OCT, bool ABU, bool WINT, int KIND, bool LT>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
     constexpr bool CL = (KIND == 2), HP = (KIND == 1);
@@ -574,8 +930,8 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         D.count = min((int)blockDim.x, D.count - first);
     }
     SocPk2 *pk = A.pk;
-    const int NQ = A.NBQ + 2 * K.n + 1;
-    const int lq = (D.brick - A.NBQ) >> 1;                  // the launch this queue belongs to (workgroup-uniform)
+    const int NQ = A.NBQ + A.EQ * K.n + 1;
+    const int lq = (D.brick - A.NBQ) / A.EQ;                  // the launch this queue belongs to (workgroup-uniform)
     const SocSim &S = K.S[lq];
     const int qbase = (A.NBQ > A.NB) ? lq * A.NB : 0;      // first brick queue of this launch
     extern __shared__ float lds[];
@@ -604,7 +960,33 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         w.scat = (int)(p.D.z >> 24);
         int key = (int)p.D.w;
         uint32_t cl_cell = p.D.w;                              // SimRAM_CL: the cell the work item emits from
-        bool create = (((D.brick - A.NBQ) & 1) == 0);
+        const int evk = (D.brick - A.NBQ) % A.EQ;              // 0 creation, 1 scattering, 2 slow step (brick-local hierarchies)
+        bool create = (evk == 0);
+        int ccx = 0, ccy = 0, ccz = 0;                         // brick-local hierarchies: cell coordinates on the cell's level
+        if (LT) {
+            // record of soc_lbrick_walk: C = tau, cell coordinates; D.z = III | scatterings << 24 | level << 29
+            ccx = __float_as_int(p.C.y);  ccy = __float_as_int(p.C.z);  ccz = __float_as_int(p.C.w);
+            w.level = (int)(p.D.z >> 29);
+            w.scat  = (int)((p.D.z >> 24) & 31u);
+            if (evk == 2) cl_cell = p.D.w & ~SOC_LT_ARRIVE;                      // (a work item that has not started holds a negative cell)
+            w.ind = -1;
+            if (!create) w.ind = soc_cell_index(G, w.level, ccx, ccy, ccz, w.dens);      // the cell the packet is in (or stepped from)
+        }
+        if (LT && (evk == 2)) {
+            // slow step: Index() itself, in double, for a step that exact geometry does not decide (soc_ltree.h).  The
+            // packet holds its old cell and the advanced position; tallies of the step are done.
+            const int ind0 = w.ind, level0 = w.level;
+            soc_index<true, double>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+            if (w.ind < 0) {
+                create = true;                                                  // left the model: the work item's next packet
+            } else {
+                if (!CL && (w.level == level0) && (w.ind == ind0)) {            // failed step: nudge (SimRAM_PB / HP only)
+                    w.px += SOC_PEPS * w.ux;  w.py += SOC_PEPS * w.uy;  w.pz += SOC_PEPS * w.uz;
+                }
+                soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);
+                key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
+            }
+        } else
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
             const int oind = (OCT ? sOFF[w.level] : 0) + w.ind;
@@ -635,6 +1017,9 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);           // one table read per event: no staging
             w.tau = 0.0f;
             if (!CL && (w.scat > 20)) { w.ind = -1;  create = true; }         // dropped after 20 scatterings
+            if (LT) {                                                        // back to the brick of its cell
+                key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
+            } else
             if (CL) {                                                        // back to the brick of its cell (D.w holds the emitting cell)
                 if (OCT) {
                     const uint32_t si = __float_as_uint(A.DS[oind].y);
@@ -652,7 +1037,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             // SimRAM_CL (kernel_ASOC.c:1283-1432): the work item walks the cells id, id+GLOBAL, ... and sends `batch`
             // packets from each.  Its place is kept in the record: D.w = cell, III = packets sent from it; batch and
             // the packet weight follow from the cell (EMWEI) and are recomputed.
-            int ICELL = (int)p.D.w, IRAY = III, batch = -1;
+            int ICELL = (int)cl_cell, IRAY = III, batch = -1;
             float PWEI = 1.0f;
             if (ICELL >= 0) {
                 if (S.USE_EMWEIGHT > 0) {
@@ -717,6 +1102,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                 w.ux = sin_theta * cp;  w.uy = sin_theta * sp;  w.uz = cos_theta;
                 n_pkt++;
                 w.begin();
+                if (LT) {
+                    soc_cell_coords(G, sOFF, level, ind, ccx, ccy, ccz);
+                    key = A.rbrick[((ccz >> level) * G.NY + (ccy >> level)) * G.NX + (ccx >> level)];
+                } else
                 if (OCT) {
                     const uint32_t si = __float_as_uint(A.DS[oabs].y);
                     key = (int)(si >> SOC_SLOT_BITS);  lid = (int)(si & SOC_SLOT_MASK);
@@ -745,6 +1134,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                 III++;
                 n_pkt++;
                 if (w.ind >= 0) {
+                    if (LT) {
+                        soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);
+                        key = A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
+                    } else
                     if (OCT) {
                         const uint32_t si = __float_as_uint(A.DS[sOFF[w.level] + w.ind].y);
                         key = (int)(si >> SOC_SLOT_BITS);  lid = (int)(si & SOC_SLOT_MASK);
@@ -758,8 +1151,13 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         }
         p.A = make_float4(w.px, w.py, w.pz, w.photons);
         p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
+        if (LT) {
+            p.C = make_float4(w.tau, __int_as_float(ccx), __int_as_float(ccy), __int_as_float(ccz));
+            p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24) | ((uint32_t)w.level << 29), CL ? cl_cell : 0u);
+        } else {
         p.C = make_float4(w.tau, w.dens, __int_as_float(lid | ((OCT ? w.level : 0) << SOC_LVL_SHIFT) | (lq << SOC_LCH_SHIFT)), __int_as_float(w.ind));
         p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24), CL ? cl_cell : (uint32_t)key);
+        }
         pk[wid] = p;
         A.keyq[D.start + j] = (uint32_t)key;
         mypack = soc_qh_rank(sH, A.HS, key, A.hist);
@@ -790,7 +1188,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void s
         soc_brick_walk<OCT, DBL, ABU, WINT, KIND>(G, K, A, b);
     } else {
         const int e = b - nwalk;
-        soc_brick_events<OCT, ABU, WINT, KIND>(G, K, A, e / slices, e % slices);
+        soc_brick_events<OCT, ABU, WINT, KIND, false>(G, K, A, e / slices, e % slices);
+    }
+}
+
+// the same for brick-local hierarchies (soc_lbrick_walk).  The brick's cells take 8 bytes of LDS each, which is what
+// bounds the waves per SIMD here, not the registers.
+template <bool WINT, int KIND>
+__global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
+{
+    const SocSimPack &K = *Kp;
+    const int b = (int)blockIdx.x;
+    if (b < nwalk) {
+        soc_lbrick_walk<WINT, KIND>(G, K, A, b);
+    } else {
+        const int e = b - nwalk;
+        soc_brick_events<true, false, WINT, KIND, true>(G, K, A, e / slices, e % slices);
     }
 }
 
@@ -814,7 +1227,7 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
             sAdm[l] = m;
             A.admit[1 + 3 * l] = lo;
             A.admit[2 + 3 * l] = m;
-            if (m) atomicAdd(&A.hist[A.ev_brick + 2 * l], m);            // at L2: the loads below must see it
+            if (m) atomicAdd(&A.hist[A.ev_brick + A.EQ * l], m);            // at L2: the loads below must see it
         }
         A.admit[0] = next + n;
     }
@@ -843,8 +1256,8 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         const int c = A.hist[b];
         A.off[b] = off;
         if (b == A.ev_brick) A.ndesc_next[2] = offd;
-        if (b >= A.ev_brick && ((b - A.ev_brick) & 1) == 0) {           // a creation queue: the admitted ids go to its end
-            const int l = (b - A.ev_brick) >> 1;
+        if (b >= A.ev_brick && ((b - A.ev_brick) % A.EQ) == 0) {        // a creation queue: the admitted ids go to its end
+            const int l = (b - A.ev_brick) / A.EQ;
             if (l < A.nl && sAdm[l]) A.admit[3 + 3 * l] = off + c - sAdm[l];
         }
         const int nk = (c + A.P - 1) / A.P;               // chunks of equal size (a queue of P+1 is not 2048 + 1)
@@ -951,13 +1364,34 @@ struct SocOctBricks {
 };
 static SocOctBricks g_ob[16];
 
+// brick-local hierarchies (soc_lbricks.h) on the device, built once per grid and cap
+struct SocLBricksDev {
+    bool valid = false, failed = false;
+    int  NB = 0, cap = 0, max_slots = 0;
+    size_t cells = 0;
+    const float *dens_key = nullptr;
+    SocLBrick *lbr = nullptr;
+    float *btree = nullptr;
+    int *bcell = nullptr, *bbase = nullptr, *rbrick = nullptr;
+};
+static SocLBricksDev g_lb[16];
+
+static void soc_lb_release(int device)
+{
+    SocLBricksDev &o = g_lb[device];
+    void *ptrs[] = { o.lbr, o.btree, o.bcell, o.bbase, o.rbrick };
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    o = SocLBricksDev();
+}
+
 void soc_brick_invalidate(int device)
 {
-    if (device >= 0 && device < 16) g_ob[device].valid = false;
+    if (device >= 0 && device < 16) { g_ob[device].valid = false;  g_lb[device].valid = false;  g_lb[device].failed = false; }
 }
 
 static void soc_oct_release(int device)
 {
+    soc_lb_release(device);
     SocOctBricks &o = g_ob[device];
     if (o.DS) (void)hipFree(o.DS);
     if (o.bcell) (void)hipFree(o.bcell);
@@ -1098,6 +1532,65 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
     return hipSuccess;
 }
 
+// Bricks for the walk on brick-local hierarchies.  hipErrorNotSupported: the hierarchy cannot be cut that way (a root
+// cell with more than cap cells below it) -- the caller keeps the sweep that reads the hierarchy from global memory.
+static hipError_t soc_lb_build(int device, const SocGrid &G, int cap, hipStream_t st, bool verbose)
+{
+    SocLBricksDev &lb = g_lb[device];
+    if (lb.cap == cap && lb.cells == (size_t)G.CELLS && lb.dens_key == G.DENS) {
+        if (lb.valid) return hipSuccess;
+        if (lb.failed) return hipErrorNotSupported;
+    }
+    soc_lb_release(device);
+    lb.cap = cap;  lb.cells = (size_t)G.CELLS;  lb.dens_key = G.DENS;
+    std::vector<float> D((size_t)G.CELLS);
+    BCHK(hipStreamSynchronize(st));
+    BCHK(hipMemcpy(D.data(), G.DENS, (size_t)G.CELLS * 4, hipMemcpyDeviceToHost));
+    SocLBricksHost H;
+    if (!soc_lbricks_build(G.NX, G.NY, G.NZ, G.LEVELS, G.LCELLS, G.OFF, D.data(), cap, H) || H.bricks.size() >= (1u << 20)) {
+        lb.failed = true;
+        return hipErrorNotSupported;
+    }
+    const int NB = (int)H.bricks.size();
+    std::vector<int> bbase((size_t)NB + 1);
+    for (int b = 0; b < NB; b++) bbase[b] = H.bricks[b].base;
+    bbase[NB] = (int)H.btree.size();
+    BCHK(brick_alloc(&lb.lbr, (size_t)NB));
+    BCHK(brick_alloc(&lb.btree, H.btree.size()));
+    BCHK(brick_alloc(&lb.bcell, H.bcell.size()));
+    BCHK(brick_alloc(&lb.bbase, bbase.size()));
+    BCHK(brick_alloc(&lb.rbrick, H.rbrick.size()));
+    BCHK(hipMemcpy(lb.lbr, H.bricks.data(), (size_t)NB * sizeof(SocLBrick), hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(lb.btree, H.btree.data(), H.btree.size() * 4, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(lb.bcell, H.bcell.data(), H.bcell.size() * 4, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(lb.bbase, bbase.data(), bbase.size() * 4, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(lb.rbrick, H.rbrick.data(), H.rbrick.size() * 4, hipMemcpyHostToDevice));
+    lb.NB = NB;  lb.max_slots = H.max_slots;
+    lb.valid = true;
+    if (verbose)
+        fprintf(stderr, "soc_brick: hierarchy of %d cells -> %d brick-local hierarchies of <= %d cells (largest %d, mean %.0f)\n",
+                G.CELLS, NB, cap, H.max_slots, (double)G.CELLS / NB);
+    return hipSuccess;
+}
+
+template <bool WINT, int KIND>
+static void soc_lbrick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
+                                  const SocBrickArgs &A, int nwalk, int slices)
+{
+    if (lds > 64 * 1024)                           // more dynamic LDS than the default limit (per device and kernel; cheap)
+        (void)hipFuncSetAttribute((const void *)soc_lbrick_pass<WINT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    soc_lbrick_pass<WINT, KIND><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices);
+}
+
+static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
+                                   const SocBrickArgs &A, int nwalk, int slices)
+{
+#define SOC_LB_CASE(W, KD) soc_lbrick_launch_one<W, KD>(nblocks, T, lds, st, G, K, A, nwalk, slices)
+    if (wint) { if (kind == 3) SOC_LB_CASE(true, 3);  else if (kind == 2) SOC_LB_CASE(true, 2);  else if (kind == 1) SOC_LB_CASE(true, 1);  else SOC_LB_CASE(true, 0); }
+    else      { if (kind == 3) SOC_LB_CASE(false, 3); else if (kind == 2) SOC_LB_CASE(false, 2); else if (kind == 1) SOC_LB_CASE(false, 1); else SOC_LB_CASE(false, 0); }
+#undef SOC_LB_CASE
+}
+
 // LB: log2 of the brick edge (Cartesian grids; hierarchies use bricks of <= CAP leaves).  nlaunch launches
 // (same geometry, same tallies; no INT tally when nlaunch > 1) share one sweep: more
 // packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
@@ -1142,8 +1635,9 @@ static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t
 }
 
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
-                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out)
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out)
 {
+    if (form_out) *form_out = 0;
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
@@ -1164,8 +1658,43 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     A.CTH = A.FTH;
     if (tune.CTH > 0)  A.CTH = tune.CTH;
     if (tune.CAP > 0)  A.CAP = tune.CAP;
-    if (A.T < 64 || A.T > 512 || (A.T & 63) || A.P < 1 || A.P > SOC_BRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
-    if (A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS)) return hipErrorInvalidValue;
+    if (A.T < 64 || A.T > 1024 || (A.T & 63) || A.P < 1 || A.P > SOC_LBRICK_PMAX || A.KCAP < 1) return hipErrorInvalidValue;
+    A.EQ = 2;
+    // hierarchies whose Index() is evaluated in double: the walk on brick-local hierarchies (soc_ltree.h), unless the
+    // grid does not allow it (per-cell opacities, more than 8 levels, coordinates beyond 24 bits, a root cell whose
+    // subtree exceeds the brick) or soc_set_tuning("global_tree", 1) asks for the older form
+    if (V.octree && V.dbl && !V.abu && !tune.global_tree && G.LEVELS <= 8
+        && ((long long)std::max(G.NX, std::max(G.NY, G.NZ)) << (G.LEVELS - 1)) < (1LL << 24)) {
+        // cells per brick: what lets two workgroups share a CU's 160 KB of LDS (8 B per cell, 12 B with the INT tally, + 9 KB)
+        const int capl = (tune.CAP > 0) ? tune.CAP : (V.wint ? 5888 : 8704);
+        if (capl < 8 || capl > 36864) return hipErrorInvalidValue;
+        const hipError_t e = soc_lb_build(device, G, capl, st, tune.verbose != 0);
+        if (e == hipSuccess) {
+            const SocLBricksDev &lb = g_lb[device];
+            A.LT = 1;  A.EQ = 3;
+            A.NBX = A.NBY = A.NBZ = 0;
+            A.NB = lb.NB;
+            A.CAP = (lb.max_slots + 63) & ~63;                           // slots in LDS
+            A.lbr = lb.lbr;  A.btree = lb.btree;  A.bcell = lb.bcell;  A.bbase = lb.bbase;  A.rbrick = lb.rbrick;
+            int k = 1;
+            while ((1 << k) <= std::max(G.NX, std::max(G.NY, G.NZ))) k++;
+            A.sib_thr = ldexpf(1.0f, k - 29);
+            for (int l = 0; l < SOC_MAXL; l++) A.lt_thr[l] = ldexpf(1.0f, k + l - 30);
+            A.slow_every = tune.slow_every;
+            A.lean_step = tune.lean_step;
+            A.P = (tune.P > 0) ? tune.P : 16384;
+            A.KCAP = (tune.KCAP > 0) ? tune.KCAP : 64;
+            A.FTH = (tune.FTH > 0) ? tune.FTH : 16;
+            A.CTH = (tune.CTH > 0) ? tune.CTH : 8;
+            A.TAIL = (tune.TAIL > 0) ? tune.TAIL : 0;
+        } else if (e != hipErrorNotSupported) {
+            return e;
+        }
+    }
+    if (!A.LT && (A.T > 512 || A.P > SOC_BRICK_PMAX || A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS))) return hipErrorInvalidValue;
+    if (A.LT) {
+        // set above
+    } else
     if (V.octree) {
         if (G.LEVELS > 15) return hipErrorNotSupported;                  // the level shares a packet word with slot and launch
         BCHK(soc_oct_build(device, G, A.CAP, st, tune.verbose != 0));
@@ -1219,14 +1748,15 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     // launches with the INT tally: brick queues per launch, so that a workgroup's LDS tallies belong to one launch
     A.NBQ = (V.wint && K.n > 1) ? A.NB * K.n : A.NB;
     if ((long long)A.NB * K.n > (1 << 20)) return hipErrorNotSupported;
-    const int NQ = A.NBQ + 2 * K.n + 1;
+    const int NQ = A.NBQ + A.EQ * K.n + 1;
     // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
     // order, as earlier ones finish.  Queues, descriptors and the grids of the passes are sized for that many.
     if (population < 0) {
         // measured: about 5300 packets per brick on Cartesian grids (C2, 512 bricks: 2.7e6 -> 8.5e8 packets/s, 2.1e6 and
         // 3.1e6 -> 8.1e8; 256^3, 4096 bricks: 2.6e7 -> 1.09e11 steps/s, 2.7e6 -> 8.1e10), 2.6e7 on the 256^3-root
         // hierarchy (1.3e7 -> 3.7e10 steps/s, 5.0e7 -> 4.0e10)
-        const long long p = V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
+        // brick-local hierarchies: 1e8 (256^3 roots, 4 levels, 11.5e3 bricks: 5.0e7 -> 5.4e10 steps/s, 1.0e8 -> 5.7e10)
+        const long long p = A.LT ? 100000000LL : V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
         population = (int)std::min(p, 2000000000LL);
     }
     if (tune.POP > 0) population = tune.POP;
@@ -1268,7 +1798,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
+    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 3 * SOC_MAXLAUNCH + SOC_MAXL + 3 + SOC_MAXLAUNCH + 1) * 4
+                                 : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
     if (lds > 160 * 1024) return hipErrorNotSupported;
@@ -1282,7 +1813,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     }
     if (all_bg && !tune.nolean) kind = 3;               // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
-    const int nev = ((int)((live + A.P - 1) / A.P) + 3 * K.n) * slices;
+    const int nev = ((int)((live + A.P - 1) / A.P) + (A.EQ + 1) * K.n) * slices;
 
     BCHK(hipMemcpyAsync(bb.pack, &K, sizeof(SocSimPack), hipMemcpyHostToDevice, st));
     BCHK(hipStreamSynchronize(st));                                   // K is on this stack
@@ -1295,7 +1826,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (!V.octree)   soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            if (A.LT)        soc_lbrick_launch_pass(V.wint, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
@@ -1310,5 +1842,6 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (passes > 4000000) return hipErrorUnknown;                 // cannot happen: every pass retires work
     }
     if (passes_out) *passes_out = passes;
+    if (form_out) *form_out = A.LT ? 3 : (V.octree ? 2 : 1);
     return hipSuccess;
 }

@@ -79,7 +79,7 @@ struct soc_ctx {
     // features
     int with_int = 0, ps_method = 0, use_emweight = 0, mirror = 0;
     // execution
-    int exec_mode = -1, brick_log2 = 4, last_passes = 0;
+    int exec_mode = -1, brick_log2 = 4, last_passes = 0, last_form = 0;
     SocBrickTune tune{};
     // equilibrium temperature / emission (soc_emit.hip)
     float *dT = nullptr, *dTTT = nullptr, *dEbuf = nullptr, *dEF = nullptr;
@@ -159,7 +159,7 @@ static int flush_pending(soc_ctx *c)
         return SOC_OK;
     }
     // packets in flight: chosen by the sweep from the number of bricks (-1)
-    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
+    hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form);
     if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep of %d deferred launches failed: %s", (int)todo.size(), hipGetErrorString(e));
     return SOC_OK;
 }
@@ -354,7 +354,8 @@ int soc_set_tuning(soc_ctx *c, const char *name, int value)
     struct { const char *n; int *p; } tab[] = {
         { "threads", &c->tune.T }, { "chunk", &c->tune.P }, { "steps_per_visit", &c->tune.KCAP }, { "swap_lanes", &c->tune.FTH },
         { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "population", &c->tune.POP },
-        { "hash_slots", &c->tune.HS }, { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
+        { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every }, { "lean_step", &c->tune.lean_step },
+        { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
     for (auto &t : tab)
         if (!strcmp(name, t.n)) {
             if (t.p == &c->tune.CAP && value != c->tune.CAP) soc_brick_invalidate(c->device);
@@ -365,6 +366,7 @@ int soc_set_tuning(soc_ctx *c, const char *name, int value)
 }
 
 int soc_last_passes(soc_ctx *c) { return c ? c->last_passes : 0; }
+int soc_last_form(soc_ctx *c) { return (c && c->last_passes > 0) ? c->last_form : 0; }
 
 int soc_set_optical(soc_ctx *c, const float *ABS, const float *SCA, int ndust)
 {
@@ -703,7 +705,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -939,7 +941,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }
@@ -1004,7 +1006,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return SOC_OK;
     }
     if (bricks) {
-        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes);
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &S, 1, V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form);
         if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "brick sweep failed: %s", hipGetErrorString(e));
         return SOC_OK;
     }

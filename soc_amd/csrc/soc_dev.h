@@ -149,6 +149,9 @@ hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
 // soc_set_tuning (include/soc_hip.h); the parity tests use small CAP / HS values to exercise brick boundaries.
 struct SocBrickTune {
     int T, P, KCAP, FTH, CTH, CAP, TAIL, POP, HS;
+    int global_tree;           // hierarchies: the walk that reads the hierarchy from global memory, also where brick-local ones apply
+    int lean_step;             // brick-local hierarchies, experiment: fewer kinds of moves settled in the step arm
+    int slow_every;            // brick-local hierarchies, test knob: every n-th step below the root grid goes through the slow-step queue
     int nolean;                // keep the general SimRAM_PB kernel for background-only sweeps
     int oversub;               // experiment: background work items beyond 8*AREA are not clipped
     int verbose;
@@ -158,7 +161,7 @@ struct SocBrickTune {
 // population: packets in flight (0 = all work items at once, -1 = chosen from the number of bricks): the other work
 // items are admitted as earlier ones finish
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *S, int nlaunch, const SocVariant &V, int LB,
-                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out);
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out);
 void soc_brick_release(int device);
 void soc_brick_invalidate(int device);      // the grid changed: bricks of a hierarchy are rebuilt at the next sweep
 

@@ -29,6 +29,7 @@ API = {
     "soc_set_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _I, _F]),
     "soc_set_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "soc_set_exec": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "soc_last_form": (C.c_int, [C.c_void_p]),
     "soc_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "soc_last_passes": (C.c_int, [C.c_void_p]),
     "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
@@ -203,6 +204,10 @@ class Engine:
     def set_exec(self, mode=-1, brick_log2=4):
         """0 direct kernel, 1 brick sweep (LDS tallies), -1 automatic."""
         self._chk(self.lib.soc_set_exec(self.h, int(mode), int(brick_log2)))
+
+    def last_form(self):
+        """0 direct kernel, 1 brick sweep (Cartesian), 2 hierarchy in global memory, 3 brick-local hierarchies"""
+        return int(self.lib.soc_last_form(self.h))
 
     def set_tuning(self, **params):
         """shape of the brick sweep (soc_set_tuning): threads, chunk, steps_per_visit, swap_lanes, climb_lanes,

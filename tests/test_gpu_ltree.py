@@ -1,0 +1,142 @@
+"""The walk on brick-local hierarchies (soc_lbrick_walk, soc_ltree.h) on the GPU: hierarchies whose Index() the reference
+evaluates in double (NX > 100, >= 3 levels).  Same bar as the other sweeps: identical trajectories (tally-event counts
+equal to the oracle's), tallies equal to fp32 summation order; plus the older form of the sweep (`global_tree`) as a
+second witness and the slow-step queue forced on every few steps."""
+import numpy as np
+import pytest
+
+import cases
+from oracle.pyoracle import Job
+from soc_amd import synth
+from util import assert_tally_close, run_engine
+
+pytestmark = pytest.mark.gpu
+
+_CLOUD = {}
+
+
+def cloud104():
+    if "c" not in _CLOUD:
+        _CLOUD["c"] = synth.octree_cloud(104, levels=4, frac=0.08, seed=3)
+    return _CLOUD["c"]
+
+
+kw_form = {}
+
+
+def _sweep(engine, job, kind, **kw):
+    T, I, st = run_engine(engine, job, kind, exec_mode=1, **kw)
+    assert engine.last_passes() > 0
+    assert engine.last_form() == kw_form.get("form", 3)
+    return T, I, st
+
+
+@pytest.mark.parametrize("tune", [dict(), dict(brick_cells=700), dict(slow_every=3), dict(steps_per_visit=3, hash_slots=64),
+                                  dict(brick_cells=12288, threads=1024), dict(chunk=64, threads=64)])
+def test_background_packets(tune, engine, oracle_soc, tuned):
+    cl = cloud104()
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=4, SEED=0.377)
+    g0, g1 = 100000, 106000
+    T, _, n = oracle_soc.sim(job, 0, gid0=g0, gid1=g1, nthreads=8)
+    tuned(**tune)
+    Tg, _, st = _sweep(engine, job, 0, gid_first=g0, gid_count=g1 - g0)
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_older_sweep_is_a_second_witness(engine, tuned):
+    cl = cloud104()
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=2, SEED=0.91)
+    g0, g1 = 0, 40000
+    Ta, _, sa = _sweep(engine, job, 0, gid_first=g0, gid_count=g1 - g0)
+    tuned(global_tree=1)
+    kw_form["form"] = 2
+    try:
+        Tb, _, sb = _sweep(engine, job, 0, gid_first=g0, gid_count=g1 - g0)
+    finally:
+        kw_form.clear()
+    assert sa["tally_events"] == sb["tally_events"] and sa["packets"] == sb["packets"] and sa["scatterings"] == sb["scatterings"]
+    assert_tally_close(Ta, Tb, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("slow", [0, 5])
+def test_point_sources_inside_and_outside(slow, engine, oracle_soc, tuned):
+    cl = cloud104()
+    ps = np.array([[52.3, 51.7, 50.2], [52.0, 52.0, 300.0]], np.float32)
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=0, BATCH=30, SEED=0.2, GLOBAL=512, PSPOS=ps, PS=[1.0, 2.5], PS_METHOD=0,
+              WITH_INT=1, TW=1.5)
+    T, I, n = oracle_soc.sim(job, 0, nthreads=8)
+    tuned(slow_every=slow)
+    Tg, Ig, st = _sweep(engine, job, 0)
+    assert st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    assert_tally_close(Ig, I, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("emw", [0, 1])
+def test_cell_emission(emw, engine, oracle_soc, tuned):
+    """SimRAM_CL: without emission weights packets also start "in" refined cells (kernel_ASOC.c:1318-1355)"""
+    cl = cloud104()
+    emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+    emwei = np.random.default_rng(5).uniform(0, 2.5, cl.CELLS).astype(np.float32) if emw else None
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=2, BATCH=1, SEED=0.9, GLOBAL=8192, EMIT=emit, EMWEI=emwei, USE_EMWEIGHT=emw)
+    g0, g1 = 4000, 4096
+    T, _, n = oracle_soc.sim(job, 1, gid0=g0, gid1=g1, nthreads=8)
+    tuned(slow_every=7)
+    Tg, _, st = _sweep(engine, job, 1, gid_first=g0, gid_count=g1 - g0)
+    assert st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_healpix_background(engine, oracle_soc):
+    cl = cloud104()
+    sky, P = cases.hp_sky(weighted=True)
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=8, SEED=0.11, GLOBAL=4096, HPBG=sky, HPBGP=P, TW=1.2)
+    T, _, n = oracle_soc.sim(job, 2, nthreads=8)
+    Tg, _, st = _sweep(engine, job, 2)
+    assert st["tally_events"] == n
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
+def test_deferred_launches_with_and_without_int(engine, oracle_soc):
+    """several launches in one sweep (soc_batch_begin) and with their own INT tallies (soc_batch_begin_int)"""
+    cl = cloud104()
+    d6, csc6 = synth.hg_scattering_table(0.6)
+    d1, csc1 = synth.hg_scattering_table(0.1)
+    jobs = [Job(cl, csc6, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=2, SEED=0.377, TW=1.0),
+            Job(cl, csc1, ABS=1e-6, SCA=6e-5, SOURCE=1, BATCH=3, SEED=0.52, TW=0.5, BG=2.0)]
+    g0, g1 = 200000, 203000
+    want = np.zeros(cl.CELLS, np.float32)
+    ints, n = [], 0
+    for j in jobs:
+        j.WITH_INT = 1
+        T, I, k = oracle_soc.sim(j, 0, gid0=g0, gid1=g1, nthreads=8)
+        want += T
+        ints.append(I)
+        n += k
+    for keep_int in (0, 1):
+        e = engine
+        e.set_cloud(cl)
+        e.set_features(with_int=keep_int, ps_method=0, use_emweight=0)
+        e.set_opt(None)
+        e.set_exec(1, 4)
+        e.zero(0)
+        e.stats(reset=True)
+        (e.batch_begin_int if keep_int else e.batch_begin)(4)
+        for j in jobs:
+            e.set_scatter_table(j.DSC, j.CSC)
+            e.set_optical(j.ABS, j.SCA)
+            e.sim_pb(1, 0, j.BATCH, j.SEED, j.BG, j.TW, GLOBAL=j.GLOBAL, gid_first=g0, gid_count=g1 - g0)
+        e.batch_end()
+        st = e.stats()
+        assert e.last_passes() > 0 and e.last_form() == 3 and st["tally_events"] == n
+        assert_tally_close(e.read_tally(0), want, rtol=1e-5)
+        if keep_int:
+            for k, I in enumerate(ints):
+                assert_tally_close(e.batch_read_int(k), I, rtol=1e-5)
+    engine.set_exec(-1, 4)

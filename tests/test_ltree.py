@@ -133,19 +133,13 @@ def test_local_tree_steps_are_the_oracles_steps(name, cap, oracle_soc):
 def test_bricks_partition_the_hierarchy_under_sanitizers():
     """rectangular root grid that is not a multiple of the 16-cell tile, a clustered hierarchy, small caps"""
     lib = _harness(sanitize=True)
-    env_ok = True
-    try:
-        C.CDLL(lib)
-    except OSError:                       # libasan must be preloaded when the host process is not instrumented
-        env_ok = False
-    if not env_ok:
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-                "import tests.test_ltree as T\nT._sanitized_body(%r)\n" % (REPO, HERE, lib))
-        asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"]).decode().strip()
-        env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
-        subprocess.check_call(["python3", "-c", code], env=env, cwd=REPO)
-    else:
-        _sanitized_body(lib)
+    # the sanitizer runtime must come first in the process: a child python with libasan preloaded
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_ltree as T\nT._sanitized_body(%r)\nprint('sanitized ok')\n" % (REPO, HERE, lib))
+    asan = subprocess.check_output(["g++", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run(["python3", "-c", code], env=env, cwd=REPO, capture_output=True, text=True)
+    assert out.returncode == 0 and "sanitized ok" in out.stdout, out.stderr[-3000:]
 
 
 def _sanitized_body(lib):
