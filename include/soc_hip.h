@@ -41,7 +41,10 @@ void soc_destroy(soc_ctx *ctx);
 const char *soc_last_error(const soc_ctx *ctx);   /* ctx may be NULL: last creation error */
 const char *soc_version(void);
 
-/* run on an externally owned HIP stream (e.g. the stream of the caller's framework); NULL = own stream */
+/* run on an externally owned HIP stream (e.g. the stream of the caller's framework); NULL = own stream.
+ * NOTE: a framework's "default stream" is the null handle too -- pass a stream the framework created
+ * (torch.cuda.Stream().cuda_stream) and make it the current one, or the collectives of the framework
+ * are not ordered with the kernels (soc_amd/dist.py does that). */
 int soc_set_stream(soc_ctx *ctx, void *hip_stream);
 
 /* replaces the -D NX,NY,NZ,LEVELS,CELLS macros (ASOC.py:344-362), the LCELLS/OFF/DENS
@@ -188,9 +191,11 @@ int soc_read_tally(soc_ctx *ctx, int which, float *out, int64_t n);
 int soc_write_tally(soc_ctx *ctx, int which, const float *in, int64_t n);
 
 /* device address of a tally (for an RCCL all-reduce by the caller), or bind caller-owned
- * device memory (CELLS floats) as the tally so a framework tensor can be reduced in place */
+ * device memory (n = CELLS floats, checked) as the tally so a framework tensor can be reduced in place;
+ * device_ptr = NULL gives the tally back to memory of the library.  A grid with another cell count cannot
+ * be set while a caller-owned tally is bound. */
 void *soc_tally_ptr(soc_ctx *ctx, int which);
-int   soc_bind_tally(soc_ctx *ctx, int which, void *device_ptr);
+int   soc_bind_tally(soc_ctx *ctx, int which, void *device_ptr, int64_t n);
 
 /* PAR table computed by soc_set_grid (CELLS - NX*NY*NZ entries), for verification */
 int soc_read_par(soc_ctx *ctx, int32_t *out, int64_t n);
@@ -254,7 +259,7 @@ int soc_sca_sim_hp(soc_ctx *ctx, int PACKETS, int BATCH, float SEED, int GLOBAL,
 int soc_sca_read_out(soc_ctx *ctx, float *out, int64_t n);
 
 /* device address of the image, or bind caller-owned device memory as the image (for an RCCL
- * all-reduce over the GPUs that shared a launch) */
+ * all-reduce over the GPUs that shared a launch); NULL gives the image back to memory of the library */
 void *soc_sca_out_ptr(soc_ctx *ctx);
 int   soc_sca_bind_out(soc_ctx *ctx, void *device_ptr);
 
@@ -312,6 +317,16 @@ int soc_a2e_download(soc_ctx *ctx, int batch, float *AEMIT);
 int soc_a2e_eqtemp(soc_ctx *ctx, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
                    float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
                    const float *ABS, float *T, float *EMIT);
+
+/* ---- equilibrium dust components of a multi-dust run: A2E_MABU.py / kernel_eqsolver.c ---- */
+
+/* replaces kernel_T(...) + the per-frequency kernel_emission(...) launches of SolveEquilibriumDust for one batch of cells
+ * (A2E_MABU.py:520-560,608 -> kernel_eqsolver.c EqTemperature :5-62, Emission :66-79): ABS is [batch*NFREQ], the share of
+ * the absorptions taken by this dust component (split_absorbed, kernel_A2E_MABU_aux.c:3-23, is done on the host side of
+ * soc_amd/driver.py); TTT holds NE temperatures; outputs T[batch] and EMIT[batch*NFREQ] per unit density and abundance */
+int soc_eqsolver(soc_ctx *ctx, int batch, int icell, int CELLS, int NFREQ, int NE, float FACTOR, float kE,
+                 float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
+                 const float *ABS, float *T, float *EMIT);
 
 /* ---- verification probes (used by the parity tests only) ---- */
 /* RNG stream states and first draws of logical work items [gid_first, gid_first+n)

@@ -105,3 +105,31 @@ EXPORT void orc_a2e_eqtemp(int batch, int icell, int CELLS, int NFREQ, int NIP, 
         }
     }
 }
+
+/* kernel_eqsolver.c (A2E_MABU.py SolveEquilibriumDust, :436-640): equilibrium temperature of one dust component
+ * from its share of the absorptions, EqTemperature :5-62 -- Ein by trapezoid with the end intervals counted once,
+ * lookup with 0.5*Ein (beta = 1), T = 2.7 for cells without absorbed energy -- and Emission :66-79 for every
+ * frequency (non-finite values -> 0).  -D CELLS/NFREQ/FACTOR (A2E_MABU.py:492) are arguments; CR_HEATING = 0. */
+EXPORT void orc_eqsolver(int batch, int icell, int CELLS, int NFREQ, int NE, float FACTOR, float kE, float oplgkE, float Emin,
+                         const float *FREQ, const float *KABS, const float *TTT, const float *ABS, float *T, float *EMIT)
+{
+    for (int id = 0; id < batch; id++) {
+        int ind = icell + id, iE;
+        if (ind >= CELLS) continue;
+        const float scale = 6.62607e-27f;
+        float wi, beta = 1.0f, Ein = 0.0f, TP;
+        const float *A = ABS + (size_t)id * NFREQ;
+        Ein += A[0] * FREQ[0] * scale * (FREQ[1] - FREQ[0]);
+        Ein += A[NFREQ - 1] * FREQ[NFREQ - 1] * scale * (FREQ[NFREQ - 1] - FREQ[NFREQ - 2]);
+        for (int i = 1; i < (NFREQ - 1); i++) Ein += A[i] * FREQ[i] * scale * (FREQ[i + 1] - FREQ[i - 1]);
+        iE = clampi((int)M_FLOOR(oplgkE * M_LOG10((0.5f * Ein / beta) / Emin)), 0, NE - 2);
+        wi = (Emin * M_POWN(kE, iE + 1) - (Ein / beta)) / (Emin * M_POWN(kE, iE + 1) - M_POWN(kE, iE));
+        TP = wi * TTT[iE] + (1.0 - wi) * TTT[iE + 1];
+        if (Ein <= 0.0f) TP = 2.7f;
+        T[id] = TP;
+        for (int f = 0; f < NFREQ; f++) {
+            const float res = (2.79639459e-20f * FACTOR) * KABS[f] * (FREQ[f] * FREQ[f] / (M_EXP(4.7995074e-11f * FREQ[f] / TP) - 1.0f));
+            EMIT[(size_t)id * NFREQ + f] = isfinite(res) ? res : 0.0f;
+        }
+    }
+}

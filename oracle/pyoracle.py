@@ -456,6 +456,21 @@ def a2e_oracle_eqtemp(orc, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KA
     return T, E
 
 
+def oracle_eqsolver(orc, icell, CELLS, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+    """kernel_eqsolver.c EqTemperature + Emission (orc_eqsolver): ABS[batch, NFREQ] -> T[batch], EMIT[batch, NFREQ]"""
+    L = orc.lib
+    L.orc_eqsolver.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                               C.c_float, _F, _F, _F, _F, _F, _F]
+    ABS = np.ascontiguousarray(ABS, np.float32)
+    batch, NFREQ = ABS.shape
+    T = np.zeros(batch, np.float32)
+    E = np.zeros((batch, NFREQ), np.float32)
+    FREQ, KABS, TTT = (np.ascontiguousarray(a, np.float32) for a in (FREQ, KABS, TTT))
+    L.orc_eqsolver(batch, icell, CELLS, NFREQ, NE, np.float32(FACTOR), np.float32(kE), np.float32(oplgkE),
+                   np.float32(Emin), _fp(FREQ), _fp(KABS), _fp(TTT), _fp(ABS), _fp(T), _fp(E))
+    return T, E
+
+
 class RefA2E:
     """x86 build of kernel_A2E.c for one (NE, NFREQ, LOCAL, CELLS, NIP): oracle/_ref/refa2e_<tag>.so"""
 

@@ -112,6 +112,40 @@ __global__ void soc_a2e_eqtemp_kernel(const SocEqTArgs A)
     }
 }
 
+// kernel_eqsolver.c (A2E_MABU.py SolveEquilibriumDust): EqTemperature :5-62 and Emission :66-79 of one equilibrium
+// dust component, one lane per cell (A.NIP carries the number of table entries NE)
+__global__ void soc_eqsolver_kernel(const SocEqTArgs A)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= A.batch) return;
+    if (A.icell + id >= A.CELLS) return;
+    const float *a = A.ABS + (size_t)id * A.NFREQ;
+    const int   NF = A.NFREQ;
+    const float scale = 6.62607e-27f;
+    float Ein = 0.0f;
+    Ein += a[0] * A.FREQ[0] * scale * (A.FREQ[1] - A.FREQ[0]);
+    Ein += a[NF - 1] * A.FREQ[NF - 1] * scale * (A.FREQ[NF - 1] - A.FREQ[NF - 2]);
+    for (int i = 1; i < NF - 1; i++) Ein += a[i] * A.FREQ[i] * scale * (A.FREQ[i + 1] - A.FREQ[i - 1]);
+    int iE = (int)soc_floorf(A.oplgkE * soc_log10f((0.5f * Ein / 1.0f) / A.Emin));
+    iE = iE < 0 ? 0 : (iE > A.NIP - 2 ? A.NIP - 2 : iE);
+    const float wi = (A.Emin * soc_pownf(A.kE, iE + 1) - (Ein / 1.0f)) / (A.Emin * soc_pownf(A.kE, iE + 1) - soc_pownf(A.kE, iE));
+    float TP = (float)((double)(wi * A.TTT[iE]) + (1.0 - (double)wi) * (double)A.TTT[iE + 1]);
+    if (Ein <= 0.0f) TP = 2.7f;
+    A.T[id] = TP;
+    for (int f = 0; f < NF; f++) {
+        const float fr = A.FREQ[f];
+        const float res = (2.79639459e-20f * A.FACTOR) * A.KABS[f] * (fr * fr / (soc_expf(4.7995074e-11f * fr / TP) - 1.0f));
+        A.EMIT[(size_t)id * NF + f] = (res - res == 0.0f) ? res : 0.0f;          // isfinite
+    }
+}
+
+hipError_t soc_launch_eqsolver(const SocEqTArgs &A, hipStream_t st)
+{
+    if (A.batch <= 0) return hipSuccess;
+    soc_eqsolver_kernel<<<(A.batch + 255) / 256, 256, 0, st>>>(A);
+    return hipGetLastError();
+}
+
 hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st)
 {
     if (A.batch <= 0) return hipSuccess;

@@ -131,6 +131,17 @@ static size_t view_pixels(const soc_ctx *c)
     return (size_t)c->view.NDIR * c->view.NPIX_X * c->view.NPIX_Y;
 }
 
+// Hierarchies on which the brick sweep keeps the brick's cells in LDS (soc_brick.hip, soc_ltree.h): there a lone
+// launch with enough work items pays too -- also with the INT tally, which lives in LDS beside TABS.
+static bool lt_capable(const soc_ctx *c, bool abu)
+{
+    const SocGrid &G = c->G;
+    const int n = G.NX > G.NY ? (G.NX > G.NZ ? G.NX : G.NZ) : (G.NY > G.NZ ? G.NY : G.NZ);
+    return G.LEVELS > 1 && G.LEVELS <= 8 && G.NX > ((G.LEVELS < 3) ? 399 : 100) && !abu && !c->tune.global_tree
+           && (((long long)n << (G.LEVELS - 1)) < (1LL << 24));
+}
+#define SOC_LT_LONE_LAUNCH 1000000                           // work items from which a lone launch goes to the sweep there
+
 // Execute the launches deferred since soc_batch_begin: one brick sweep for all of them.
 static int flush_pending(soc_ctx *c)
 {
@@ -142,7 +153,7 @@ static int flush_pending(soc_ctx *c)
     V.abu = todo[0].OPT != nullptr;                          // what makes a launch deferrable (see soc_sim_pb)
     V.wint = (c->batch_keep_int && c->with_int) ? 1 : 0;
     HIPCHK(c, hipSetDevice(c->device));
-    if (V.octree && todo.size() == 1 && c->exec_mode < 0) {
+    if (V.octree && todo.size() == 1 && c->exec_mode < 0 && !(lt_capable(c, V.abu != 0) && todo[0].gid_count >= SOC_LT_LONE_LAUNCH)) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
         c->last_passes = 0;
         if (todo[0].SOURCE == SOC_SOURCE_HP) {
@@ -291,8 +302,10 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
     HIPCHK(c, hipMemsetAsync(c->dPAR, 0, (size_t)(c->npar ? c->npar : 1) * 4, c->stream));
     G.DENS = c->dDENS;
     G.PAR = c->dPAR;
+    if (c->have_grid && (int64_t)G.CELLS != c->G.CELLS && ((c->dTABS && !c->own_TABS) || (c->dINT && !c->own_INT)))
+        return fail(c, SOC_ERR_STATE, "soc_set_grid: a caller-owned tally of %d cells is bound; soc_bind_tally(ctx, which, NULL, 0) first, re-bind after", c->G.CELLS);
     if ((int64_t)G.CELLS != c->G.CELLS || !c->have_grid) {
-        // tallies follow the cell count (unless the caller bound its own memory)
+        // tallies follow the cell count
         if (c->own_TABS || !c->dTABS) { c->dTABS = nullptr; HIPCHK(c, dev_alloc(&c->dTABS, (size_t)cells)); c->own_TABS = true; HIPCHK(c, hipMemsetAsync(c->dTABS, 0, (size_t)cells * 4, c->stream)); }
         if (c->own_INT || !c->dINT) { c->dINT = nullptr; HIPCHK(c, dev_alloc(&c->dINT, (size_t)cells)); c->own_INT = true; HIPCHK(c, hipMemsetAsync(c->dINT, 0, (size_t)cells * 4, c->stream)); }
         if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
@@ -677,7 +690,8 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
@@ -915,7 +929,8 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
-    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
+    if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
     const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
@@ -974,7 +989,8 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
-    if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8 && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)));
+    if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
     const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
@@ -1220,12 +1236,19 @@ int soc_sca_bind_out(soc_ctx *c, void *device_ptr)
     if (!c) return SOC_ERR_ARG;
     FLUSH(c);
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_bind_out: call soc_sca_set_view first");
-    if (!device_ptr) return fail(c, SOC_ERR_ARG, "soc_sca_bind_out: NULL pointer");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->own_OUT && c->dOUT) (void)hipFree(c->dOUT);
-    c->dOUT = (float *)device_ptr;
-    c->own_OUT = false;
+    c->dOUT = nullptr;
+    if (device_ptr) {
+        c->dOUT = (float *)device_ptr;
+        c->own_OUT = false;
+    } else {                                                // back to memory of the library
+        const size_t npix = view_pixels(c);
+        HIPCHK(c, dev_alloc(&c->dOUT, npix));
+        c->own_OUT = true;
+        HIPCHK(c, hipMemsetAsync(c->dOUT, 0, npix * 4, c->stream));
+    }
     return SOC_OK;
 }
 
@@ -1266,19 +1289,27 @@ int soc_write_tally(soc_ctx *c, int which, const float *in, int64_t n)
 
 void *soc_tally_ptr(soc_ctx *c, int which) { return c ? (void *)tally_buf(c, which) : nullptr; }
 
-int soc_bind_tally(soc_ctx *c, int which, void *device_ptr)
+int soc_bind_tally(soc_ctx *c, int which, void *device_ptr, int64_t n)
 {
     if (!c) return SOC_ERR_ARG;
     FLUSH(c);
-    if (!device_ptr || (which != SOC_TALLY_TABS && which != SOC_TALLY_INT)) return fail(c, SOC_ERR_ARG, "soc_bind_tally: which=%d ptr=%p", which, device_ptr);
+    if (which != SOC_TALLY_TABS && which != SOC_TALLY_INT) return fail(c, SOC_ERR_ARG, "soc_bind_tally: which=%d", which);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_bind_tally: call soc_set_grid first (the tally has CELLS elements)");
+    if (device_ptr && n != (int64_t)c->G.CELLS)
+        return fail(c, SOC_ERR_ARG, "soc_bind_tally: the buffer holds %lld floats, the grid has %d cells", (long long)n, c->G.CELLS);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (which == SOC_TALLY_TABS) {
-        if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
-        c->dTABS = (float *)device_ptr; c->own_TABS = false;
-    } else {
-        if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
-        c->dINT = (float *)device_ptr; c->own_INT = false;
+    float **buf = (which == SOC_TALLY_TABS) ? &c->dTABS : &c->dINT;
+    bool  *own = (which == SOC_TALLY_TABS) ? &c->own_TABS : &c->own_INT;
+    if (*own && *buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    if (device_ptr) {
+        *buf = (float *)device_ptr;
+        *own = false;
+    } else {                                                // back to memory of the library
+        HIPCHK(c, dev_alloc(buf, (size_t)c->G.CELLS));
+        *own = true;
+        HIPCHK(c, hipMemsetAsync(*buf, 0, (size_t)c->G.CELLS * 4, c->stream));
     }
     return SOC_OK;
 }
@@ -1556,14 +1587,14 @@ int soc_a2e_solve(soc_ctx *c, int batch, const float *AABS, float *AEMIT)
     return soc_a2e_download(c, batch, AEMIT);
 }
 
-int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
+static int eqtemp_common(soc_ctx *c, const char *who, bool eqsolver, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
                    float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
                    const float *ABS, float *T, float *EMIT)
 {
     if (!c) return SOC_ERR_ARG;
     FLUSH(c);
     if (batch < 1 || NFREQ < 2 || NIP < 2 || !FREQ || !KABS || !TTT || !ABS || !T || !EMIT)
-        return fail(c, SOC_ERR_ARG, "soc_a2e_eqtemp: bad arguments");
+        return fail(c, SOC_ERR_ARG, "%s: bad arguments", who);
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr;
     const size_t n = (size_t)2 * NFREQ + NIP + (size_t)2 * batch * NFREQ + batch;
@@ -1578,13 +1609,27 @@ int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int N
     A.batch = batch;  A.icell = icell;  A.CELLS = CELLS;  A.NFREQ = NFREQ;  A.NIP = NIP;
     A.FACTOR = FACTOR;  A.kE = kE;  A.oplgkE = oplgkE;  A.Emin = Emin;
     A.FREQ = dF;  A.KABS = dK;  A.TTT = dT3;  A.ABS = dA;  A.T = dT;  A.EMIT = dE;
-    if (e == hipSuccess) e = soc_launch_a2e_eqtemp(A, c->stream);
+    if (e == hipSuccess) e = eqsolver ? soc_launch_eqsolver(A, c->stream) : soc_launch_a2e_eqtemp(A, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(T, dT, (size_t)batch * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(EMIT, dE, (size_t)batch * NFREQ * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_a2e_eqtemp: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
     return SOC_OK;
+}
+
+int soc_a2e_eqtemp(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int NIP, float FACTOR, float kE,
+                   float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
+                   const float *ABS, float *T, float *EMIT)
+{
+    return eqtemp_common(c, "soc_a2e_eqtemp", false, batch, icell, CELLS, NFREQ, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS, T, EMIT);
+}
+
+int soc_eqsolver(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int NE, float FACTOR, float kE,
+                 float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
+                 const float *ABS, float *T, float *EMIT)
+{
+    return eqtemp_common(c, "soc_eqsolver", true, batch, icell, CELLS, NFREQ, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS, T, EMIT);
 }
 
 // ---------------------------------------------------------------------------------------

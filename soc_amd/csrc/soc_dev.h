@@ -144,6 +144,7 @@ struct SocEqTArgs {
 
 hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st);
 hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st);
+hipError_t soc_launch_eqsolver(const SocEqTArgs &A, hipStream_t st);
 
 // Shape of the brick sweep; 0 = the built-in choice for the grid (measured).  Set per context with
 // soc_set_tuning (include/soc_hip.h); the parity tests use small CAP / HS values to exercise brick boundaries.

@@ -23,6 +23,7 @@ class Comm:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = None
         self._tensors = {}
+        self._stream = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -43,16 +44,27 @@ class Comm:
         """(first, count) of the logical work items this rank executes."""
         return shard_range(GLOBAL, self.rank, self.world)
 
+    def _engine_stream(self, engine):
+        """The engine runs on a stream torch created, and that stream is torch's current one: c10d orders its
+        collective behind the current stream and the current stream behind the collective, so tally kernels,
+        all-reduce and read-back run in program order.  (torch's default stream has the null handle, which
+        soc_set_stream reads as "the engine's own stream" -- a stream no collective is ordered with.)"""
+        t = self.torch
+        if self._stream is None:
+            self._stream = t.cuda.Stream()
+            t.cuda.set_stream(self._stream)
+        engine.set_stream(self._stream.cuda_stream)
+
     def attach(self, engine, cells):
-        """RCCL path: make the engine's tallies torch tensors so they are reduced in place and
-        run the kernels on torch's current stream (ordering with the collective)."""
+        """RCCL path: make the engine's tallies torch tensors so they are reduced in place, on a stream
+        shared with torch (see _engine_stream)."""
         if self.world > 1 and self.backend == "nccl":
             t = self.torch
+            self._engine_stream(engine)
             for which in (0, 1):
                 buf = t.zeros(cells, dtype=t.float32, device="cuda")
-                engine.bind_tally(which, buf.data_ptr())
+                engine.bind_tally(which, buf.data_ptr(), cells)
                 self._tensors[which] = buf
-            engine.set_stream(t.cuda.current_stream().cuda_stream)
 
     def all_reduce_tally(self, engine, which):
         """Sum tally `which` over all ranks (result on every rank)."""
@@ -83,10 +95,10 @@ class Comm:
         """Same for the scattered-light image OUT[NDIR*NPIX_Y*NPIX_X]."""
         if self.world > 1 and self.backend == "nccl":
             t = self.torch
+            self._engine_stream(engine)
             buf = t.zeros(npix, dtype=t.float32, device="cuda")
             engine.sca_bind_out(buf.data_ptr())
             self._tensors["out"] = buf
-            engine.set_stream(t.cuda.current_stream().cuda_stream)
 
     def all_reduce_image(self, engine):
         """Sum the image over all ranks; returns it as a host array [NDIR, NPIX_Y, NPIX_X]."""

@@ -73,7 +73,7 @@ API = {
     "soc_read_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
     "soc_write_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
     "soc_tally_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),
-    "soc_bind_tally": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "soc_bind_tally": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "soc_read_par": (C.c_int, [C.c_void_p, _I, C.c_int64]),
     "soc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "soc_timer_start": (C.c_int, [C.c_void_p]),
@@ -90,6 +90,8 @@ API = {
     "soc_a2e_download": (C.c_int, [C.c_void_p, C.c_int, _F]),
     "soc_a2e_eqtemp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, _F, _F, _F, _F, _F, _F]),
+    "soc_eqsolver": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                               C.c_float, C.c_float, _F, _F, _F, _F, _F, _F]),
     "soc_probe_rng": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_int, _U, _U]),
     "soc_probe_math": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_int64]),
     "soc_probe_trace": (C.c_int, [C.c_void_p, _F, _F, C.c_int, _I, _I, _F, _F, _I]),
@@ -103,7 +105,9 @@ class SocError(RuntimeError):
 
 
 def load_library(path=None):
-    """dlopen libsoc_hip.so and declare every prototype.  Raises SocError if it is missing."""
+    """dlopen libsoc_hip.so and declare every prototype.  Raises SocError if it is missing.
+    A process that also uses torch (multi-GPU runs: soc_amd/dist.py) must import torch BEFORE this call, so that the
+    library binds to the HIP runtime torch ships; loaded the other way round, torch finds no device."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -467,7 +471,7 @@ class Engine:
         return self.lib.soc_sca_out_ptr(self.h)
 
     def sca_bind_out(self, device_ptr):
-        self._chk(self.lib.soc_sca_bind_out(self.h, C.c_void_p(device_ptr)))
+        self._chk(self.lib.soc_sca_bind_out(self.h, C.c_void_p(device_ptr) if device_ptr else None))
 
     def sync(self):
         self._chk(self.lib.soc_sync(self.h))
@@ -485,8 +489,12 @@ class Engine:
     def tally_ptr(self, which=TALLY_TABS):
         return self.lib.soc_tally_ptr(self.h, int(which))
 
-    def bind_tally(self, which, device_ptr):
-        self._chk(self.lib.soc_bind_tally(self.h, int(which), C.c_void_p(device_ptr)))
+    def bind_tally(self, which, device_ptr, n=None):
+        """caller-owned device memory (n floats, default CELLS) as tally `which`; device_ptr None/0 = back to the library's"""
+        if not device_ptr:
+            self._chk(self.lib.soc_bind_tally(self.h, int(which), None, 0))
+        else:
+            self._chk(self.lib.soc_bind_tally(self.h, int(which), C.c_void_p(device_ptr), int(self.CELLS if n is None else n)))
 
     def read_par(self):
         out = np.zeros(max(self.NPAR, 1), np.int32)
@@ -536,6 +544,18 @@ class Engine:
         out = np.zeros((batch, self._a2e_nfreq), np.float32)
         self._chk(self.lib.soc_a2e_download(self.h, int(batch), _f(out)))
         return out
+
+    def eqsolver(self, icell, CELLS, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+        """SolveEquilibriumDust of A2E_MABU.py for one batch: ABS[batch, NFREQ] -> T[batch], EMIT[batch, NFREQ]"""
+        ABS = np.ascontiguousarray(ABS, np.float32)
+        batch, NFREQ = ABS.shape
+        FREQ, KABS, TTT = (np.ascontiguousarray(a, np.float32) for a in (FREQ, KABS, TTT))
+        T = np.zeros(batch, np.float32)
+        E = np.zeros((batch, NFREQ), np.float32)
+        self._chk(self.lib.soc_eqsolver(self.h, batch, int(icell), int(CELLS), NFREQ, int(NE), np.float32(FACTOR),
+                                        np.float32(kE), np.float32(oplgkE), np.float32(Emin), _f(FREQ), _f(KABS),
+                                        _f(TTT), _f(ABS), _f(T), _f(E)))
+        return T, E
 
     def a2e_eqtemp(self, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
         ABS = np.ascontiguousarray(ABS, np.float32)

@@ -26,7 +26,10 @@ def oracle_libm():
 
 @pytest.fixture(scope="session")
 def engine():
-    """The HIP engine on cuda:0.  Fails loudly (no fallback) when the library or GPU is missing."""
+    """The HIP engine on cuda:0.  Fails loudly (no fallback) when the library or GPU is missing.
+    torch is imported first: a process that uses both must load torch's HIP runtime before libsoc_hip.so binds to one
+    (two runtimes in one process: the second sees no device) -- soc_amd/dist.py and bench.py follow the same order."""
+    import torch                                   # noqa: F401
     from soc_amd.lib import Engine
     eng = Engine(0)
     yield eng

@@ -124,7 +124,7 @@ class OracleEngine:
         b.append(np.zeros(self.cloud.CELLS, np.float32))
         return b[-1]
 
-    def bind_tally(self, which, ptr):
+    def bind_tally(self, which, ptr, n=None):
         raise NotImplementedError
 
     def set_stream(self, s):
@@ -238,11 +238,8 @@ class OracleEngine:
         pass
 
 
-class OracleA2E:
-    """the A2E entry points of soc_amd.lib.Engine on the CPU oracle (multi-process tests of soc_amd.a2e)"""
-
-    def __init__(self, mode="soc"):
-        self.orc = Oracle(mode)
+class _A2EMethods:
+    """the A2E / equilibrium-dust entry points of soc_amd.lib.Engine on the CPU oracle"""
 
     def a2e_set_size(self, NE, NFREQ, size, AF):
         self.NE, self.NFREQ, self.size, self.AF = NE, NFREQ, size, np.asarray(AF, np.float32)
@@ -254,3 +251,18 @@ class OracleA2E:
     def a2e_eqtemp(self, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
         from oracle.pyoracle import a2e_oracle_eqtemp
         return a2e_oracle_eqtemp(self.orc, icell, CELLS, NIP, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS)
+
+    def eqsolver(self, icell, CELLS, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS):
+        from oracle.pyoracle import oracle_eqsolver
+        return oracle_eqsolver(self.orc, icell, CELLS, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS)
+
+
+class OracleA2E(_A2EMethods):
+    """multi-process tests of soc_amd.a2e"""
+
+    def __init__(self, mode="soc"):
+        self.orc = Oracle(mode)
+
+
+class OraclePipelineEngine(OracleEngine, _A2EMethods):
+    """everything soc_amd.driver.Pipeline calls: the packet engine, the map kernel and the emission solvers"""

@@ -163,3 +163,30 @@ def test_gpu_a2e_sharded_program_equals_in_memory_run(engine, tmp_path):
                            os.path.join(d, "em.bin"), NSTOCH=2, verbose=False)
     want, _ = a2e.run(engine, files.read_solver(os.path.join(d, "x.solver")), ABS, NSTOCH=2, verbose=False)
     assert n == 300 and np.array_equal(files.read_absorbed(os.path.join(d, "em.bin")), want)
+
+
+@pytest.mark.gpu
+def test_eqsolver_hip_equals_oracle(engine, oracle_soc, tmp_path):
+    """kernel_eqsolver.c (equilibrium dust components of a multi-dust run): HIP == oracle, operation for operation"""
+    import os
+    from oracle.pyoracle import oracle_eqsolver
+    from soc_amd import driver
+    from soc_amd.launch import FACTOR
+    nf = 24
+    FREQ = np.logspace(np.log10(1.5e11), np.log10(2.0e15), nf)
+    dust = os.path.join(str(tmp_path), "eq.dust")
+    with open(dust, "w") as fp:
+        fp.write("eqdust\n 1.0e-7\n 1.0e-4\n%d\n" % nf)
+        for f in FREQ:
+            fp.write(" %.5e  0.5  %.5e  %.5e\n" % (f, 2.0e-2 * (f / 1e14) ** 1.2, 5.0e-2 * (f / 1e14) ** 1.5))
+    Fq, KABS, Emin, kE, oplgkE, TTT = driver.eq_dust_table(dust)
+    rng = np.random.default_rng(2)
+    ABS = (10.0 ** rng.uniform(-2, 5, (3000, nf)) * (FREQ[None, :] / 1e14) ** -1.0).astype(np.float32)
+    ABS[7, :] = 0.0                                       # no absorbed energy: T = 2.7
+    ABS[9, :] = -1.0e20                                   # a refined cell of the absorbed file
+    Tw, Ew = oracle_eqsolver(oracle_soc, 100, 3050, driver.NE_EQ, FACTOR, kE, oplgkE, Emin, Fq, KABS, TTT, ABS)
+    Tg, Eg = engine.eqsolver(100, 3050, driver.NE_EQ, FACTOR, kE, oplgkE, Emin, Fq, KABS, TTT, ABS)
+    assert Tw[7] == np.float32(2.7) and 3 < np.median(Tw) < 300
+    assert np.array_equal(Tg[:2950].view(np.uint32), Tw[:2950].view(np.uint32))
+    assert np.array_equal(Eg[:2950].view(np.uint32), Ew[:2950].view(np.uint32))
+    assert (Eg[2950:] == 0).all()                         # cells beyond CELLS are not touched

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "sca.npz"))
 
 
-def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True):
+def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True, rebind=None):
     eng.set_cloud(job.cloud)
     eng.set_features(with_int=0, ps_method=job.PS_METHOD, use_emweight=job.USE_EMWEIGHT)
     eng.set_scatter_table(job.DSC, job.CSC)
@@ -25,6 +25,8 @@ def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True):
         eng.sca_set_healpix(view.nside, view.ODIR[0, :3], view.FFS)
     else:
         eng.sca_set_view(view.ODIR, view.RA, view.DE, view.NPIX, view.MAP_DX, view.CENTRE, view.FFS)
+    if rebind:
+        eng.sca_bind_out(rebind)                 # caller-owned image (soc_sca_set_view allocates the library's)
     if zero:
         eng.sca_zero()
     eng.stats(reset=True)

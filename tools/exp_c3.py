@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--packets", type=float, default=2.5e8)
     ap.add_argument("--global0", type=int, default=4194304)
     ap.add_argument("--freq", type=int, default=30)
+    ap.add_argument("--int", dest="with_int", type=int, default=0, help="1: launches keep the per-frequency INT tally and run one at a time (read after each)")
     ap.add_argument("tunes", nargs="*")
     a = ap.parse_args()
     t0 = time.time()
@@ -48,7 +49,7 @@ def main():
     buf = (C.c_ulonglong * 16)()
     eng = Engine(0)
     eng.set_cloud(cloud)
-    eng.set_features(0, 0, 0)
+    eng.set_features(a.with_int, 0, 0)
     eng.set_emission(work["step"](1)["EMIT"], None)
     for ts in (a.tunes or ["{}"]):
         tune = json.loads(ts)
@@ -60,8 +61,11 @@ def main():
             if prof:
                 prof(buf, 1)
             eng.timer_start()
-            eng.batch_begin(min(16, a.launches))
+            if not a.with_int:
+                eng.batch_begin(min(16, a.launches))
             for k in range(a.launches):
+                if a.with_int:
+                    eng.zero(1)
                 f = (a.freq + k) % 50
                 s = work["step"](2 * f + (0 if a.kind == "ps" else 1))
                 L = dict(s["L"])
@@ -77,7 +81,10 @@ def main():
                 else:
                     Lb = launch.bg_launch(int(a.packets), cloud.AREA)
                     eng.sim_pb(1, Lb["PACKETS"], Lb["BATCH"], seed, 1e-3, s["TW"], GLOBAL=Lb["GLOBAL"])
-            eng.batch_end()
+                if a.with_int:
+                    eng.read_tally(1)
+            if not a.with_int:
+                eng.batch_end()
             ms = eng.timer_stop()
             st = eng.stats()
             print("%-60s %s rep %d: %8.1f ms  %.3e packets/s  %.3e steps/s  %.1f steps/packet  passes %d form %d" % (
