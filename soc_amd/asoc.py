@@ -210,16 +210,21 @@ class AbsorptionRun:
             # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
             # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
             deferred = (not self.with_int) and self.ROI_SAVE is None and hasattr(e, "batch_begin")   # the engine decides per launch
-            # runs that keep the per-frequency absorptions: up to 16 frequencies per batch, every launch with its own
-            # INT tally, read after the batch (one process, Cartesian grids: there the shared sweep pays)
+            # runs that keep the per-frequency absorptions, Cartesian grids: up to 16 frequencies per batch, every launch
+            # with its own INT tally, read after the batch -- and summed over the ranks then, on its way to the host array.
+            # (Hierarchies: one launch at a time; with `global` large enough each is a brick sweep of its own, the INT
+            # tally in LDS beside TABS -- DESIGN.md.)
             int_batched = (self.with_int and FABSORBED is not None and self.ROI_SAVE is None and II != 3 and c.LEVELS == 1
-                           and (self.comm is None or self.world == 1) and hasattr(e, "batch_begin_int"))
+                           and hasattr(e, "batch_begin_int"))
             group = []
 
             def end_group():
                 e.batch_end()
                 for k, f in enumerate(group):
-                    FABSORBED[:, f] += e.batch_read_int(k)
+                    arr = e.batch_read_int(k)
+                    if self.comm and self.world > 1:
+                        arr = self.comm.all_reduce_host(arr)
+                    FABSORBED[:, f] += arr
                 del group[:]
             if deferred:
                 e.batch_begin(0)
@@ -275,7 +280,7 @@ class AbsorptionRun:
                     e.sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, FF,
                              PSPOS=U.PSPOS[:max(U.NO_PS, 1), :3], PS=PS, XPS=self.XPS,
                              GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-                if self.with_int and self.comm:
+                if self.with_int and self.comm and not int_batched:
                     self.comm.all_reduce_tally(e, 1)      # one all-reduce of the per-cell buffer per frequency
                 if int_batched:
                     group.append(IFREQ)

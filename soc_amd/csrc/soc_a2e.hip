@@ -44,48 +44,91 @@ __global__ __launch_bounds__(64) void soc_a2e_dosolve_kernel(const SocA2EArgs A)
     for (int i = lane; i < NFREQ; i += 64) { sABS[i] = ABS[i];  sAF[i] = A.AF[i]; }
     __syncthreads();
 
-    // 1. heating: L[u,l] = max(sum_i ABS[i]*Iw*AF[i], 0)   (kernel_A2E.c:45-54)
-    for (int e = lane; e < A.npair; e += 64) {
-        const int i0 = A.pair_first[e], i1 = A.pair_last[e];
-        const float *w = A.Iw + A.pair_iw[e];
-        float I = 0.0f;
-        for (int i = i0; i <= i1; i++) I += sABS[i] * w[i - i0] * sAF[i];
-        L[A.pair_dst[e]] = __builtin_fmaxf(I, 0.0f);
-    }
-    __syncthreads();
-    // 2. suffix sums over the upper level, column by column (kernel_A2E.c:72-77)
-    for (int i = lane; i < NE - 2; i += 64) {
-        for (int j = NE - 3; j > i; j--) L[A2E_IND(j, i)] += L[A2E_IND(j + 1, i)];
-    }
-    __syncthreads();
-    // 3. forward substitution (kernel_A2E.c:80-88)
-    if (lane == 0) XL[0] = 1.0e-20f;
-    __syncthreads();
-    for (int j = 1; j < NE; j++) {
-        float part = 0.0f;
-        for (int i = lane; i < j; i += 64) part += L[A2E_IND(j, i)] * XL[i];
-        float x = soc_wave_sum(part);
-        x = x / (A.Tdown[j] + 1.0e-30f);
-        x = __builtin_fmaxf(x, 0.0f);
-        if (x > 1.0e20f) {                               // uniform in the wave
-            for (int i = lane; i < j; i += 64) XL[i] *= 1.0e-20f;
-            x *= 1.0e-20f;
+    // 1. heating: L[u,l] = max(sum_i ABS[i]*Iw*AF[i], 0)   (kernel_A2E.c:45-54).  Four pairs per lane at a time: their
+    //    descriptors and weights are asked for together (one wave per SIMD here: nothing else hides the latency of the
+    //    table reads); every sum runs over its own window in the reference's order.
+    for (int e0 = lane; e0 < A.npair; e0 += 256) {
+        int   i0[4], n[4], dst[4];
+        const float *w[4];
+        float I[4];
+        int   nmax = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = e0 + 64 * q;
+            const bool on = e < A.npair;
+            i0[q]  = on ? A.pair_first[e] : 0;
+            n[q]   = on ? (A.pair_last[e] - i0[q] + 1) : 0;
+            w[q]   = A.Iw + (on ? A.pair_iw[e] : 0);
+            dst[q] = on ? A.pair_dst[e] : -1;
+            I[q]   = 0.0f;
+            nmax   = n[q] > nmax ? n[q] : nmax;
         }
-        if (lane == 0) XL[j] = x;
-        __syncthreads();
+        for (int t = 0; t < nmax; t++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t < n[q]) I[q] += sABS[i0[q] + t] * w[q][t] * sAF[i0[q] + t];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (dst[q] >= 0) L[dst[q]] = __builtin_fmaxf(I[q], 0.0f);
     }
-    // normalise (kernel_A2E.c:90-92)
-    float s = 0.0f;
-    for (int i = lane; i < NE; i += 64) s += XL[i];
-    s = 1.0f / soc_wave_sum(s);
-    for (int i = lane; i < NE; i += 64) XL[i] = XL[i] * s;
+    __syncthreads();
+    // 2. suffix sums over the upper level (kernel_A2E.c:72-77): a lane owns the columns lane, lane + 64, ... and walks
+    //    them together, row by row from the bottom -- per column the reference's order, several chains in flight
+    for (int j = NE - 3; j > 0; j--) {
+        for (int i = lane; i < j; i += 64) L[A2E_IND(j, i)] += L[A2E_IND(j + 1, i)];
+    }
+    __syncthreads();
+    // 3. forward substitution (kernel_A2E.c:80-88), row per lane: lane r of a block of 64 rows keeps the sum of its row
+    //    XL[j] = sum_{i<j} L[j,i] * XL[i], added up in the reference's order (i ascending, mul then add); the rows of a
+    //    block are finished one after the other, the finished XL[j] handed to the rows below by v_readlane.  No barrier,
+    //    no tree reduction: the same fp32 operations as the serial loop, so the same bits.
+    if (lane == 0) XL[0] = 1.0e-20f;
+    for (int j0 = 0; j0 < NE; j0 += 64) {
+        const int row = j0 + lane;
+        const bool live = (row < NE);
+        float s = 0.0f;
+        if (live) for (int i = 0; i < j0; i++) s += L[A2E_IND(row, i)] * XL[i];       // the blocks above: all XL[i] final
+        const int kend = (NE - j0 < 64) ? (NE - j0) : 64;
+        const float td = live ? (A.Tdown[row] + 1.0e-30f) : 1.0f;                     // lane k finishes row j0 + k
+        for (int k = 0; k < kend; k++) {
+            const int jk = j0 + k;
+            float x = 1.0e-20f;                                                       // XL[0]
+            if (jk > 0) {
+                x = s / td;
+                x = __builtin_fmaxf(x, 0.0f);
+            }
+            float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k));
+            if (xk > 1.0e20f) {
+                // rescaling (kernel_A2E.c:86-88): XL[0..jk] *= 1e-20, and every later row is summed from those values --
+                // the sums in hand were taken with the old ones, so they are taken again (rare)
+                for (int i = lane; i < jk; i += 64) XL[i] *= 1.0e-20f;
+                xk *= 1.0e-20f;
+                if (lane == k) XL[jk] = xk;
+                s = 0.0f;
+                if (live && row > jk) for (int i = 0; i <= jk; i++) s += L[A2E_IND(row, i)] * XL[i];
+            } else {
+                if (lane == k) XL[jk] = xk;
+                if (live && row > jk) s += L[A2E_IND(row, jk)] * xk;
+            }
+        }
+    }
+    __syncthreads();
+    // normalise (kernel_A2E.c:90-92): the sum in the reference's order, every lane for itself (broadcast reads)
+    float nrm = 0.0f;
+    for (int i = 0; i < NE; i++) nrm += XL[i];
+    nrm = 1.0f / nrm;
+    __syncthreads();
+    for (int i = lane; i < NE; i += 64) XL[i] = XL[i] * nrm;
     __syncthreads();
     // 4. emission (kernel_A2E.c:95-100): one frequency per lane, serial over the bins
     float *EMIT = A.AEMIT + (size_t)cell * NFREQ;
     for (int f = lane; f < NFREQ; f += 64) {
         float I = 0.0f;
-        const float *ea = A.EA + (size_t)f * NE;
-        for (int i = A.Ibeg[f]; i < NE; i++) I += ea[i] * XL[i];
+        const float *ea = A.EA + f;                       // EA transposed: [bin][frequency]
+        const int ib = A.Ibeg[f];
+#pragma unroll 8
+        for (int i = ib; i < NE; i++) I += ea[(size_t)i * NFREQ] * XL[i];
         EMIT[f] = I;
     }
 }

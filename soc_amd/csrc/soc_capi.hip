@@ -1522,7 +1522,13 @@ int soc_a2e_set_size(soc_ctx *c, int NE, int NFREQ, int noIw, const float *Iw, c
     HIPCHK(c, hipMemcpy(c->aIwOff, off.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->aDst, dst.data(), (size_t)npair * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->aTdown, Tdown, (size_t)NE * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->aEA, EA, (size_t)NE * NFREQ * 4, hipMemcpyHostToDevice));
+    {   // transposed on the way: EAT[i * NFREQ + f] = EA[f * NE + i], so that the lanes of the emission loop (one
+        // frequency each) read neighbouring words (the sum over the enthalpy bins keeps its order)
+        std::vector<float> eat((size_t)NE * NFREQ);
+        for (int f = 0; f < NFREQ; f++)
+            for (int i = 0; i < NE; i++) eat[(size_t)i * NFREQ + f] = EA[(size_t)f * NE + i];
+        HIPCHK(c, hipMemcpy(c->aEA, eat.data(), (size_t)NE * NFREQ * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMemcpy(c->aIbeg, Ibeg, (size_t)NFREQ * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->aAF, AF, (size_t)NFREQ * 4, hipMemcpyHostToDevice));
     if (NFREQ != c->a2e_NFREQ) c->a2e_cap = 0;

@@ -128,7 +128,7 @@ struct SocA2EArgs {
     const int   *pair_iw;            // [npair] offset of the pair's first weight in Iw
     const int   *pair_dst;           // [npair] (u*u-u)/2 + l
     const float *Tdown;              // [NE]
-    const float *EA;                 // [NFREQ*NE]
+    const float *EA;                 // [NE*NFREQ]: transposed by soc_a2e_set_size (bin-major)
     const int   *Ibeg;               // [NFREQ]
     const float *AF;                 // [NFREQ]
     const float *AABS;               // [batch*NFREQ]

@@ -1,10 +1,16 @@
 """A2E (stochastically heated grains): oracle pinned to the reference's DoSolve/EqTemperature
 (bit-exact in libm mode), file formats, and -- on the GPU -- the HIP kernels against the oracle.
 
-Tolerances on the GPU: EqTemperature is one lane per cell with the shared math header ->
-bit-identical to the oracle's soc mode.  DoSolve keeps the reference's summation order
-everywhere except the forward-substitution dot products (wave butterfly instead of a serial
-loop): all terms are >= 0, so the bound is n*eps per sum; rtol 5e-5 is asserted."""
+On the GPU both kernels are held to the oracle bit for bit: EqTemperature is one lane per cell with the shared math
+header; DoSolve keeps the reference's fp32 operations and their order everywhere -- the forward substitution sums
+each row in one lane (i ascending, mul then add), finished values handed down by v_readlane -- and uses +,*,/,max
+only, so it equals the reference's own golden output as well."""
+
+
+def _same_bits(got, want):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    ok = np.isfinite(want)
+    return np.array_equal(np.isfinite(got), ok) and np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
 import os
 import sys
 
@@ -87,8 +93,8 @@ def test_gpu_dosolve_vs_oracle_and_golden(tag, engine, oracle_soc):
         engine.a2e_set_size(m["NE"], m["NFREQ"], sol["sizes"][isize], AF)
         got = engine.a2e_solve(ABS)
         assert np.isfinite(got).all()
-        assert np.allclose(got, want, rtol=5e-5, atol=1e-30)
-        assert np.allclose(got, GOLD["%s_s%d_emit" % (tag, isize)], rtol=5e-5, atol=1e-30)
+        assert _same_bits(got, want)
+        assert _same_bits(got, GOLD["%s_s%d_emit" % (tag, isize)])
 
 
 @pytest.mark.gpu
@@ -103,10 +109,9 @@ def test_gpu_dosolve_ragged_and_edge_inputs(engine, oracle_soc):
     engine.a2e_set_size(m["NE"], m["NFREQ"], sol["sizes"][1], AF)
     got = engine.a2e_solve(ABS)
     ok = np.isfinite(want)
-    assert np.array_equal(np.isfinite(got), ok)
-    assert np.allclose(got[ok], want[ok], rtol=5e-5, atol=1e-30)
+    assert _same_bits(got, want)
     one = engine.a2e_solve(ABS[5:6])                   # batch of one cell
-    assert np.allclose(one[0], want[5], rtol=5e-5, atol=1e-30)
+    assert _same_bits(one[0], want[5])
     from soc_amd.lib import SocError
     bad = dict(sol["sizes"][1])
     bad["L2"] = bad["L2"].copy()
@@ -146,7 +151,7 @@ def test_gpu_a2e_host_program(engine, oracle_soc, tmp_path):
     T, e2 = a2e_oracle_eqtemp(oracle_soc, 0, 300, a2e.NIP, 1e20, kE, oplgkE, Emin, sol["FREQ"], KABS, TTT,
                               np.asarray(A * AF, np.float32))
     want += e2 * (sol["GD"] * sol["S_FRAC"][2])
-    assert np.allclose(E, want, rtol=5e-5, atol=1e-30 * want.max())
+    assert np.allclose(E, want, rtol=1e-6, atol=1e-30 * want.max())
 
 
 @pytest.mark.gpu

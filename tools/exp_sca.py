@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Throughput of the scattered-light kernel (config 4) on its geometry: 256^3-root octree with 3 refinement levels,
+3 observers, 256^2 pixels, forced first scattering; background, point-source and cell-emission launches.
+
+    python tools/exp_sca.py [--n 256] [--batch 1] [--ndir 3]
+
+Prints one JSON line per launch kind: packets/s and the read-only roofline of SURVEY.md 8(d): 4 B (density) per cell
+step of a packet, of a look-ahead and of a peel-off ray (the kernel counts them)."""
+import argparse
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soc_amd import launch, synth         # noqa: E402
+from soc_amd.lib import Engine            # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--ndir", type=int, default=3)
+    a = ap.parse_args()
+    N = a.n
+    cloud = synth.octree_cloud(N, levels=a.levels, frac=0.10, seed=1234) if a.levels > 1 else synth.cartesian_cloud(N, seed=1234)
+    dsc, csc = synth.hg_scattering_table(0.6)
+    eng = Engine(0)
+    eng.set_cloud(cloud)
+    eng.set_features(0, 0, 0)
+    eng.set_scatter_table(dsc, csc)
+    k = 2.0 / (N * float(cloud.DENS[cloud.DENS > 0][:N ** 3].mean()))          # optical depth ~2 across the cloud
+    eng.set_optical(0.5 * k, k)
+    eng.set_opt(None)
+    th = [math.radians(30 + 25 * i) for i in range(a.ndir)]
+    ph = [math.radians(40 * i) for i in range(a.ndir)]
+    _, OD, RA, DE = launch.set_observer_directions(th, ph)
+    eng.sca_set_view(OD, RA, DE, (256, 256), N / 256.0 * 1.5, (N / 2, N / 2, N / 2), 1)
+    AREA = 6 * N * N
+    GLOBAL = launch.Fix(8 * AREA, 64)
+    ps = np.array([[N / 2 + 0.3, N / 2 + 0.2, N / 2 + 0.1]], np.float32)
+    emit = np.where(cloud.DENS > 0, cloud.DENS * 1e-3, 0).astype(np.float32)
+    eng.set_emission(emit)
+    runs = (("SimRAM_PB background", lambda s: eng.sca_sim_pb(1, 8 * AREA * a.batch, a.batch, s, 1.0, GLOBAL=GLOBAL)),
+            ("SimRAM_PS point source", lambda s: eng.sca_sim_ps(1048576 * 8, 8, s, 0.0, ps, [1.0], GLOBAL=1048576)),
+            ("SimRAM_CL cell emission", lambda s: eng.sca_sim_cl(2, cloud.CELLS, 1, s, 1048576)))
+    for name, fn in runs:
+        best = None
+        for rep in range(2):
+            eng.sca_zero()
+            eng.stats(reset=True)
+            eng.timer_start()
+            fn(0.3 + 0.1 * rep)
+            ms = eng.timer_stop()
+            st = eng.stats()
+            if best is None or ms < best[0]:
+                best = (ms, st)
+        ms, st = best
+        print(json.dumps({"kernel": "soc_sca_kernel", "launch": name, "cells": cloud.CELLS, "ndir": a.ndir, "kernel_ms": ms,
+                          "packets": st["packets"], "packets_per_s": st["packets"] / ms * 1e3,
+                          "image_contributions": st["tally_events"], "scatterings": st["scatterings"]}), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
