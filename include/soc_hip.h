@@ -104,6 +104,18 @@ int soc_read_opt(soc_ctx *ctx, float *OPT);
  * (unused by the absorption kernels, required by soc_sca_sim_ps/pb); BINS = USER.DSC_BINS */
 int soc_set_scatter_table(soc_ctx *ctx, const float *DSC, const float *CSC, int BINS);
 
+/* -D WITH_MSF (ASOC.py:132-138, :1239-1243; kernel_ASOC.c:777-795, :1654-1668): one scattering function per dust species,
+ * DSC[NDUST][BINS] and CSC[NDUST][BINS]; NDUST == 1 is soc_set_scatter_table.  With NDUST > 1 a launch needs the
+ * abundances of the same NDUST species (soc_set_abundances, not the one-abundance form) and this frequency's
+ * soc_set_optical_abu -- whose AFSCA are the per-species SCA the kernels draw the scatterer with -- and is not deferred. */
+int soc_set_scatter_tables(soc_ctx *ctx, int NDUST, const float *DSC, const float *CSC, int BINS);
+
+/* -D STEP_WEIGHT / SW_A / SW_B (ASOC.py:348,357; kernel_ASOC.c:516-535, :752-763, :941-955, :1444-1462, :1625-1640):
+ * free paths from p(t) = A*exp(-A*t) (mode 1) or B*A*exp(-A*t) + (1-B)*2A*exp(-2A*t) (mode 2) with the packet weight
+ * corrected; mode <= 0 switches the weighting off.  The arguments are the VALUES OF THE -D MACROS; the reference's host
+ * fills them from the ini key `stepweight a b c` as STEP_WEIGHT=int(c), SW_A=int(a), SW_B=b (ASOC.py:357). */
+int soc_set_step_weight(soc_ctx *ctx, int mode, float SW_A, float SW_B);
+
 /* replaces the EMIT / EMWEI uploads (ASOC.py:1276, 1291); arrays of CELLS floats */
 int soc_set_emission(soc_ctx *ctx, const float *EMIT, const float *EMWEI);
 

@@ -41,6 +41,8 @@ class OrcModel(C.Structure):
         ("WITH_ALI", C.c_int), ("XAB", _F), ("EMINDEX", _I),
         ("WITH_ROI_SAVE", C.c_int), ("ROI", C.c_int * 6), ("ROI_STEP", C.c_int), ("ROI_NSIDE", C.c_int), ("ROI_SAVE", _F),
         ("WITH_ROI_LOAD", C.c_int), ("ROI_DIM", C.c_int * 3), ("ROI_LOAD", _F),
+        ("STEP_WEIGHT", C.c_int), ("SW_A", C.c_float), ("SW_B", C.c_float),
+        ("MSF_NDUST", C.c_int), ("MSF_SCA", _F), ("ABU", _F),
     ]
 
 
@@ -68,8 +70,18 @@ class Job:
     def __init__(self, cloud, CSC, ABS=0.0, SCA=0.0, SOURCE=1, BATCH=1, SEED=0.5, BG=1.0, TW=1.0,
                  GLOBAL=None, PACKETS=0, PSPOS=None, PS=None, PS_METHOD=0, XPS=None, OPT=None,
                  EMIT=None, EMWEI=None, USE_EMWEIGHT=0, WITH_INT=0, DSC=None, HPBG=None, HPBGP=None, MIRROR=0,
-                 WITH_ALI=0, EMINDEX=None, ROI=None, ROI_STEP=1, ROI_NSIDE=2, ROI_LOAD=None, ROI_DIM=None):
+                 WITH_ALI=0, EMINDEX=None, ROI=None, ROI_STEP=1, ROI_NSIDE=2, ROI_LOAD=None, ROI_DIM=None,
+                 STEP_WEIGHT=None, MSF=None):
         self.cloud = cloud
+        # weighted free paths: STEP_WEIGHT = (mode 1|2, SW_A, SW_B) as the -D values (-D DIR_WEIGHT > 0 does not compile);
+        # MSF = (ABS[NDUST], SCA[NDUST], CSC[NDUST, BINS], ABU[CELLS, NDUST]): per-dust scattering functions (WITH_MSF),
+        # OPT must be the matching sum(ABU * cross sections) (WITH_ABU)
+        self.STEP_WEIGHT = (0, 0.0, 0.0) if STEP_WEIGHT is None else (int(STEP_WEIGHT[0]), float(STEP_WEIGHT[1]), float(STEP_WEIGHT[2]))
+        self.MSF = None
+        if MSF is not None:
+            self.MSF = (np.ascontiguousarray(MSF[0], np.float32), np.ascontiguousarray(MSF[1], np.float32),
+                        np.ascontiguousarray(MSF[2], np.float32), np.ascontiguousarray(MSF[3], np.float32))
+            CSC = self.MSF[2].reshape(len(self.MSF[1]), -1)[0]
         # region of interest: ROI = [x0,x1,y0,y1,z0,z1] turns on WITH_ROI_SAVE; ROI_LOAD [elements, 12*NSIDE^2]
         # with ROI_DIM = (nx, ny, nz) of its surface discretisation is the SOURCE == 3 input (WITH_ROI_LOAD)
         self.ROI = None if ROI is None else np.ascontiguousarray(ROI, np.int32)
@@ -194,6 +206,11 @@ class Oracle:
         if job.ROI_LOAD is not None:
             m.ROI_DIM = (C.c_int * 3)(*[int(v) for v in job.ROI_DIM])
             m.ROI_LOAD = _fp(job.ROI_LOAD)
+        m.STEP_WEIGHT, m.SW_A, m.SW_B = job.STEP_WEIGHT
+        m.MSF_NDUST = 0
+        if job.MSF is not None:
+            m.MSF_NDUST = len(job.MSF[1])
+            m.MSF_SCA, m.CSC, m.ABU = _fp(job.MSF[1]), _fp(job.MSF[2]), _fp(job.MSF[3])
         return m
 
     def parents(self, job):
@@ -315,6 +332,10 @@ class Ref:
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
         assert job.MIRROR == m.get("MIRROR", 0)
         assert job.WITH_ALI == m.get("WITH_ALI", 0)
+        assert job.STEP_WEIGHT[0] == max(0, m.get("STEP_WEIGHT", -1))
+        if job.STEP_WEIGHT[0] > 0:
+            assert (np.float32(job.STEP_WEIGHT[1]), np.float32(job.STEP_WEIGHT[2])) == (np.float32(m["SW_A"]), np.float32(m["SW_B"]))
+        assert (0 if job.MSF is None else len(job.MSF[1])) == (m.get("NDUST", 1) if m.get("WITH_MSF", 0) else 0)
         assert int(job.ROI is not None) == m.get("WITH_ROI_SAVE", 0) and int(job.ROI_LOAD is not None) == m.get("WITH_ROI_LOAD", 0)
         if job.ROI is not None:
             assert job.ROI_STEP == m.get("ROI_STEP", 0)
@@ -401,16 +422,19 @@ class Ref:
         idummy = np.zeros(4, np.int32)
         ABS = np.asarray([job.ABS], np.float32)
         SCA = np.asarray([job.SCA], np.float32)
+        CSC, ABU = job.CSC, dummy
+        if job.MSF is not None:                      # -D WITH_MSF: ABS[NDUST], SCA[NDUST], CSC[NDUST*BINS], ABU[CELLS*NDUST]
+            ABS, SCA, CSC, ABU = job.MSF
         a = RefArgs()
         a.SOURCE, a.PACKETS, a.BATCH, a.GLOBAL = job.SOURCE, job.PACKETS, job.BATCH, job.GLOBAL
         a.SEED, a.BG, a.TW = job.SEED, job.BG, job.TW
         a.ABS, a.SCA, a.PSPOS, a.PS = _fp(ABS), _fp(SCA), _fp(job.PSPOS), _fp(job.PS)
         a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
         a.DENS, a.EMIT, a.TABS = _fp(job.DENS), _fp(job.EMIT), _fp(TABS)
-        a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(job.CSC), _fp(job.XAB), _fp(job.EMWEI)
+        a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(CSC), _fp(job.XAB), _fp(job.EMWEI)
         a.INT, a.INTX, a.INTY, a.INTZ = _fp(INT), _fp(dummy), _fp(dummy), _fp(dummy)
         a.OPT = _fp(job.OPT) if job.OPT is not None else _fp(dummy)
-        a.ABU = _fp(dummy)
+        a.ABU = _fp(ABU)
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         a.EMINDEX = _ip(job.EMINDEX) if job.EMINDEX is not None else _ip(idummy)
         a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP if job.HPBGP is not None else dummy)

@@ -124,6 +124,11 @@ typedef struct {
     float *ROI_SAVE;                  /* [elements * 12*ROI_NSIDE^2]                                      */
     int   WITH_ROI_LOAD, ROI_DIM[3];
     const float *ROI_LOAD;            /* [elements * 12*ROI_NSIDE^2] photons, already scaled by the host  */
+    /* weighted free paths (-D STEP_WEIGHT, SW_A, SW_B) and per-dust scattering functions (-D WITH_MSF,
+     * NDUST): MSF_NDUST > 1 -> CSC holds NDUST tables, MSF_SCA[NDUST] the scattering cross sections, ABU[CELLS*NDUST] */
+    int   STEP_WEIGHT;  float SW_A, SW_B;
+    int   MSF_NDUST;
+    const float *MSF_SCA, *ABU;
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -316,6 +321,46 @@ static void Scatter(f3 *DIR, const float *CSC, int BINS, rng_t *rng)
     normalize3(DIR);
 }
 
+/* the free path of a new flight, kernel_ASOC.c:516-535 (creation) = :736-755 (after a scattering): unweighted, or drawn
+ * from a stretched exponential (STEP_WEIGHT 1) / a sum of two (2) with the packet weight corrected */
+static float DrawFreePath(const orc_model *M, rng_t *rng, float *PHOTONS)
+{
+    float free_path;
+    const float SW_A = M->SW_A, SW_B = M->SW_B;
+    if (M->STEP_WEIGHT <= 0) return -M_LOG(Rand(rng));
+    if (M->STEP_WEIGHT == 1) {
+        free_path = -M_LOG(Rand(rng)) / SW_A;
+        *PHOTONS *= M_EXP(SW_A * free_path - free_path) / SW_A;
+        return free_path;
+    }
+    free_path = -M_LOG((-SW_B + M_SQRT(SW_B * SW_B + 4.0f * Rand(rng) * (1.0f - SW_B))) / (2.0f - 2.0f * SW_B)) / SW_A;
+    *PHOTONS *= 1.0f / (SW_A * SW_B * M_EXP((1.0f - SW_A) * free_path) + 2.0f * SW_A * (1.0f - SW_B) * M_EXP((1.0f - 2.0f * SW_A) * free_path));
+    return free_path;
+}
+
+/* the new direction after a scattering in cell oind, kernel_ASOC.c:768-799 (SimRAM_PB), :1146-1175 (HP), :1644-1675 (CL):
+ * the scattering function of a dust species picked by its share of the cell's scattering cross section (WITH_MSF), or the
+ * one table.  cl: SimRAM_CL keeps the cell's OPT value in free_path (:1662).  (-D DIR_WEIGHT > 0 does not compile in
+ * the reference -- :770-775 use undeclared pweight, pind -- and is not restated.) */
+static void NewDirection(const orc_model *M, f3 *DIR, rng_t *rng, int oind, float *PHOTONS, float *free_path, int cl)
+{
+    if (M->MSF_NDUST > 1) {
+        const int NDUST = M->MSF_NDUST;
+        const float dx = M->OPT[2 * (long)oind + 1];
+        float ds = 0.99999f * Rand(rng);
+        int   idust;
+        if (cl) *free_path = dx;
+        for (idust = 0; idust < NDUST; idust++) {
+            ds -= M->ABU[idust + NDUST * ((long)oind)] * M->MSF_SCA[idust] / dx;
+            if (ds <= 0.0) break;
+        }
+        if (idust >= NDUST) idust = NDUST - 1;
+        Scatter(DIR, M->CSC + (long)idust * M->BINS, M->BINS, rng);
+    } else {
+        Scatter(DIR, M->CSC, M->BINS, rng);
+    }
+}
+
 /* kernel_ASOC_aux.c:912-940 */
 static void Surface(const orc_model *M, f3 *POS, f3 *DIR)
 {
@@ -453,7 +498,7 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
     cl_order &= 1;
     scatterings = 0;
     tau = 0.0f;
-    free_path = -M_LOG(Rand(rng));
+    free_path = DrawFreePath(M, rng, &PHOTONS);
     steps = 0;
     int roi = -1, oroi = -1;
     if (M->WITH_ROI_SAVE) roi = oroi = InRoi(M, level, ind);            /* kernel_ASOC.c:550, :1439 */
@@ -523,10 +568,10 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
         POS.y = POS0.y + dx * DIR.y;
         POS.z = POS0.z + dx * DIR.z;
         PHOTONS *= M_EXP(-tauA);
-        free_path = -M_LOG(Rand(rng));
+        free_path = DrawFreePath(M, rng, &PHOTONS);
         ind   = ind0;
         level = level0;
-        Scatter(&DIR, M->CSC, M->BINS, rng);
+        NewDirection(M, &DIR, rng, oind, &PHOTONS, &free_path, cl_order);
         if (!cl_order && (scatterings > 20)) { ind = -1; continue; }
     }
     (void)steps;

@@ -32,14 +32,12 @@ class UnsupportedOption(RuntimeError):
 
 def _check_supported(USER, NDUST, WITH_MSF):
     bad = []
-    if WITH_MSF:
-        bad.append("several dsc files (WITH_MSF)")
     if USER.DO_SPLIT:
         bad.append("split")
-    if USER.STEP_WEIGHT[0] > 0:
-        bad.append("stepweight")
+    if int(USER.STEP_WEIGHT[2]) > 2:
+        bad.append("stepweight with a third argument > 2 (the kernel then uses an uninitialised free path, kernel_ASOC.c:516-535)")
     if USER.DIR_WEIGHT[0] > 0:
-        bad.append("direweight")
+        bad.append("direweight (-D DIR_WEIGHT > 0 does not compile in the reference: pweight, pind undeclared, kernel_ASOC.c:770-775)")
     if USER.ROI_MAP:
         bad.append("roimap")
     if USER.SAVE_INTENSITY == 2:
@@ -87,7 +85,7 @@ class AbsorptionRun:
             raise ValueError("the dust file needs >= 2 frequencies (trapezoid weights, ASOC.py:1220); "
                              "restrict the simulated range with `simum` instead")
         self.FDSC, self.FCSC = files.read_scattering_functions(U.file_scafunc, self.NFREQ, U.DSC_BINS)
-        WITH_MSF = len(self.FDSC) > 1
+        self.WITH_MSF = WITH_MSF = len(self.FDSC) > 1
         _check_supported(U, self.NDUST, WITH_MSF)
         self.IBG = files.read_background_intensity(U.file_background, self.NFREQ, U.scale_background) \
             if U.BGPAC > 0 else []
@@ -105,7 +103,13 @@ class AbsorptionRun:
         if self.WITH_ABU and U.SINGLE_ABU:
             if self.NDUST != 2:
                 raise ValueError("singleabu assumes exactly two dust components")
+            if self.WITH_MSF:
+                raise ValueError("singleabu cannot be used with several scattering functions (ASOC.py:159-161)")
             self.ABU = np.ravel(self.ABU[:, 0])
+        if self.WITH_MSF and not self.WITH_ABU:
+            raise ValueError("cannot have multiple scattering functions without multiple dusts with variable abundances (ASOC.py:168-170)")
+        if self.WITH_MSF and len(self.FDSC) != self.NDUST:
+            raise ValueError("%d dsc files for %d dust species" % (len(self.FDSC), self.NDUST))
         self.DIFFUSERAD = files.mmap_diffuserad(U.file_diffuse, c.CELLS) if len(U.file_diffuse) > 0 else []
 
         # LOCAL only enters through the rounding of packet counts (ASOC.py:221-227)
@@ -135,6 +139,11 @@ class AbsorptionRun:
         e.set_cloud(c)
         e.set_features(with_int=self.with_int, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 2))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
+        # `stepweight a b c`: the reference hands the kernels -D SW_A=int(a) -D SW_B=b -D STEP_WEIGHT=int(c), each float
+        # written with %.3e (ASOC.py:348,357) -- the drop-in passes the same values
+        sw = int(U.STEP_WEIGHT[2])
+        if sw > 0 or hasattr(e, "set_step_weight"):
+            e.set_step_weight(sw, float("%.3e" % int(U.STEP_WEIGHT[0])), float("%.3e" % U.STEP_WEIGHT[1]))
         if self.WITH_ABU:
             e.set_abundances(self.ABU, single=bool(U.SINGLE_ABU))
         if self.comm:
@@ -157,6 +166,13 @@ class AbsorptionRun:
             e.set_opt(None)
         e.set_optical(ABS, SCA)
         return ABS, SCA
+
+    def _scatter_tables_for(self, IFREQ):
+        """DSC, CSC of the frequency; one pair per species with WITH_MSF (ASOC.py:1234-1243)"""
+        if self.WITH_MSF:
+            self.eng.set_scatter_tables(self.FDSC[:, IFREQ, :], self.FCSC[:, IFREQ, :])
+        else:
+            self.eng.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
 
     def simulate_constant_sources(self):
         """for II in (point sources, background, diffuse): for IFREQ: launch (ASOC.py:1028-1545).
@@ -241,7 +257,7 @@ class AbsorptionRun:
                 PS = (self.LPS[:, IFREQ] * np.float32(WPS)) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
                 BG = np.float32(float(self.IBG[IFREQ]) * WBG / FREQ) if len(self.IBG) == NFREQ else np.float32(0.0)
                 FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
-                e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                self._scatter_tables_for(IFREQ)
                 if U.SEED > 0:
                     seed = launch.launch_seed(U.SEED, IFREQ, DEVICES, ID)
                 else:
@@ -383,7 +399,7 @@ class AbsorptionRun:
                     t0 = time.time()
                     self._optical_for(IFREQ)
                     FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
-                    e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                    self._scatter_tables_for(IFREQ)
                     if IFREQ < I1 or IFREQ > I2:
                         continue
                     EMIT[:] = EMITTED[:, IFREQ - I1]

@@ -203,13 +203,13 @@ struct SocBrickLane {
     int   level, ind, scat;
     soc_rng_t rng;
 
-    __device__ __forceinline__ void begin_conditioned()    // SimRAM_HP: the direction is conditioned at creation
+    __device__ __forceinline__ void begin_conditioned(const SocSim &S)    // SimRAM_HP: the direction is conditioned at creation
     {
         scat = 0;
         tau  = 0.0f;
-        free_path = -soc_logf(soc_rand(&rng));
+        free_path = soc_draw_free_path(S, &rng, photons);
     }
-    __device__ __forceinline__ void begin()
+    __device__ __forceinline__ void begin(const SocSim &S)
     {
         if (soc_fabsf(ux) < SOC_DEPS) ux = SOC_DEPS;
         if (soc_fabsf(uy) < SOC_DEPS) uy = SOC_DEPS;
@@ -217,7 +217,7 @@ struct SocBrickLane {
         soc_normalize(ux, uy, uz);
         scat = 0;
         tau  = 0.0f;
-        free_path = -soc_logf(soc_rand(&rng));
+        free_path = soc_draw_free_path(S, &rng, photons);
     }
 };
 
@@ -1013,8 +1013,8 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             w.py = w.py + dx * w.uy;
             w.pz = w.pz + dx * w.uz;
             w.photons *= e;
-            w.free_path = -soc_logf(soc_rand(&w.rng));
-            soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);           // one table read per event: no staging
+            w.free_path = soc_draw_free_path(S, &w.rng, w.photons);
+            soc_new_direction<CL>(S, S.CSC, oind, w.ux, w.uy, w.uz, w.free_path, &w.rng);   // one table read per event: no staging
             w.tau = 0.0f;
             if (!CL && (w.scat > 20)) { w.ind = -1;  create = true; }         // dropped after 20 scatterings
             if (LT) {                                                        // back to the brick of its cell
@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                 soc_sincosf(phi, &sp, &cp);
                 w.ux = sin_theta * cp;  w.uy = sin_theta * sp;  w.uz = cos_theta;
                 n_pkt++;
-                w.begin();
+                w.begin(S);
                 if (LT) {
                     soc_cell_coords(G, sOFF, level, ind, ccx, ccy, ccz);
                     key = A.rbrick[((ccz >> level) * G.NY + (ccy >> level)) * G.NX + (ccx >> level)];
@@ -1126,10 +1126,10 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                 if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
                 if (HP) {                                                      // SimRAM_HP (kernel_ASOC.c:878-955)
                     soc_hp_create<OCT>(G, S, sOFF, w);
-                    w.begin_conditioned();
+                    w.begin_conditioned(S);
                 } else {
                     soc_pb_create<OCT, SocBrickLane, SRC>(G, S, sOFF, E, III, w);
-                    w.begin();
+                    w.begin(S);
                 }
                 III++;
                 n_pkt++;

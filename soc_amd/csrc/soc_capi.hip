@@ -42,6 +42,10 @@ struct soc_ctx {
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
     float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
     int    abu_ndust = 0, abu_single = 0;
+    bool   opt_from_abu = false;       // dOPT and dAF hold the current frequency's soc_set_optical_abu values
+    int    msf_ndust = 1;              // > 1: -D WITH_MSF, dCSC/dDSC hold [msf_ndust][BINS] (soc_set_scatter_tables)
+    int    step_weight = 0;            // -D STEP_WEIGHT (soc_set_step_weight)
+    float  sw_a = 0.0f, sw_b = 0.0f;
     size_t abu_cells = 0;
     SocRoi roi{};                                 // region of interest (host copy of *dRoi)
     SocRoi *dRoi = nullptr;
@@ -397,6 +401,7 @@ int soc_set_opt(soc_ctx *c, const float *OPT)
     // no flush: a deferred launch keeps its own copy of the opacities (soc_sim_pb)
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_opt: call soc_set_grid first");
     HIPCHK(c, hipSetDevice(c->device));
+    c->opt_from_abu = false;
     if (!OPT) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->dOPT) { (void)hipFree(c->dOPT); c->dOPT = nullptr; }
@@ -414,6 +419,7 @@ int soc_set_abundances(soc_ctx *c, int NDUST, int single, const float *ABU)
     FLUSH(c);
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_abundances: call soc_set_grid first");
     HIPCHK(c, hipSetDevice(c->device));
+    c->opt_from_abu = false;
     if (!ABU) {                                             // off
         c->abu_ndust = 0;
         c->abu_cells = 0;
@@ -446,6 +452,7 @@ int soc_set_optical_abu(soc_ctx *c, const float *AFABS, const float *AFSCA, int 
     HIPCHK(c, hipMemcpyAsync(c->dAF, af, (size_t)2 * ndust * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));             // af is on the stack
     HIPCHK(c, soc_launch_opt(c->G.CELLS, ndust, c->abu_single, c->dABU, c->dAF, c->dOPT, c->stream));
+    c->opt_from_abu = true;
     return SOC_OK;
 }
 
@@ -460,22 +467,42 @@ int soc_read_opt(soc_ctx *c, float *OPT)
     return SOC_OK;
 }
 
-int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BINS)
+int soc_set_scatter_tables(soc_ctx *c, int NDUST, const float *DSC, const float *CSC, int BINS)
 {
     if (!c) return SOC_ERR_ARG;
-    if (!CSC || BINS < 1 || BINS > 16000) return fail(c, SOC_ERR_ARG, "soc_set_scatter_table: need CSC and 1 <= BINS <= 16000 (got %d)", BINS);
+    if (!CSC || BINS < 1 || BINS > 16000) return fail(c, SOC_ERR_ARG, "soc_set_scatter_tables: need CSC and 1 <= BINS <= 16000 (got %d)", BINS);
+    if (NDUST < 1 || NDUST > 64) return fail(c, SOC_ERR_ARG, "soc_set_scatter_tables: NDUST %d (1..64)", NDUST);
     HIPCHK(c, hipSetDevice(c->device));
-    if (BINS != c->BINS || !c->dCSC) {
+    if (NDUST > 1 || c->msf_ndust > 1) FLUSH(c);            // a deferred launch snapshots one table only: run what is pending first
+    const size_t n = (size_t)NDUST * BINS;
+    if (BINS != c->BINS || NDUST != c->msf_ndust || !c->dCSC) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, dev_alloc(&c->dCSC, (size_t)BINS));
-        HIPCHK(c, dev_alloc(&c->dDSC, (size_t)BINS));
+        HIPCHK(c, dev_alloc(&c->dCSC, n));
+        HIPCHK(c, dev_alloc(&c->dDSC, n));
         c->BINS = BINS;
+        c->msf_ndust = NDUST;
         c->have_dsc = false;
     }
     if (DSC) c->have_dsc = true;
-    HIPCHK(c, hipMemcpyAsync(c->dCSC, CSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
-    if (DSC) HIPCHK(c, hipMemcpyAsync(c->dDSC, DSC, (size_t)BINS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCSC, CSC, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (DSC) HIPCHK(c, hipMemcpyAsync(c->dDSC, DSC, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host buffer may be reused by the caller
+    return SOC_OK;
+}
+
+int soc_set_scatter_table(soc_ctx *c, const float *DSC, const float *CSC, int BINS)
+{
+    return soc_set_scatter_tables(c, 1, DSC, CSC, BINS);
+}
+
+int soc_set_step_weight(soc_ctx *c, int mode, float SW_A, float SW_B)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (mode <= 0) { c->step_weight = 0;  c->sw_a = c->sw_b = 0.0f;  return SOC_OK; }
+    if (mode > 2) return fail(c, SOC_ERR_ARG, "soc_set_step_weight: mode %d (0 off, 1 exp(-A*t), 2 B*exp(-A*t)+(1-B)*exp(-2*A*t))", mode);
+    if (!(SW_A > 0.0f) || !std::isfinite(SW_A)) return fail(c, SOC_ERR_ARG, "soc_set_step_weight: SW_A=%g must be positive", (double)SW_A);
+    if (mode == 2 && !(SW_B > 0.0f && SW_B < 1.0f)) return fail(c, SOC_ERR_ARG, "soc_set_step_weight: mode 2 needs 0 < SW_B < 1, got %g", (double)SW_B);
+    c->step_weight = mode;  c->sw_a = SW_A;  c->sw_b = SW_B;
     return SOC_OK;
 }
 
@@ -555,6 +582,9 @@ static int check_launch(soc_ctx *c, const char *who, int BATCH, int GLOBAL, int 
     if (!c->have_grid) return fail(c, SOC_ERR_STATE, "%s: call soc_set_grid first", who);
     if (!c->dCSC) return fail(c, SOC_ERR_STATE, "%s: call soc_set_scatter_table first", who);
     if (!c->dOPT && !c->have_optical) return fail(c, SOC_ERR_STATE, "%s: call soc_set_optical or soc_set_opt first", who);
+    if (c->msf_ndust > 1 && !(c->opt_from_abu && c->dOPT && c->abu_ndust == c->msf_ndust && !c->abu_single && c->abu_cells == (size_t)c->G.CELLS))
+        return fail(c, SOC_ERR_STATE, "%s: %d scattering functions (WITH_MSF) need soc_set_abundances with %d species and this frequency's soc_set_optical_abu",
+                    who, c->msf_ndust, c->msf_ndust);
     if (BATCH < 0) return fail(c, SOC_ERR_ARG, "%s: BATCH=%d", who, BATCH);
     if (GLOBAL < 1 || gid_first < 0 || gid_count < 0 || (int64_t)gid_first + gid_count > GLOBAL)
         return fail(c, SOC_ERR_ARG, "%s: work-item range [%d,+%d) outside GLOBAL=%d", who, gid_first, gid_count, GLOBAL);
@@ -576,6 +606,9 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     S.HPBG = c->dHPBG; S.HPBGP = c->dHPBGP; S.HPBG_WEIGHTED = c->hpbg_weighted ? 1 : 0;
     S.TABS = c->dTABS; S.INT = c->dINT;
     S.stats = c->dStats;
+    S.STEP_WEIGHT = c->step_weight;  S.SW_A = c->sw_a;  S.SW_B = c->sw_b;
+    S.NDUST = c->msf_ndust;
+    if (c->msf_ndust > 1) { S.MSF_SCA = c->dAF + c->msf_ndust;  S.ABU = c->dABU; }
     V.octree = c->G.LEVELS > 1;
     V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);   // DIMLIM, kernel_ASOC_aux.c:25-37
     V.abu = c->dOPT != nullptr;
@@ -696,7 +729,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOURCE, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_pb: a batch with the INT tally holds launches of one kind");
@@ -933,7 +966,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_hp: a batch with the INT tally holds launches of one kind");
@@ -993,7 +1026,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int);
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_cl: a batch with the INT tally holds launches of one kind");
@@ -1133,6 +1166,7 @@ static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVaria
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "%s: call soc_sca_set_view first", who);
     if (kind != SOC_SCA_CL && kind != SOC_SCA_HP && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
     if (c->BINS > 8000) return fail(c, SOC_ERR_ARG, "%s: BINS=%d > 8000", who, c->BINS);
+    if (c->msf_ndust > 1) return fail(c, SOC_ERR_ARG, "%s: scattered-light images with %d scattering functions (WITH_MSF) are not implemented", who, c->msf_ndust);
     SocSca X = c->view;
     X.kind = kind;
     X.DSC = c->dDSC;

@@ -51,6 +51,11 @@ struct SocSim {
     float *TABS, *INT;
     unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
     const SocRoi *ROI;         /* NULL without roisave / roiload                          */
+    int    STEP_WEIGHT;        /* -D STEP_WEIGHT: 0 none, 1 | 2 weighted free paths (kernel_ASOC.c:516-535) */
+    float  SW_A, SW_B;
+    int    NDUST;              /* > 1: -D WITH_MSF, CSC holds [NDUST][BINS] (kernel_ASOC.c:777-795)          */
+    const float  *MSF_SCA;     /* [NDUST] scattering cross sections of the species, current frequency       */
+    const float  *ABU;         /* [CELLS][NDUST] abundances                                                  */
 };
 
 #define SOC_SOURCE_HP 4        /* brick sweep only: the launch is a SimRAM_HP one (Healpix sky instead of BG) */

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
                             w.pz = (w.uz > 0.0f) ? SOC_PEPS : ((float)G.NZ - SOC_PEPS);
                         }
                         soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
-                        w.begin();
+                        w.begin(S);
                         if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);
                         mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
                         break;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void soc_sim_pb_kernel(const SocGrid G, const 
                 } else {
                     soc_pb_create<OCT>(G, S, sOFF, E, III, w);
                     III++;
-                    w.begin();
+                    w.begin(S);
                     if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);       // kernel_ASOC.c:550
                     mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
                 }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void soc_sim_hp_kernel(const SocGrid G, const 
                 } else {
                     soc_hp_create<OCT>(G, S, sOFF, w);
                     III++;
-                    w.begin_conditioned();
+                    w.begin_conditioned(S);
                     mode = (w.ind >= 0) ? SOC_M_STEP : SOC_M_CREATE;
                 }
             }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void soc_sim_cl_kernel(const SocGrid G, const 
                     w.uy = sin_theta * sp;
                     w.uz = cos_theta;
                     n_pkt++;
-                    w.begin();
+                    w.begin(S);
                     if (w.roi_on) w.roi = soc_inroi(G, sOFF, *S.ROI, w.level, w.ind);       // kernel_ASOC.c:1439
                     mode = SOC_M_STEP;
                 }

@@ -229,6 +229,47 @@ __device__ __forceinline__ void soc_scatter(float &ux, float &uy, float &uz, con
     soc_normalize(ux, uy, uz);
 }
 
+// The first and every later free path (kernel_ASOC.c:516-535, :752-763 and the same lines of SimRAM_HP / SimRAM_CL):
+// -D STEP_WEIGHT=1 samples exp(-SW_A*t) instead of exp(-t), =2 the mixture SW_B*exp(-SW_A*t) + (1-SW_B)*exp(-2*SW_A*t);
+// the packet's weight carries the ratio of the two densities.
+__device__ __forceinline__ float soc_draw_free_path(const SocSim &S, soc_rng_t *rng, float &photons)
+{
+    if (S.STEP_WEIGHT <= 0) return -soc_logf(soc_rand(rng));
+    const float A = S.SW_A, B = S.SW_B;
+    float fp;
+    if (S.STEP_WEIGHT == 1) {
+        fp = -soc_logf(soc_rand(rng)) / A;
+        photons *= soc_expf(A * fp - fp) / A;
+        return fp;
+    }
+    fp = -soc_logf((-B + soc_sqrtf(B * B + 4.0f * soc_rand(rng) * (1.0f - B))) / (2.0f - 2.0f * B)) / A;
+    photons *= 1.0f / (A * B * soc_expf((1.0f - A) * fp) + 2.0f * A * (1.0f - B) * soc_expf((1.0f - 2.0f * A) * fp));
+    return fp;
+}
+
+// New direction after a scattering in cell oind.  -D WITH_MSF (kernel_ASOC.c:777-795): the scatterer is one of NDUST
+// species, drawn with probabilities ABU*SCA/OPT.sca, and its own cumulative scattering function is used.  SimRAM_CL
+// reuses `free_path` as scratch for OPT.sca there (:1662), so the next free path of such a packet IS that number.
+template <bool CL_ORDER>
+__device__ __forceinline__ void soc_new_direction(const SocSim &S, const float *sCSC, const int oind, float &ux, float &uy, float &uz,
+                                                  float &free_path, soc_rng_t *rng)
+{
+    if (S.NDUST > 1) {
+        const float dx = S.OPT[oind].y;
+        float ds = 0.99999f * soc_rand(rng);
+        int idust = 0;
+        if (CL_ORDER) free_path = dx;
+        for (; idust < S.NDUST; idust++) {
+            ds -= S.ABU[idust + (long)S.NDUST * oind] * S.MSF_SCA[idust] / dx;
+            if (ds <= 0.0f) break;
+        }
+        if (idust >= S.NDUST) idust = S.NDUST - 1;
+        soc_scatter(ux, uy, uz, S.CSC + (long)idust * S.BINS, S.BINS, rng);
+    } else {
+        soc_scatter(ux, uy, uz, sCSC, S.BINS, rng);
+    }
+}
+
 // Surface (kernel_ASOC_aux.c:912-940): step from outside the model to its boundary
 __device__ __forceinline__ void soc_surface(const SocGrid &G, float &px, float &py, float &pz, float ux, float uy, float uz)
 {
@@ -329,7 +370,7 @@ struct SocWalker {
     }
 
     // after creation: kernel_ASOC.c:508-519
-    __device__ __forceinline__ void begin()
+    __device__ __forceinline__ void begin(const SocSim &S)
     {
         if (soc_fabsf(ux) < SOC_DEPS) ux = SOC_DEPS;
         if (soc_fabsf(uy) < SOC_DEPS) uy = SOC_DEPS;
@@ -337,16 +378,16 @@ struct SocWalker {
         soc_normalize(ux, uy, uz);
         scat = 0;
         tau  = 0.0f;
-        free_path = -soc_logf(soc_rand(&rng));
+        free_path = soc_draw_free_path(S, &rng, photons);
     }
 
     // SimRAM_HP conditions the direction itself, before it picks the entry point
     // (kernel_ASOC.c:919-922); only the counters and the first free path remain (:950-955)
-    __device__ __forceinline__ void begin_conditioned()
+    __device__ __forceinline__ void begin_conditioned(const SocSim &S)
     {
         scat = 0;
         tau  = 0.0f;
-        free_path = -soc_logf(soc_rand(&rng));
+        free_path = soc_draw_free_path(S, &rng, photons);
     }
 
     // One pass of the inner loop body (kernel_ASOC.c:565-683).  Returns true when the free
@@ -433,8 +474,8 @@ struct SocWalker {
         py = py + dx * uy;
         pz = pz + dx * uz;
         photons *= e;
-        free_path = -soc_logf(soc_rand(&rng));
-        soc_scatter(ux, uy, uz, sCSC, S.BINS, &rng);
+        free_path = soc_draw_free_path(S, &rng, photons);
+        soc_new_direction<CL_ORDER>(S, sCSC, oind, ux, uy, uz, free_path, &rng);
         if (!CL_ORDER && (scat > 20)) ind = -1;
         tau = 0.0f;
     }

@@ -35,6 +35,8 @@ API = {
     "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
     "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
     "soc_set_scatter_table": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
+    "soc_set_scatter_tables": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_int]),
+    "soc_set_step_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float]),
     "soc_set_emission": (C.c_int, [C.c_void_p, _F, _F]),
     "soc_set_emindex": (C.c_int, [C.c_void_p, _I]),
     "soc_set_ali": (C.c_int, [C.c_void_p, C.c_int]),
@@ -262,6 +264,20 @@ class Engine:
         CSC = np.ascontiguousarray(CSC, np.float32)
         DSC = None if DSC is None else np.ascontiguousarray(DSC, np.float32)
         self._chk(self.lib.soc_set_scatter_table(self.h, _f(DSC), _f(CSC), int(CSC.size)))
+
+    def set_scatter_tables(self, DSC, CSC):
+        """-D WITH_MSF: CSC[NDUST, BINS] (and DSC) per dust species; needs set_abundances + set_optical_abu per frequency"""
+        CSC = np.ascontiguousarray(CSC, np.float32)
+        if CSC.ndim != 2:
+            raise SocError("set_scatter_tables: CSC[NDUST, BINS]")
+        DSC = None if DSC is None else np.ascontiguousarray(DSC, np.float32)
+        if DSC is not None and DSC.shape != CSC.shape:
+            raise SocError("set_scatter_tables: DSC and CSC differ in shape")
+        self._chk(self.lib.soc_set_scatter_tables(self.h, int(CSC.shape[0]), _f(DSC), _f(CSC), int(CSC.shape[1])))
+
+    def set_step_weight(self, mode, SW_A=0.0, SW_B=0.0):
+        """values of -D STEP_WEIGHT, -D SW_A, -D SW_B (kernel_ASOC.c:516-535); mode 0 = off"""
+        self._chk(self.lib.soc_set_step_weight(self.h, int(mode), float(SW_A), float(SW_B)))
 
     def set_emission(self, EMIT, EMWEI=None):
         EMIT = np.ascontiguousarray(EMIT, np.float32)

@@ -93,6 +93,21 @@ def _roil(cloud, dim, nside, nbatch, **kw):
                BATCH=nbatch * 12 * nside * nside, ROI_LOAD=a, ROI_DIM=dim, ROI_NSIDE=nside, **kw)
 
 
+def msf_inputs(cloud, ndust=3, seed=6):
+    """-D WITH_MSF inputs: per-dust cross sections, scattering functions (different asymmetries), abundances per cell,
+    and the OPT array the host sums from them (ASOC.py:1146-1165)"""
+    rr = np.random.default_rng(seed)
+    ABS = (1e-4 * rr.uniform(0.5, 2, ndust)).astype(np.float32)
+    SCA = (3e-4 * rr.uniform(0.5, 2, ndust)).astype(np.float32)
+    CSC = np.stack([synth.hg_scattering_table(g)[1] for g in np.linspace(0.1, 0.7, ndust)]).astype(np.float32)
+    ABU = rr.uniform(0.2, 1.5, (cloud.CELLS, ndust)).astype(np.float32)
+    OPT = np.zeros((cloud.CELLS, 2), np.float32)
+    for i in range(ndust):
+        OPT[:, 0] += ABU[:, i] * ABS[i]
+        OPT[:, 1] += ABU[:, i] * SCA[i]
+    return dict(OPT=OPT, MSF=(ABS, SCA, CSC, ABU))
+
+
 CASES = {
     # name: (ref build, kind, job factory); kind 0 = SimRAM_PB, 1 = SimRAM_CL, 2 = SimRAM_HP
     "bg_c8": ("c8", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=50, SEED=0.6004384)),
@@ -146,6 +161,16 @@ CASES = {
                                                 EMIT=_emit(_oct8()), WITH_ALI=1)),
     "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
                                      EMIT=_emit(_c8()))),
+    # weighted free paths (-D STEP_WEIGHT=1|2 with SW_A, SW_B: kernel_ASOC.c:516-535) and per-dust scattering functions
+    "bg_c8_sw1": ("c8sw1", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=30, SEED=0.44, STEP_WEIGHT=(1, 0.5, 0.0))),
+    "bg_oct8_sw2": ("oct8sw2", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=20, SEED=0.45,
+                                               STEP_WEIGHT=(2, 0.7, 0.4))),
+    "cl_oct8_sw2": ("oct8sw2", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                               EMIT=_emit(_oct8()), STEP_WEIGHT=(2, 0.7, 0.4))),
+    "bg_oct8_msf": ("oct8msf", 0, lambda: Job(_oct8(), None, SOURCE=1, BATCH=20, SEED=0.46, **msf_inputs(_oct8()))),
+    "cl_oct8_msf": ("oct8msf", 1, lambda: Job(_oct8(), None, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128, EMIT=_emit(_oct8()),
+                                               **msf_inputs(_oct8()))),
+    "hp_oct8_msf": ("oct8msf", 2, lambda: Job(_oct8(), None, HPBG=hp_sky()[0], BATCH=4, SEED=0.12, GLOBAL=3072, **msf_inputs(_oct8()))),
 }
 
 # ---- scattered-light images (kernel_ASOC_sca.c) --------------------------------------------

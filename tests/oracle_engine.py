@@ -52,12 +52,21 @@ class OracleEngine:
                 OPT[:, 0] += ABU[:, d] * np.float32(AFABS[d])
                 OPT[:, 1] += ABU[:, d] * np.float32(AFSCA[d])
         self.OPT = OPT
+        self.af = (np.asarray(AFABS, np.float32).copy(), np.asarray(AFSCA, np.float32).copy())
 
     def read_opt(self):
         return self.OPT.copy()
 
     def set_scatter_table(self, DSC, CSC):
         self.DSC, self.CSC = DSC, CSC
+        self.msf_csc = None
+
+    def set_scatter_tables(self, DSC, CSC):
+        CSC = np.asarray(CSC, np.float32)
+        self.DSC, self.CSC, self.msf_csc = (None if DSC is None else np.asarray(DSC, np.float32)[0]), CSC[0], CSC.copy()
+
+    def set_step_weight(self, mode, SW_A=0.0, SW_B=0.0):
+        self.step_weight = None if mode <= 0 else (int(mode), float(SW_A), float(SW_B))
 
     def set_emission(self, EMIT, EMWEI=None):
         self.EMIT, self.EMWEI = EMIT, EMWEI
@@ -131,11 +140,15 @@ class OracleEngine:
         pass
 
     def _job(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, GLOBAL, PSPOS=None, PS=None, XPS=None):
+        msf = None
+        if getattr(self, "msf_csc", None) is not None:
+            msf = (self.af[0], self.af[1], self.msf_csc, self.ABU.reshape(self.cloud.CELLS, -1))
         return Job(self.cloud, self.CSC, ABS=self.ABS, SCA=self.SCA, SOURCE=SOURCE, BATCH=BATCH, SEED=SEED, BG=BG,
                    TW=TW, GLOBAL=GLOBAL, PACKETS=PACKETS, PSPOS=PSPOS if SOURCE == 0 else None,
                    PS=PS if SOURCE == 0 else None, PS_METHOD=self.feat["ps_method"], XPS=XPS if SOURCE == 0 else None,
                    OPT=self.OPT, EMIT=self.EMIT, EMWEI=self.EMWEI, USE_EMWEIGHT=self.feat["use_emweight"],
-                   WITH_INT=self.feat["with_int"], DSC=self.DSC, MIRROR=getattr(self, "mirror", 0))
+                   WITH_INT=self.feat["with_int"], DSC=self.DSC, MIRROR=getattr(self, "mirror", 0),
+                   STEP_WEIGHT=getattr(self, "step_weight", None), MSF=msf)
 
     def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None, GLOBAL=None,
                gid_first=0, gid_count=None):

@@ -355,6 +355,20 @@ def test_deferred_healpix_launches(engine, oracle_soc):
     assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["bg_oct8_sw2", "bg_oct8_msf"])
+def test_brick_sweep_octree_weighting_and_species(name, engine, oracle_soc, tuned):
+    """-D STEP_WEIGHT and -D WITH_MSF in the sweep's event workgroups (hierarchy in global memory; per-cell opacities)"""
+    tuned(brick_cells=100)
+    ref, kind, mk = cases.CASES[name]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    Tg, Ig, st = run_engine(engine, job, kind, exec_mode=1)
+    assert engine.last_passes() > 0
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)
+
+
 CLB = [n for n, (ref, kind, mk) in sorted(cases.CASES.items())
        if kind == 1 and not any(t in n for t in ("mirror", "emw2", "ali", "roi"))]
 

@@ -45,6 +45,20 @@ def test_background_packets(tune, engine, oracle_soc, tuned):
     engine.set_exec(-1, 4)
 
 
+@pytest.mark.parametrize("sw", [(1, 0.5, 0.0), (2, 0.7, 0.4)])
+def test_weighted_free_paths(sw, engine, oracle_soc):
+    """-D STEP_WEIGHT in the event workgroups of the brick-local form: creation and scattering draw the weighted path"""
+    cl = cloud104()
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=3, SEED=0.52, STEP_WEIGHT=sw)
+    g0, g1 = 200000, 205000
+    T, _, n = oracle_soc.sim(job, 0, gid0=g0, gid1=g1, nthreads=8)
+    Tg, _, st = _sweep(engine, job, 0, gid_first=g0, gid_count=g1 - g0)
+    assert st["tally_events"] == n and st["scatterings"] > 100
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_step_weight(0)
+    engine.set_exec(-1, 4)
+
+
 def test_older_sweep_is_a_second_witness(engine, tuned):
     cl = cloud104()
     job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=2, SEED=0.91)

@@ -187,7 +187,7 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("split 1\n", "stepweight 1 0.5 0.5\n", "psmethod 3\n"):
+    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
 
@@ -333,3 +333,82 @@ def test_abundance_run(single, tmp_path):
                   GLOBAL=L["GLOBAL"], WITH_INT=1, OPT=OPT)
         Oracle("soc").sim(job, 0, TABS=T)
     assert T.sum() > 0 and np.allclose(CT, T, rtol=2e-6)
+
+
+def test_stepweight_key(tmp_path):
+    """`stepweight a b c` reaches the kernels as -D SW_A=int(a) -D SW_B=b -D STEP_WEIGHT=int(c) (ASOC.py:348,357 -- not in
+    the order the key's comment suggests, ASOC_aux.py:476-481): the drop-in hands the engine those values"""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    os.chdir(d)
+    cloud = synth.cartesian_cloud(5, seed=3)
+    U = User(_write_model(d, cloud, nfreq=2, extra="stepweight 2 0.4 2\n"))
+    assert U.STEP_WEIGHT == [2, 0.4, 2.0]
+    eng = OracleEngine("soc")
+    run = AbsorptionRun(U, eng)
+    CT, _ = run.run()
+    assert eng.step_weight == (2, 2.0, 0.4)
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 2, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, cloud.AREA)
+    T = np.zeros(cloud.CELLS, np.float32)
+    T0 = np.zeros(cloud.CELLS, np.float32)
+    for i in range(2):
+        kw = dict(ABS=AFABS[0][i], SCA=AFSCA[0][i], SOURCE=1, BATCH=L["BATCH"], SEED=launch.launch_seed(math.pi / 4, i),
+                  BG=np.float32(float(IBG[i]) * L["WBG"] / float(FFREQ[i])), TW=launch.trapezoid_weight(FFREQ, i),
+                  GLOBAL=L["GLOBAL"], WITH_INT=1)
+        Oracle("soc").sim(Job(cloud, FCSC[0, i], STEP_WEIGHT=(2, 2.0, 0.4), **kw), 0, TABS=T)
+        Oracle("soc").sim(Job(cloud, FCSC[0, i], **kw), 0, TABS=T0)
+    assert T.sum() > 0 and np.array_equal(CT, T)
+    assert not np.array_equal(T, T0) and abs(T.sum(dtype=np.float64) / T0.sum(dtype=np.float64) - 1) < 0.05    # same physics, other weights
+    # a key absent from the ini file switches the weighting off
+    eng2 = OracleEngine("soc")
+    AbsorptionRun(User(_write_model(d, cloud, nfreq=2)), eng2).setup_engine()
+    assert eng2.step_weight is None
+
+
+def test_several_scattering_functions(tmp_path):
+    """one dsc file per dust species = -D WITH_MSF (ASOC.py:132-138): abundances are required, the engine receives the
+    tables of all species for every frequency and draws the scatterer per event"""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    os.chdir(d)
+    cloud = synth.octree_cloud(5, levels=2, frac=0.1, seed=4)
+    rr = np.random.default_rng(4)
+    abu = rr.uniform(0.2, 1.0, cloud.CELLS).astype(np.float32)
+    abu.tofile(os.path.join(d, "a.abu"))
+    GL = 5.0e-7
+    ini = _write_model(d, cloud, nfreq=2, extra="gridlength %g\n" % GL)
+    with open(os.path.join(d, "m2.dust"), "w") as fp:
+        fp.write("eqdust\n 1.0e-7\n 0.7e-4\n2\n 4.00000e+14  0.6  2.0e-2  1.2e-1\n 4.67700e+14  0.6  2.5e-2  1.0e-1\n")
+    dsc, csc = synth.hg_scattering_table(0.1, 500)
+    files.write_scattering_functions(os.path.join(d, "m2.dsc"), np.tile(dsc, (2, 1)), np.tile(csc, (2, 1)))
+    txt = open(ini).read().replace("optical %s/m.dust\n" % d, "optical %s/m.dust %s/a.abu\noptical %s/m2.dust\n" % (d, d, d))
+    open(ini, "w").write(txt.replace("dsc %s/m.dsc 500\n" % d, "dsc %s/m.dsc 500\ndsc %s/m2.dsc 500\n" % (d, d)))
+    run = AbsorptionRun(User(ini), OracleEngine("soc"))
+    assert run.WITH_MSF and run.NDUST == 2
+    CT, _ = run.run()
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust"), os.path.join(d, "m2.dust")], GL)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc"), os.path.join(d, "m2.dsc")], 2, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, cloud.AREA)
+    ABU = np.stack([abu, np.ones(cloud.CELLS, np.float32)], 1)
+    T = np.zeros(cloud.CELLS, np.float32)
+    for i in range(2):
+        OPT = np.zeros((cloud.CELLS, 2), np.float32)
+        for k in range(2):
+            OPT[:, 0] += ABU[:, k] * AFABS[k][i]
+            OPT[:, 1] += ABU[:, k] * AFSCA[k][i]
+        msf = ([AFABS[0][i], AFABS[1][i]], [AFSCA[0][i], AFSCA[1][i]], FCSC[:, i, :], ABU)
+        job = Job(cloud, None, SOURCE=1, BATCH=L["BATCH"], SEED=launch.launch_seed(math.pi / 4, i),
+                  BG=np.float32(float(IBG[i]) * L["WBG"] / float(FFREQ[i])), TW=launch.trapezoid_weight(FFREQ, i),
+                  GLOBAL=L["GLOBAL"], WITH_INT=1, OPT=OPT, MSF=msf)
+        Oracle("soc").sim(job, 0, TABS=T)
+    assert T.sum() > 0 and np.array_equal(CT, T)
+    # without abundances the reference stops (ASOC.py:168-170)
+    open(ini, "w").write(open(ini).read().replace(" %s/a.abu" % d, ""))
+    with pytest.raises(ValueError):
+        AbsorptionRun(User(ini), OracleEngine("soc"))

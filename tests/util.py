@@ -7,9 +7,17 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
     cl = job.cloud
     eng.set_cloud(cl)
     eng.set_features(with_int=job.WITH_INT, ps_method=job.PS_METHOD, use_emweight=job.USE_EMWEIGHT)
-    eng.set_scatter_table(job.DSC, job.CSC)
     eng.set_optical(job.ABS, job.SCA)
-    eng.set_opt(job.OPT)
+    eng.set_step_weight(*getattr(job, "STEP_WEIGHT", (0, 0.0, 0.0)))
+    if getattr(job, "MSF", None) is not None:            # -D WITH_MSF: abundances once, cross sections + tables per frequency
+        ABS, SCA, CSC, ABU = job.MSF
+        eng.set_abundances(ABU)
+        eng.set_optical_abu(ABS, SCA)
+        eng.set_scatter_tables(None, CSC)
+        assert np.array_equal(eng.read_opt().view(np.uint32), np.asarray(job.OPT, np.float32).view(np.uint32))
+    else:
+        eng.set_scatter_table(job.DSC, job.CSC)
+        eng.set_opt(job.OPT)
     eng.set_mirror(getattr(job, "MIRROR", 0))
     eng.set_exec(exec_mode, brick_log2)
     if job.ROI is not None:
@@ -47,6 +55,12 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
     if kind == 1 and job.WITH_ALI:
         job.XAB_gpu = eng.read_tally(2)
         eng.set_ali(0)
+    if getattr(job, "STEP_WEIGHT", (0,))[0] > 0:
+        eng.set_step_weight(0)                           # the session's engine goes back to the plain state
+    if getattr(job, "MSF", None) is not None:
+        eng.set_scatter_table(None, job.MSF[2][0])
+        eng.set_opt(None)
+        eng.set_abundances(None)
     return eng.read_tally(0), eng.read_tally(1), eng.stats()
 
 
