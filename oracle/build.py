@@ -133,7 +133,7 @@ def build_ref_a2e(tag, NE, NFREQ, LOCAL, CELLS, NIP=5000, force=False):
 
 
 def sca_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0, USE_EMWEIGHT=0, FFS=1, GL=0.01,
-             MIRROR=0, HPBG_WEIGHTED=0):
+             MIRROR=0, HPBG_WEIGHTED=0, WITH_MSF=0, NDUST=1):
     """The -D list of ASOCS.py:133-147 for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
     d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=0, PS_METHOD=PS_METHOD, CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS),
@@ -141,7 +141,7 @@ def sca_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_AB
              AYZ="%.5ff" % (NY * NZ / AREA), LEVELS=LEVELS, LENGTH="%.5ef" % (GL * 3.08567758e18), POLSTAT=0,
              SW_A="0.000e+00f", SW_B="0.000e+00f", STEP_WEIGHT=-1, DIR_WEIGHT=-1, DW_A="0.000e+00f", LEVEL_THRESHOLD=0,
              POLRED=0, WITH_COLDEN=0, MINLOS="-1.000e+00f", MAXLOS="1.000e+10f", FFS=FFS, BG_METHOD=0,
-             USE_EMWEIGHT=USE_EMWEIGHT, HPBG_WEIGHTED=HPBG_WEIGHTED, WITH_MSF=0, NDUST=1, OPT_IS_HALF=0, WITH_ROI_LOAD=0, ROI_NSIDE=16,
+             USE_EMWEIGHT=USE_EMWEIGHT, HPBG_WEIGHTED=HPBG_WEIGHTED, WITH_MSF=WITH_MSF, NDUST=NDUST, OPT_IS_HALF=0, WITH_ROI_LOAD=0, ROI_NSIDE=16,
              MIRROR=MIRROR, NVIDIA=0)
     return ["-D%s=%s" % (k, v) for k, v in d.items()]
 
@@ -236,6 +236,8 @@ def sca_ref_models():
         "c8hpw": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, HPBG_WEIGHTED=1),
         "oct8": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
         "oct8emw": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, USE_EMWEIGHT=1),
+        "c8msf": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ABU=1, WITH_MSF=1, NDUST=3, NO_PS=2),
+        "oct8msf": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, WITH_ABU=1, WITH_MSF=1, NDUST=3),
     }
 
 

@@ -100,7 +100,8 @@ class Job:
         self.HPBG = None if HPBG is None else np.ascontiguousarray(HPBG, np.float32)
         self.HPBGP = None if HPBGP is None else np.ascontiguousarray(HPBGP, np.float32)
         self.CSC = np.ascontiguousarray(CSC, np.float32)
-        self.DSC = np.ascontiguousarray(DSC if DSC is not None else np.ones_like(self.CSC), np.float32)
+        # discrete scattering function of the peel-off (sca kernels); with MSF one row per species, DSC[NDUST, BINS]
+        self.DSC = np.ascontiguousarray(DSC if DSC is not None else np.ones_like(self.CSC if self.MSF is None else self.MSF[2]), np.float32)
         self.BINS = len(self.CSC)
         self.ABS, self.SCA = np.float32(ABS), np.float32(SCA)
         self.SOURCE, self.BATCH = int(SOURCE), int(BATCH)
@@ -573,7 +574,7 @@ class SArgs(C.Structure):
                 ("SEED", C.c_float), ("BG", C.c_float), ("MAP_DX", C.c_float), ("CX", C.c_float), ("CY", C.c_float), ("CZ", C.c_float),
                 ("ABS", _F), ("SCA", _F), ("PSPOS", _F), ("PS", _F), ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
                 ("DENS", _F), ("EMIT", _F), ("DSC", _F), ("CSC", _F), ("ODIRS", _F), ("ORA", _F), ("ODE", _F), ("OUT", _F),
-                ("OPT", _F), ("EMWEI", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("HPBG", _F), ("HPBGP", _F)]
+                ("OPT", _F), ("EMWEI", _F), ("XPS_NSIDE", _I), ("XPS_SIDE", _I), ("XPS_AREA", _F), ("HPBG", _F), ("HPBGP", _F), ("ABU", _F)]
 
 
 def oracle_sim_sca(orc, job, view, kind=0, gid0=0, gid1=None, nthreads=1, stride=1, OUT=None):
@@ -619,6 +620,7 @@ class RefSca:
         assert int(job.OPT is not None) == m.get("WITH_ABU", 0) and job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1)) and job.PS_METHOD == m.get("PS_METHOD", 0)
         assert job.MIRROR == m.get("MIRROR", 0)
+        assert (0 if job.MSF is None else len(job.MSF[1])) == (m.get("NDUST", 1) if m.get("WITH_MSF", 0) else 0)
         PAR = np.zeros(max(1, cl.CELLS - cl.NX * cl.NY * cl.NZ), np.int32)
         self.lib.ref_sca_parents(_fp(job.DENS), _ip(job.LCELLS), _ip(job.OFF), _ip(PAR))
         OUT = np.zeros(view.out_size(), np.float32) if OUT is None else OUT
@@ -638,6 +640,9 @@ class RefSca:
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)
         a.HPBG, a.HPBGP = _fp(job.HPBG), _fp(job.HPBGP)
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
+        if job.MSF is not None:                      # -D WITH_MSF: ABS[NDUST], SCA[NDUST], DSC/CSC[NDUST*BINS], ABU[CELLS*NDUST]
+            a.ABS, a.SCA, a.CSC, a.ABU = _fp(job.MSF[0]), _fp(job.MSF[1]), _fp(job.MSF[2]), _fp(job.MSF[3])
+            assert job.DSC.size == job.MSF[2].size
         gid1 = job.GLOBAL if gid1 is None else gid1
         self.lib.ref_sca_sim(C.byref(a), kind, gid0, gid1, stride)
         return OUT

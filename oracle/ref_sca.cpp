@@ -31,6 +31,7 @@ struct sca_args {
     int   *XPS_NSIDE, *XPS_SIDE;      // int32 on the host, float* in the kernel (as in ASOCS.py)
     float *XPS_AREA;
     float *HPBG, *HPBGP;              // Healpix sky of the current frequency (sca SimRAM_HP)
+    float *ABU;                       // -D WITH_MSF: ABU[CELLS*NDUST]; ABS, SCA, DSC, CSC then hold NDUST entries / tables
 };
 
 // kind 0: SimRAM_PB, 1: SimRAM_CL, 2: SimRAM_PS, 3: SimRAM_HP; work items gid0, gid0+stride, ... < gid1
@@ -47,20 +48,20 @@ void ref_sca_sim(const sca_args *a, int kind, int gid0, int gid1, int stride)
         if (kind == 0)
             SimRAM_PB(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->BG, (float3 *)a->PSPOS, a->PS,
                       a->LCELLS, a->OFF, a->PAR, a->DENS, a->DSC, a->CSC, a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C,
-                      (float3 *)a->ORA, (float3 *)a->ODE, a->OUT, dummy, a->OPT ? a->OPT : dummy, (float *)a->XPS_NSIDE,
+                      (float3 *)a->ORA, (float3 *)a->ODE, a->OUT, a->ABU ? a->ABU : dummy, a->OPT ? a->OPT : dummy, (float *)a->XPS_NSIDE,
                       (float *)a->XPS_SIDE, a->XPS_AREA, idummy, dummy);
         else if (kind == 1)
             SimRAM_CL(a->SOURCE, a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->LCELLS, a->OFF, a->PAR, a->DENS, a->EMIT,
                       a->DSC, a->CSC, a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA, (float3 *)a->ODE,
-                      a->OUT, a->OPT ? a->OPT : dummy, dummy, a->EMWEI ? a->EMWEI : dummy);
+                      a->OUT, a->OPT ? a->OPT : dummy, a->ABU ? a->ABU : dummy, a->EMWEI ? a->EMWEI : dummy);
         else if (kind == 3)
             SimRAM_HP(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->LCELLS, a->OFF, a->PAR, a->DENS, a->DSC, a->CSC,
-                      a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA, (float3 *)a->ODE, a->OUT, dummy,
+                      a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA, (float3 *)a->ODE, a->OUT, a->ABU ? a->ABU : dummy,
                       a->OPT ? a->OPT : dummy, a->HPBG, a->HPBGP ? a->HPBGP : dummy);
         else
             SimRAM_PS(a->PACKETS, a->BATCH, a->SEED, a->ABS, a->SCA, a->BG, (float3 *)a->PSPOS, a->PS, a->LCELLS, a->OFF,
                       a->PAR, a->DENS, a->DSC, a->CSC, a->NDIR, (float3 *)a->ODIRS, NPIX, a->MAP_DX, C, (float3 *)a->ORA,
-                      (float3 *)a->ODE, a->OUT, dummy, a->OPT ? a->OPT : dummy, (float *)a->XPS_NSIDE, (float *)a->XPS_SIDE,
+                      (float3 *)a->ODE, a->OUT, a->ABU ? a->ABU : dummy, a->OPT ? a->OPT : dummy, (float *)a->XPS_NSIDE, (float *)a->XPS_SIDE,
                       a->XPS_AREA);
     }
 }

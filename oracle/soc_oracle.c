@@ -342,19 +342,28 @@ static float DrawFreePath(const orc_model *M, rng_t *rng, float *PHOTONS)
  * the scattering function of a dust species picked by its share of the cell's scattering cross section (WITH_MSF), or the
  * one table.  cl: SimRAM_CL keeps the cell's OPT value in free_path (:1662).  (-D DIR_WEIGHT > 0 does not compile in
  * the reference -- :770-775 use undeclared pweight, pind -- and is not restated.) */
+/* -D WITH_MSF: the species that scatters in cell oind, drawn with probabilities ABU*SCA/OPT.sca (kernel_ASOC.c:780-791;
+ * kernel_ASOC_sca.c:340-347, :427-431 and the same lines of the other kernels).  kernel_ASOC.c limits the index to
+ * NDUST-1 when rounding leaves ds > 0 after the last species; the sca kernels do not (they would read past DSC/CSC):
+ * the restatement limits it in both. */
+static int MsfDust(const orc_model *M, rng_t *rng, int oind)
+{
+    const int NDUST = M->MSF_NDUST;
+    const float dx = M->OPT[2 * (long)oind + 1];
+    float ds = 0.99999f * Rand(rng);
+    int   idust;
+    for (idust = 0; idust < NDUST; idust++) {
+        ds -= M->ABU[idust + NDUST * ((long)oind)] * M->MSF_SCA[idust] / dx;
+        if (ds <= 0.0) break;
+    }
+    if (idust >= NDUST) idust = NDUST - 1;
+    return idust;
+}
 static void NewDirection(const orc_model *M, f3 *DIR, rng_t *rng, int oind, float *PHOTONS, float *free_path, int cl)
 {
     if (M->MSF_NDUST > 1) {
-        const int NDUST = M->MSF_NDUST;
-        const float dx = M->OPT[2 * (long)oind + 1];
-        float ds = 0.99999f * Rand(rng);
-        int   idust;
-        if (cl) *free_path = dx;
-        for (idust = 0; idust < NDUST; idust++) {
-            ds -= M->ABU[idust + NDUST * ((long)oind)] * M->MSF_SCA[idust] / dx;
-            if (ds <= 0.0) break;
-        }
-        if (idust >= NDUST) idust = NDUST - 1;
+        if (cl) *free_path = M->OPT[2 * (long)oind + 1];                  /* SimRAM_CL: `free_path` is the scratch (:1662) */
+        const int idust = MsfDust(M, rng, oind);
         Scatter(DIR, M->CSC + (long)idust * M->BINS, M->BINS, rng);
     } else {
         Scatter(DIR, M->CSC, M->BINS, rng);
@@ -1168,7 +1177,7 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
     const int *OFF = M->OFF;
     const float ABS = M->ABS, SCA = M->SCA;
     const float CLAMP = is_cl ? 0.9999f : 0.999f;
-    int   oind = 0, ind0 = -1, level0 = 0, scatterings, i, j;
+    int   oind = 0, ind0 = -1, level0 = 0, scatterings, i, j, idust = 0;
     float ds, free_path, tau, dtau, delta, dx, cos_theta, W;
     f3    POS0, ODIR;
     long  nadd = 0;
@@ -1254,12 +1263,13 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
                 else             tau += ds * DENS[oind] * (ABS + SCA);
             }
             cos_theta = clampf(DIR.x * ODIR.x + DIR.y * ODIR.y + DIR.z * ODIR.z, -CLAMP, +CLAMP);
+            idust = (M->MSF_NDUST > 1) ? MsfDust(M, rng, OFF[level0] + ind0) : 0;     /* one draw per peel-off (:339-347) */
             if (is_cl) {
                 const float G = 0.65f;
                 const float fraction = (1.0f / (4.0f * PI_F)) * (1.0f - G * G) / M_POW15(1.0f + G * G - 2.0f * G * cos_theta);
                 delta *= PHOTONS * fraction * ((tau > TAULIM) ? (1.0f - M_EXP(-tau)) : (tau * (1.0f - 0.5f * tau)));
             } else {
-                delta *= PHOTONS * M_EXP(-tau) * M->DSC[clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
+                delta *= PHOTONS * M_EXP(-tau) * M->DSC[(long)idust * M->BINS + clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
             }
             {
                 const float theta = M_ACOS(-ODIR.z);
@@ -1280,6 +1290,7 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
                 else             tau += ds * DENS[oind] * (ABS + SCA);
             }
             cos_theta = clampf(DIR.x * ODIR.x + DIR.y * ODIR.y + DIR.z * ODIR.z, -CLAMP, +CLAMP);
+            idust = (M->MSF_NDUST > 1) ? MsfDust(M, rng, OFF[level0] + ind0) : 0;     /* one draw per observer (:382-390) */
             if (is_cl) {
                 /* kernel_ASOC_aux.c:1 has "#define HG_TEST 0" and SimRAM_CL tests "#ifdef HG_TEST"
                  * (:1387): the reference as shipped takes the analytic branch -- Henyey-Greenstein
@@ -1289,7 +1300,7 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
                 const float fraction = (1.0f / (4.0f * PI_F)) * (1.0f - G * G) / M_POW15(1.0f + G * G - 2.0f * G * cos_theta);
                 delta = PHOTONS * fraction * ((tau > TAULIM) ? (1.0f - M_EXP(-tau)) : (tau * (1.0f - 0.5f * tau)));
             } else {
-                delta = PHOTONS * M_EXP(-tau) * M->DSC[clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
+                delta = PHOTONS * M_EXP(-tau) * M->DSC[(long)idust * M->BINS + clampi((int)(M->BINS * (1.0f + cos_theta) * 0.5f), 0, M->BINS - 1)];
             }
             POS.x -= M->CX;  POS.y -= M->CY;  POS.z -= M->CZ;
             i = (0.5f * M->NPIX_X - 0.00005f) + (POS.x * M->ORA[4 * idir] + POS.y * M->ORA[4 * idir + 1] + POS.z * M->ORA[4 * idir + 2]) / M->MAP_DX;
@@ -1301,7 +1312,8 @@ static long walk_packet_sca(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, floa
             }
         }
         POS = POS0;  ind = ind0;  level = level0;
-        Scatter(&DIR, M->CSC, M->BINS, rng);
+        idust = (M->MSF_NDUST > 1) ? MsfDust(M, rng, OFF[level0] + ind0) : 0;         /* :424-432 */
+        Scatter(&DIR, M->CSC + (long)idust * M->BINS, M->BINS, rng);
         free_path = -M_LOG(Rand(rng));
         if (scatterings == MAX_SCATTERINGS) { ind = -1; continue; }
     }

@@ -31,6 +31,8 @@ class ScatteringRun(AbsorptionRun):
         U, c = self.U, self.cloud
         if U.ROIPAC > 0:
             raise UnsupportedOption("roiload in the scattering run")
+        if self.WITH_ABU and U.SINGLE_ABU:
+            raise UnsupportedOption("singleabu in the scattering run (ASOCS.py does not know the key: it reads ABU[CELLS, NDUST], :51-55)")
         if len(U.file_hpbg) > 2:                                   # ASOCS.py:104-107: no user scaling here
             self.HPBG = np.fromfile(U.file_hpbg, np.float32).reshape(self.NFREQ, 49152)
         self.healpix = U.INTOBS[0] > -10000.0                      # ASOCS.py:44-48: one Healpix map seen from INTOBS
@@ -74,6 +76,8 @@ class ScatteringRun(AbsorptionRun):
         e.set_cloud(c)
         e.set_features(with_int=0, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 1))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
+        if self.WITH_ABU:
+            e.set_abundances(self.ABU)                         # once; OPT per frequency on the device (ASOCS.py:519-523)
         if self.healpix:
             e.sca_set_healpix(U.OUT_NSIDE, U.INTOBS, U.FFS)
             npix = 12 * U.OUT_NSIDE * U.OUT_NSIDE
@@ -156,7 +160,7 @@ class ScatteringRun(AbsorptionRun):
                 PS = (self.LPS[:, IFREQ] * np.float32(WPS)) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
                 if U.USE_EMWEIGHT > 0:
                     self._update_emwei(IFREQ)
-                e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                self._scatter_tables_for(IFREQ)
                 seed = self._seed(IFREQ, True)
                 if II == 2:
                     if IFREQ >= self.DIFFUSERAD.shape[1]:
@@ -204,7 +208,7 @@ class ScatteringRun(AbsorptionRun):
                     continue
                 t0 = time.time()
                 self._optical_for(IFREQ)
-                e.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+                self._scatter_tables_for(IFREQ)
                 EMIT[:] = self.EMITTED[:, IFREQ - self.REMIT_I1]
                 for level in range(c.LEVELS):
                     coeff = 1.0e-20 * U.GL * PARSEC / (8.0 ** level)

@@ -1166,7 +1166,6 @@ static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVaria
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "%s: call soc_sca_set_view first", who);
     if (kind != SOC_SCA_CL && kind != SOC_SCA_HP && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
     if (c->BINS > 8000) return fail(c, SOC_ERR_ARG, "%s: BINS=%d > 8000", who, c->BINS);
-    if (c->msf_ndust > 1) return fail(c, SOC_ERR_ARG, "%s: scattered-light images with %d scattering functions (WITH_MSF) are not implemented", who, c->msf_ndust);
     SocSca X = c->view;
     X.kind = kind;
     X.DSC = c->dDSC;

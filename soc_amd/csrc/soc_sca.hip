@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                 if (idir >= 0) {
                     const float CL = CLW ? 0.9999f : 0.999f;
                     const float cos_theta = soc_clampf(dx_ * w.ux + dy_ * w.uy + dz_ * w.uz, -CL, +CL);
+                    // -D WITH_MSF: one species per peel-off, its DSC row (kernel_ASOC_sca.c:339-347, :382-390; SimRAM_CL draws too)
+                    const int idust = (S.NDUST > 1) ? soc_msf_dust(S, &w.rng, sOFF[mlevel] + mind) : 0;
                     float delta;
                     if (CLW) {
                         const float g = 0.65f;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                     } else {
                         int b = (int)(S.BINS * (1.0f + cos_theta) * 0.5f);
                         b = b < 0 ? 0 : (b > S.BINS - 1 ? S.BINS - 1 : b);
-                        delta = w.photons * soc_expf(-taup) * sDSC[b];
+                        delta = w.photons * soc_expf(-taup) * ((S.NDUST > 1) ? V.DSC[(long)idust * S.BINS + b] : sDSC[b]);
                     }
                     if (HPX) {
                         // 1/d^2 and the pixel of the direction towards the observer (:352-360)
@@ -171,7 +173,12 @@ __global__ __launch_bounds__(256) void soc_sca_kernel(const SocGrid G, const Soc
                     // back to the packet at the scattering position; new direction, new free path
                     w.px = mx;  w.py = my;  w.pz = mz;  w.level = mlevel;  w.ind = mind;  w.dens = mdens;
                     w.ux = dx_;  w.uy = dy_;  w.uz = dz_;
-                    soc_scatter(w.ux, w.uy, w.uz, sCSC, S.BINS, &w.rng);
+                    if (S.NDUST > 1) {                                              // :424-432
+                        const int idust = soc_msf_dust(S, &w.rng, sOFF[mlevel] + mind);
+                        soc_scatter(w.ux, w.uy, w.uz, S.CSC + (long)idust * S.BINS, S.BINS, &w.rng);
+                    } else {
+                        soc_scatter(w.ux, w.uy, w.uz, sCSC, S.BINS, &w.rng);
+                    }
                     free_path = -soc_logf(soc_rand(&w.rng));
                     tau = 0.0f;
                     mode = (scat == SCA_MAX_SCATTERINGS) ? SCA_M_CREATE : SCA_M_MAIN;

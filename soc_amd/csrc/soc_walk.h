@@ -247,23 +247,31 @@ __device__ __forceinline__ float soc_draw_free_path(const SocSim &S, soc_rng_t *
     return fp;
 }
 
-// New direction after a scattering in cell oind.  -D WITH_MSF (kernel_ASOC.c:777-795): the scatterer is one of NDUST
-// species, drawn with probabilities ABU*SCA/OPT.sca, and its own cumulative scattering function is used.  SimRAM_CL
-// reuses `free_path` as scratch for OPT.sca there (:1662), so the next free path of such a packet IS that number.
+// -D WITH_MSF: the species that scatters in cell oind, drawn with probabilities ABU*SCA/OPT.sca (kernel_ASOC.c:780-791;
+// kernel_ASOC_sca.c:340-347, :427-431).  kernel_ASOC.c limits the index to NDUST-1 when rounding leaves ds > 0 after the
+// last species; the sca kernels would read past their tables there -- limited in both here.
+__device__ __forceinline__ int soc_msf_dust(const SocSim &S, soc_rng_t *rng, const int oind)
+{
+    const float dx = S.OPT[oind].y;
+    float ds = 0.99999f * soc_rand(rng);
+    int idust = 0;
+    for (; idust < S.NDUST; idust++) {
+        ds -= S.ABU[idust + (long)S.NDUST * oind] * S.MSF_SCA[idust] / dx;
+        if (ds <= 0.0f) break;
+    }
+    return (idust >= S.NDUST) ? S.NDUST - 1 : idust;
+}
+
+// New direction after a scattering in cell oind.  With -D WITH_MSF the species' own cumulative scattering function is
+// used (kernel_ASOC.c:777-795); SimRAM_CL reuses `free_path` as scratch for OPT.sca there (:1662), so the next free path
+// of such a packet IS that number.
 template <bool CL_ORDER>
 __device__ __forceinline__ void soc_new_direction(const SocSim &S, const float *sCSC, const int oind, float &ux, float &uy, float &uz,
                                                   float &free_path, soc_rng_t *rng)
 {
     if (S.NDUST > 1) {
-        const float dx = S.OPT[oind].y;
-        float ds = 0.99999f * soc_rand(rng);
-        int idust = 0;
-        if (CL_ORDER) free_path = dx;
-        for (; idust < S.NDUST; idust++) {
-            ds -= S.ABU[idust + (long)S.NDUST * oind] * S.MSF_SCA[idust] / dx;
-            if (ds <= 0.0f) break;
-        }
-        if (idust >= S.NDUST) idust = S.NDUST - 1;
+        if (CL_ORDER) free_path = S.OPT[oind].y;
+        const int idust = soc_msf_dust(S, rng, oind);
         soc_scatter(ux, uy, uz, S.CSC + (long)idust * S.BINS, S.BINS, rng);
     } else {
         soc_scatter(ux, uy, uz, sCSC, S.BINS, rng);

@@ -67,6 +67,10 @@ def _hpjob(cloud, ref_weighted, **kw):
     return Job(cloud, _CSC, ABS=1e-4, SCA=3e-4, HPBG=bg, HPBGP=P, **kw)
 
 
+def _hpjob_msf():
+    return Job(_oct8(), None, HPBG=hp_sky()[0], BATCH=6, SEED=0.11, GLOBAL=4096, **msf_inputs(_oct8(), dsc=True))
+
+
 def _emindex(cloud, n=300, seed=3):
     """USE_EMWEIGHT==2 inputs: a list of emitting leaf cells (terminated by -1) and packet weights"""
     rr = np.random.default_rng(seed)
@@ -93,18 +97,21 @@ def _roil(cloud, dim, nside, nbatch, **kw):
                BATCH=nbatch * 12 * nside * nside, ROI_LOAD=a, ROI_DIM=dim, ROI_NSIDE=nside, **kw)
 
 
-def msf_inputs(cloud, ndust=3, seed=6):
+def msf_inputs(cloud, ndust=3, seed=6, dsc=False):
     """-D WITH_MSF inputs: per-dust cross sections, scattering functions (different asymmetries), abundances per cell,
     and the OPT array the host sums from them (ASOC.py:1146-1165)"""
     rr = np.random.default_rng(seed)
     ABS = (1e-4 * rr.uniform(0.5, 2, ndust)).astype(np.float32)
     SCA = (3e-4 * rr.uniform(0.5, 2, ndust)).astype(np.float32)
-    CSC = np.stack([synth.hg_scattering_table(g)[1] for g in np.linspace(0.1, 0.7, ndust)]).astype(np.float32)
+    tabs = [synth.hg_scattering_table(g) for g in np.linspace(0.1, 0.7, ndust)]
+    CSC = np.stack([t[1] for t in tabs]).astype(np.float32)
     ABU = rr.uniform(0.2, 1.5, (cloud.CELLS, ndust)).astype(np.float32)
     OPT = np.zeros((cloud.CELLS, 2), np.float32)
     for i in range(ndust):
         OPT[:, 0] += ABU[:, i] * ABS[i]
         OPT[:, 1] += ABU[:, i] * SCA[i]
+    if dsc:
+        return dict(OPT=OPT, MSF=(ABS, SCA, CSC, ABU), DSC=np.stack([t[0] for t in tabs]).astype(np.float32))
     return dict(OPT=OPT, MSF=(ABS, SCA, CSC, ABU))
 
 
@@ -244,6 +251,15 @@ SCA_CASES = {
                                         EMIT=_emit(_c8()), DSC=_DSC), {}),
     "sca_cl_oct8": ("oct8", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
                                             EMIT=_emit(_oct8()), DSC=_DSC), {}),
+    # -D WITH_MSF: the species is drawn per peel-off (its DSC row) and per scattering (its CSC row)
+    "sca_bg_oct8_msf": ("oct8msf", 0, lambda: Job(_oct8(), None, SOURCE=1, BATCH=8, SEED=0.41, **msf_inputs(_oct8(), dsc=True)), {}),
+    "sca_hpx_bg_oct8_msf": ("oct8msf", 0, lambda: Job(_oct8(), None, SOURCE=1, BATCH=6, SEED=0.43, **msf_inputs(_oct8(), dsc=True)),
+                            dict(healpix=(8, (20.0, 5.0, 5.5)))),
+    "sca_ps_c8_msf": ("c8msf", 2, lambda: Job(_c8(), None, SOURCE=0, BATCH=20, SEED=0.2, GLOBAL=256, PSPOS=_PS_IN, PS=[1.0, 2.0],
+                                               **msf_inputs(_c8(), dsc=True)), {}),
+    "sca_cl_oct8_msf": ("oct8msf", 1, lambda: Job(_oct8(), None, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128, EMIT=_emit(_oct8()),
+                                                   **msf_inputs(_oct8(), dsc=True)), {}),
+    "sca_hp_oct8_msf": ("oct8msf", 3, lambda: _hpjob_msf(), {}),
     "sca_cl_oct8_emw": ("oct8emw", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
                                                    EMIT=_emit(_oct8()), EMWEI=_emwei(_oct8()), USE_EMWEIGHT=1, DSC=_DSC), {}),
 }

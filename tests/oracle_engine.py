@@ -63,7 +63,7 @@ class OracleEngine:
 
     def set_scatter_tables(self, DSC, CSC):
         CSC = np.asarray(CSC, np.float32)
-        self.DSC, self.CSC, self.msf_csc = (None if DSC is None else np.asarray(DSC, np.float32)[0]), CSC[0], CSC.copy()
+        self.DSC, self.CSC, self.msf_csc = (None if DSC is None else np.asarray(DSC, np.float32).copy()), CSC[0], CSC.copy()
 
     def set_step_weight(self, mode, SW_A=0.0, SW_B=0.0):
         self.step_weight = None if mode <= 0 else (int(mode), float(SW_A), float(SW_B))

@@ -17,9 +17,14 @@ GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "sca.npz"))
 def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True, rebind=None):
     eng.set_cloud(job.cloud)
     eng.set_features(with_int=0, ps_method=job.PS_METHOD, use_emweight=job.USE_EMWEIGHT)
-    eng.set_scatter_table(job.DSC, job.CSC)
     eng.set_optical(job.ABS, job.SCA)
-    eng.set_opt(job.OPT)
+    if job.MSF is not None:                      # -D WITH_MSF: one DSC/CSC row per species, OPT built from the abundances
+        eng.set_abundances(job.MSF[3])
+        eng.set_optical_abu(job.MSF[0], job.MSF[1])
+        eng.set_scatter_tables(job.DSC, job.MSF[2])
+    else:
+        eng.set_scatter_table(job.DSC, job.CSC)
+        eng.set_opt(job.OPT)
     eng.set_mirror(job.MIRROR)
     if view.nside:
         eng.sca_set_healpix(view.nside, view.ODIR[0, :3], view.FFS)
@@ -45,6 +50,10 @@ def run_sca(eng, job, view, kind, gid_first=0, gid_count=None, zero=True, rebind
         eng.set_emission(job.EMIT, job.EMWEI)
         eng.sca_sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
     eng.sync()
+    if job.MSF is not None:
+        eng.set_scatter_table(None, job.MSF[2][0])
+        eng.set_opt(None)
+        eng.set_abundances(None)
     return eng.sca_read_out(), eng.stats()
 
 

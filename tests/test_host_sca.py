@@ -161,3 +161,47 @@ def test_perspective_and_healpix_background(tmp_path):
     want = img * np.float32(float(FFREQ[i]) * 1.0e23 * launch.PLANCK / (4.0 * np.pi / (12.0 * 16.0)))
     np.testing.assert_allclose(OUTC[i], want, rtol=2e-6)
     assert n > 0 and OUTC[i].sum() > 0
+
+
+def test_scattering_run_with_several_scattering_functions(tmp_path):
+    """-D WITH_MSF in the scattering run (ASOCS.py:26-30, :622-629): the tables of all species per frequency"""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca
+    d = str(tmp_path)
+    os.chdir(d)
+    cloud = synth.cartesian_cloud(5, seed=2)
+    rr = np.random.default_rng(4)
+    abu = rr.uniform(0.2, 1.0, cloud.CELLS).astype(np.float32)
+    abu.tofile(os.path.join(d, "a.abu"))
+    GL = 5.0e-7
+    ini = _ini(d, cloud, nfreq=2, extra="gridlength %g\n" % GL)
+    with open(os.path.join(d, "m2.dust"), "w") as fp:
+        fp.write("eqdust\n 1.0e-7\n 0.7e-4\n2\n 4.00000e+14  0.6  2.0e-2  1.2e-1\n 4.67700e+14  0.6  2.5e-2  1.0e-1\n")
+    dsc, csc = synth.hg_scattering_table(0.1, 500)
+    files.write_scattering_functions(os.path.join(d, "m2.dsc"), np.tile(dsc, (2, 1)), np.tile(csc, (2, 1)))
+    txt = open(ini).read().replace("optical %s/m.dust\n" % d, "optical %s/m.dust %s/a.abu\noptical %s/m2.dust\n" % (d, d, d))
+    open(ini, "w").write(txt.replace("dsc %s/m.dsc 500\n" % d, "dsc %s/m.dsc 500\ndsc %s/m2.dsc 500\n" % (d, d)))
+    run = ScatteringRun(User(ini), OracleEngine("soc"))
+    assert run.WITH_MSF
+    OUTC = run.run()
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust"), os.path.join(d, "m2.dust")], GL)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc"), os.path.join(d, "m2.dsc")], 2, 500)
+    _, OD, RA, DE = launch.set_observer_directions([math.radians(30), math.radians(90)], [math.radians(40), 0.0])
+    view = ScaView(OD, RA, DE, NPIX=(12, 10), MAP_DX=0.8, CENTRE=(2.5, 2.5, 2.5), FFS=1)
+    ABU = np.stack([abu, np.ones(cloud.CELLS, np.float32)], 1)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    L = launch.bg_launch(run.BGPAC, cloud.AREA)
+    for i in range(2):
+        FREQ = float(FFREQ[i])
+        OPT = np.zeros((cloud.CELLS, 2), np.float32)
+        for k in range(2):
+            OPT[:, 0] += ABU[:, k] * AFABS[k][i]
+            OPT[:, 1] += ABU[:, k] * AFSCA[k][i]
+        msf = ([AFABS[0][i], AFABS[1][i]], [AFSCA[0][i], AFSCA[1][i]], FCSC[:, i, :], ABU)
+        seed = math.fmod(math.pi / 4 + launch.SEED0 + i * launch.SEED1, 1.0)
+        job = Job(cloud, None, SOURCE=1, BATCH=L["BATCH"], SEED=seed, GLOBAL=L["GLOBAL"],
+                  BG=np.float32(float(IBG[i]) * L["WBG"] / FREQ), OPT=OPT, MSF=msf, DSC=FDSC[:, i, :])
+        img, n = oracle_sim_sca(Oracle("soc"), job, view, 0)
+        want = img.reshape(2, 10, 12) * np.float32(FREQ * 1.0e23 * launch.PLANCK / (0.8 * 0.8))
+        assert n > 1000
+        np.testing.assert_allclose(OUTC[i], want, rtol=1e-6)
