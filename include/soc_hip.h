@@ -34,6 +34,9 @@ typedef struct soc_ctx soc_ctx;
 #define SOC_TALLY_TABS    0   /* absorbed energy integrated over frequency (TABS, kernel arg 15) */
 #define SOC_TALLY_INT     1   /* per-frequency absorptions (INT, kernel arg 20)                  */
 #define SOC_TALLY_XAB     2   /* WITH_ALI: absorptions inside the emitting cell (XAB, kernel arg 19) */
+#define SOC_TALLY_INTX    3   /* SAVE_INTENSITY==2: sum of delta*DIR.x per cell (INTX, kernel arg 21); soc_zero(1) clears  */
+#define SOC_TALLY_INTY    4   /*   INT and these three, as ZeroAMC tag 1 does (kernel_ASOC_aux.c:676-681)                   */
+#define SOC_TALLY_INTZ    5
 
 /* replaces ASOC_aux.py:1188-1256 opencl_init(): create a context on GPU `device` */
 int  soc_create(int device, soc_ctx **out);
@@ -55,7 +58,9 @@ int soc_set_stream(soc_ctx *ctx, void *hip_stream);
 int soc_set_grid(soc_ctx *ctx, int NX, int NY, int NZ, int LEVELS, const int32_t *LCELLS, const float *DENS);
 
 /* feature switches the reference compiles in with -D (ASOC.py:344-362):
- *   with_int     : SAVE_INTENSITY in (1,2) or NOABSORBED==0 -> INT tally is updated
+ *   with_int     : 1 = SAVE_INTENSITY==1 or NOABSORBED==0 -> INT tally is updated; 2 = SAVE_INTENSITY==2 -> INT and the
+ *                  vector sums INTX, INTY, INTZ (kernel_ASOC.c:604-612, :724-732; needs soc_set_grid first; such launches
+ *                  run on the direct kernels)
  *   ps_method    : PS_METHOD 0,1,2,4,5 (3 does not compile in the reference)
  *   use_emweight : USE_EMWEIGHT 0, 1, or 2 = cells listed by soc_set_emindex (SimRAM_CL)     */
 int soc_set_features(soc_ctx *ctx, int with_int, int ps_method, int use_emweight);
@@ -99,6 +104,11 @@ int soc_set_opt(soc_ctx *ctx, const float *OPT);
 int soc_set_abundances(soc_ctx *ctx, int NDUST, int single, const float *ABU);
 int soc_set_optical_abu(soc_ctx *ctx, const float *AFABS, const float *AFSCA, int ndust);
 int soc_read_opt(soc_ctx *ctx, float *OPT);
+
+/* -D OPT_IS_HALF (ini key `optishalf`; kernel_ASOC_aux.c:12-18, ASOC.py:1158-1159): the reference stores OPT as fp16.
+ * on != 0: every later soc_set_opt / soc_set_optical_abu rounds OPT to fp16 (nearest even) -- the kernels then compute
+ * with exactly the values vload_half would give them. */
+int soc_set_opt_half(soc_ctx *ctx, int on);
 
 /* replaces the DSC/CSC row uploads (ASOC.py:1234-1243, ASOCS.py:625-626); DSC may be NULL
  * (unused by the absorption kernels, required by soc_sca_sim_ps/pb); BINS = USER.DSC_BINS */

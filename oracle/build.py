@@ -258,6 +258,8 @@ def ref_models():
     m = {
         "c8":      dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512),
         "c8int":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, NOABSORBED=0),
+        "c8int2":  dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, SAVE_INTENSITY=2),
+        "oct8int2": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, SAVE_INTENSITY=2),
         "c8abu":   dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, WITH_ABU=1),
         "r654":    dict(NX=6, NY=5, NZ=4, LEVELS=1, CELLS=120),
         "c16":     dict(NX=16, NY=16, NZ=16, LEVELS=1, CELLS=4096),

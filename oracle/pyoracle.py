@@ -43,6 +43,7 @@ class OrcModel(C.Structure):
         ("WITH_ROI_LOAD", C.c_int), ("ROI_DIM", C.c_int * 3), ("ROI_LOAD", _F),
         ("STEP_WEIGHT", C.c_int), ("SW_A", C.c_float), ("SW_B", C.c_float),
         ("MSF_NDUST", C.c_int), ("MSF_SCA", _F), ("ABU", _F),
+        ("INTV", _F),
     ]
 
 
@@ -127,7 +128,8 @@ class Job:
         self.EMIT = np.ascontiguousarray(EMIT if EMIT is not None else np.zeros(cloud.CELLS), np.float32)
         self.EMWEI = np.ascontiguousarray(EMWEI if EMWEI is not None else np.ones(cloud.CELLS), np.float32)
         self.USE_EMWEIGHT = int(USE_EMWEIGHT)
-        self.WITH_INT = int(WITH_INT)
+        self.WITH_INT = int(WITH_INT)             # 2 = -D SAVE_INTENSITY=2: INT and the vector sums INTV[3, CELLS] = INTX, INTY, INTZ
+        self.INTV = np.zeros((3, cloud.CELLS), np.float32) if self.WITH_INT == 2 else None
         self.LCELLS = np.ascontiguousarray(cloud.LCELLS, np.int32)
         self.OFF = np.ascontiguousarray(cloud.OFF, np.int32)
         self.DENS = np.ascontiguousarray(cloud.DENS, np.float32)
@@ -180,7 +182,8 @@ class Oracle:
         m.NX, m.NY, m.NZ, m.LEVELS, m.CELLS = cl.NX, cl.NY, cl.NZ, cl.LEVELS, cl.CELLS
         m.BINS, m.PS_METHOD, m.NO_PS = job.BINS, job.PS_METHOD, max(1, job.NO_PS)
         m.WITH_ABU = int(job.OPT is not None)
-        m.WITH_INT, m.USE_EMWEIGHT = job.WITH_INT, job.USE_EMWEIGHT
+        m.WITH_INT, m.USE_EMWEIGHT = int(job.WITH_INT > 0), job.USE_EMWEIGHT
+        m.INTV = _fp(job.INTV) if job.INTV is not None else None
         m.DOUBLE_INDEX = double_index(cl.NX, cl.LEVELS)
         m.LCELLS, m.OFF, m.DENS = _ip(job.LCELLS), _ip(job.OFF), _fp(job.DENS)
         if job.PAR is None:
@@ -328,7 +331,8 @@ class Ref:
         assert job.PS_METHOD == m.get("PS_METHOD", 0)
         assert int(job.OPT is not None) == m.get("WITH_ABU", 0)
         assert job.USE_EMWEIGHT == m.get("USE_EMWEIGHT", 0)
-        assert job.WITH_INT == int(m.get("NOABSORBED", 1) == 0 or m.get("SAVE_INTENSITY", 0) in (1, 2))
+        assert int(job.WITH_INT > 0) == int(m.get("NOABSORBED", 1) == 0 or m.get("SAVE_INTENSITY", 0) in (1, 2))
+        assert (job.WITH_INT == 2) == (m.get("SAVE_INTENSITY", 0) == 2)
         assert max(1, job.NO_PS) == max(1, m.get("NO_PS", 1))
         assert int(job.HPBGP is not None) == m.get("HPBG_WEIGHTED", 0)
         assert job.MIRROR == m.get("MIRROR", 0)
@@ -434,6 +438,8 @@ class Ref:
         a.DENS, a.EMIT, a.TABS = _fp(job.DENS), _fp(job.EMIT), _fp(TABS)
         a.DSC, a.CSC, a.XAB, a.EMWEI = _fp(job.DSC), _fp(CSC), _fp(job.XAB), _fp(job.EMWEI)
         a.INT, a.INTX, a.INTY, a.INTZ = _fp(INT), _fp(dummy), _fp(dummy), _fp(dummy)
+        if job.INTV is not None:
+            a.INTX, a.INTY, a.INTZ = (job.INTV[k].ctypes.data_as(_F) for k in range(3))
         a.OPT = _fp(job.OPT) if job.OPT is not None else _fp(dummy)
         a.ABU = _fp(ABU)
         a.XPS_NSIDE, a.XPS_SIDE, a.XPS_AREA = _ip(job.XPS_NSIDE), _ip(job.XPS_SIDE), _fp(job.XPS_AREA)

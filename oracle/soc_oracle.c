@@ -129,6 +129,7 @@ typedef struct {
     int   STEP_WEIGHT;  float SW_A, SW_B;
     int   MSF_NDUST;
     const float *MSF_SCA, *ABU;
+    float *INTV;                      /* -D SAVE_INTENSITY=2: INTX | INTY | INTZ, CELLS floats each (kernel_ASOC.c:604-612) */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -536,6 +537,11 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
             if ((M->WITH_ALI == 1) && (oind == e_index)) tally(M, M->XAB, oind, delta * M->TW);   /* :1486-1491, :1589-1594 */
             else tally(M, M->TABS, oind, delta * M->TW * 1.0f);
             if (M->WITH_INT) tally(M, M->INT, oind, delta);
+            if (M->INTV) {                                               /* net flux vector, :604-612 */
+                tally(M, M->INTV, oind, delta * DIR.x);
+                tally(M, M->INTV + M->CELLS, oind, delta * DIR.y);
+                tally(M, M->INTV + 2 * (long)M->CELLS, oind, delta * DIR.z);
+            }
             nt++;
             PHOTONS *= M_EXP(-tauA);
             tau += dtau;
@@ -570,6 +576,11 @@ static long walk_packet(const orc_model *M, rng_t *rng, f3 POS, f3 DIR, float PH
         if ((M->WITH_ALI == 1) && (oind == e_index)) tally(M, M->XAB, oind, delta * M->TW);   /* :1486-1491, :1589-1594 */
             else tally(M, M->TABS, oind, delta * M->TW * 1.0f);
         if (M->WITH_INT) tally(M, M->INT, oind, delta);
+        if (M->INTV) {                                                   /* :724-732 */
+            tally(M, M->INTV, oind, delta * DIR.x);
+            tally(M, M->INTV + M->CELLS, oind, delta * DIR.y);
+            tally(M, M->INTV + 2 * (long)M->CELLS, oind, delta * DIR.z);
+        }
         nt++;
         dx = M_LDEXP_UP(dx, level0);
         dx = fmaxf(0.0f, dx - 2.0f * PEPS);

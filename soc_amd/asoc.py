@@ -40,14 +40,42 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("direweight (-D DIR_WEIGHT > 0 does not compile in the reference: pweight, pind undeclared, kernel_ASOC.c:770-775)")
     if USER.ROI_MAP:
         bad.append("roimap")
-    if USER.SAVE_INTENSITY == 2:
-        bad.append("saveint 2 (intensity vectors)")
     if USER.PS_METHOD == 3:
         bad.append("psmethod 3 (does not compile in the reference either)")
-    if USER.OPT_IS_HALF:
-        bad.append("optishalf")
-    if USER.WITH_REFERENCE:
-        bad.append("reference (reference field)")
+    if USER.WITH_REFERENCE and USER.SAVE_INTENSITY > 0:
+        bad.append("saveint with the reference field (ASOC.py:994 asserts against it: the tallies hold differences)")
+    if 'SUBITERATIONS' in USER.KEYS:
+        bad.append("SUBITERATIONS (sub-iterations of the reference field, ASOC.py:2261-2720)")
+    # keys the parser knows (soc_amd/ini.py keeps the reference's keyword set) whose effect is not built: refused, so that
+    # an ini file using them stops here instead of finishing with products missing or different
+    if USER.ABSTHIN > 1:
+        bad.append("absthin (absorptions of every n:th cell only)")
+    if USER.POLMAP or USER.POLSIM or len(USER.BFILES) > 0 or len(getattr(USER, "file_polred", "")) > 0:
+        bad.append("polmap / polred / magnetic-field files (polarisation maps)")
+    if USER.FAST_MAP >= 2:
+        bad.append("mapping with a fourth argument >= 2 (FAST_MAP: all frequencies at once / one map per hierarchy level)")
+    if USER.MAP_INTERPOLATION > 0 or USER.INTERPOLATE > 0:
+        bad.append("mapint / interpolate (interpolated map integration)")
+    if USER.LEVEL_THRESHOLD > 0:
+        bad.append("threshold (maps without the coarse hierarchy levels)")
+    if USER.CR_HEATING > 0:
+        bad.append("CR_HEATING")
+    if len(USER.kernel_defs.strip()) > 0:
+        bad.append("DEFS (extra -D options for the OpenCL compiler)")
+    if len(USER.file_pssavetau) > 0:
+        bad.append("pssavetau (optical depths towards the point sources)")
+    if len(USER.file_external_mask) > 0:
+        bad.append("externalmask (SUBITERATIONS)")
+    if len(USER.file_sourcemap) > 0:
+        bad.append("sourcemap")
+    if USER.BG_METHOD != 0:
+        bad.append("bgmethod")
+    if USER.Y_SHEAR != 0.0:
+        bad.append("yshear")
+    if getattr(USER, "FITS", 0) > 0 and not USER.NOMAP:
+        bad.append("fits (FITS containers need astropy, which the reference imports for them; drop the key for the .bin files)")
+    if USER.LOAD_TEMPERATURE and USER.ITERATIONS > 0 and USER.WITH_ALI:
+        bad.append("loadtemp with ALI iterations (the old temperatures enter the escape-probability correction, ASOC.py:2064-2071)")
     if bad:
         raise UnsupportedOption("ini options not supported by this engine: " + ", ".join(bad))
 
@@ -126,7 +154,11 @@ class AbsorptionRun:
         # launch size for point-source / cell-emission launches: reference default 32768
         # (ASOC.py:86), `global` keyword overrides (more work items fill an MI355X better)
         self.GLOBAL_0 = U.GLOBAL if U.GLOBAL > 0 else launch.GLOBAL_0
-        self.with_int = int((U.SAVE_INTENSITY in (1, 2)) or (not U.NOABSORBED))
+        self.with_int = 2 if U.SAVE_INTENSITY == 2 else int((U.SAVE_INTENSITY == 1) or (not U.NOABSORBED))
+        if U.SAVE_INTENSITY > 0 and self.WITH_ABU:
+            # ASOC.py:1499-1515 divides by ABS, which the abundance branch never sets (:1146-1165 fill OPT only)
+            raise UnsupportedOption("saveint with an abundance file (the reference scales the intensity by 1/ABS = 1/0 there)")
+        self.INTENSITY = None
 
     def write_packet_info(self, path="packet.info"):
         """int32 [BGPAC, PSPAC, DFPAC, CLPAC] (ASOC.py:251)"""
@@ -145,6 +177,8 @@ class AbsorptionRun:
         if sw > 0 or hasattr(e, "set_step_weight"):
             e.set_step_weight(sw, float("%.3e" % int(U.STEP_WEIGHT[0])), float("%.3e" % U.STEP_WEIGHT[1]))
         if self.WITH_ABU:
+            if U.OPT_IS_HALF or hasattr(e, "set_opt_half"):
+                e.set_opt_half(bool(U.OPT_IS_HALF))            # OPT as fp16 (ASOC.py:1158-1159)
             e.set_abundances(self.ABU, single=bool(U.SINGLE_ABU))
         if self.comm:
             self.comm.attach(e, c.CELLS)
@@ -173,6 +207,33 @@ class AbsorptionRun:
             self.eng.set_scatter_tables(self.FDSC[:, IFREQ, :], self.FCSC[:, IFREQ, :])
         else:
             self.eng.set_scatter_table(self.FDSC[0, IFREQ, :], self.FCSC[0, IFREQ, :])
+
+    def _save_intensity(self, IFREQ, FREQ, ABS, TMP):
+        """saveint 1|2: the per-frequency INT tally (already summed over ranks) becomes the mean intensity of the cells,
+        INTENSITY += (h*f/ABS) * 8^level * INT / n; saveint 2 adds the vector sums INTX, INTY, INTZ the same way
+        (ASOC.py:1499-1515, :1895-1908)"""
+        U, c, e = self.U, self.cloud, self.eng
+        comps = [TMP]
+        if U.SAVE_INTENSITY == 2:
+            for which in (3, 4, 5):
+                v = e.read_tally(which)
+                if self.comm and self.world > 1:
+                    v = self.comm.all_reduce_host(v)
+                comps.append(v)
+        if self.rank != 0:
+            return
+        if self.INTENSITY is None:
+            self.INTENSITY = files.create_intensity_file(U.SAVE_INTENSITY_FILE, c.CELLS, self.NFREQ, U.SAVE_INTENSITY == 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for icomp, v in enumerate(comps):
+                for level in range(c.LEVELS):
+                    # float32 throughout, as numpy evaluates KDEV*(PLANCK*FREQ/ABS)*(8.0**level) with ABS a float32 array
+                    coeff = np.float32(launch.PLANCK * FREQ) / np.float32(ABS) * np.float32(8.0 ** level)
+                    a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
+                    if U.SAVE_INTENSITY == 2:
+                        self.INTENSITY[a:b, IFREQ, icomp] += coeff * v[a:b] / c.DENS[a:b]
+                    else:
+                        self.INTENSITY[a:b, IFREQ] += coeff * v[a:b] / c.DENS[a:b]
 
     def simulate_constant_sources(self):
         """for II in (point sources, background, diffuse): for IFREQ: launch (ASOC.py:1028-1545).
@@ -231,7 +292,7 @@ class AbsorptionRun:
             # (Hierarchies: one launch at a time; with `global` large enough each is a brick sweep of its own, the INT
             # tally in LDS beside TABS -- DESIGN.md.)
             int_batched = (self.with_int and FABSORBED is not None and self.ROI_SAVE is None and II != 3 and c.LEVELS == 1
-                           and hasattr(e, "batch_begin_int"))
+                           and U.SAVE_INTENSITY == 0 and hasattr(e, "batch_begin_int"))
             group = []
 
             def end_group():
@@ -308,8 +369,12 @@ class AbsorptionRun:
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
                 t0 = time.time()
-                if FABSORBED is not None and not int_batched:
-                    FABSORBED[:, IFREQ] += e.read_tally(1)
+                if (FABSORBED is not None or U.SAVE_INTENSITY > 0) and not int_batched:
+                    TMP = e.read_tally(1)
+                    if FABSORBED is not None:
+                        FABSORBED[:, IFREQ] += TMP
+                    if U.SAVE_INTENSITY > 0:
+                        self._save_intensity(IFREQ, FREQ, ABS, TMP)
                 if self.ROI_SAVE is not None:
                     # += : point sources, background and a loaded record all pass here; GL^2 scales away the
                     # dependence on the current grid length (ASOC.py:1466-1475)
@@ -377,10 +442,30 @@ class AbsorptionRun:
         beta = None
         hostrng = np.random.default_rng(int(U.SEED * 2 ** 31) if U.SEED > 0 else None)
         EMIT = np.zeros(CELLS, np.float32)
+        # reference field (`reference` key, ASOC.py:796-812, :1571-1586): the packets of an iteration carry the CHANGE of
+        # the emission since the previous one, EMITTED - OEMITTED; the absorptions the previous emission caused, OTABS,
+        # are added back on the host.  Both are damped by k = iteration/ITERATIONS at the start of an iteration, so the
+        # first one simulates the full field.  reference = AABB continues a run of AA iterations at iteration BB.
+        ref = int(U.WITH_REFERENCE)
+        OEMITTED = OTABS = OXAB = OXEM = None
+        if ref > 0 and self.CLPAC > 0:
+            if I2 - I1 + 1 != NFREQ:
+                raise ValueError("the reference field needs emission at every simulated frequency (ASOC.py:797)")
+            OEMITTED = np.zeros((CELLS, NFREQ), np.float32)
+            OTABS = np.zeros(CELLS, np.float32)
+            if ref > 1 and ref % 100 > 0:
+                OEMITTED[:, :] = np.fromfile('OEMITTED.save', np.float32).reshape(CELLS, NFREQ)
+                OTABS[:] = np.fromfile('OTABS.save', np.float32)
+            if ali:
+                OXAB, OXEM = np.zeros(CELLS, np.float32), np.zeros(CELLS, np.float32)
         for iteration in range(U.ITERATIONS):
             self.log("ITERATION %d/%d" % (iteration + 1, U.ITERATIONS))
             e.zero(0)
             XEM = np.full(CELLS, 1.0e-32, np.float64) if ali else None      # ASOC.py:1606
+            if OEMITTED is not None:                                         # ASOC.py:1607-1632
+                k = iteration / float(U.ITERATIONS) if ref == 1 else (iteration + ref % 100) / float(ref // 100)
+                OEMITTED *= np.float32(k)
+                OTABS *= np.float32(k)
             if self.CLPAC > 0:
                 GLOBAL, BATCH = self.GLOBAL_0, max(1, int(self.CLPAC / CELLS))
                 first, count = self.comm.shard(GLOBAL) if self.comm else (0, GLOBAL)
@@ -397,12 +482,16 @@ class AbsorptionRun:
                     if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
                         continue
                     t0 = time.time()
-                    self._optical_for(IFREQ)
+                    ABS_f, _ = self._optical_for(IFREQ)
                     FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
                     self._scatter_tables_for(IFREQ)
                     if IFREQ < I1 or IFREQ > I2:
                         continue
-                    EMIT[:] = EMITTED[:, IFREQ - I1]
+                    if OEMITTED is not None:                       # ASOC.py:1728-1735
+                        EMIT[:] = EMITTED[:, IFREQ - I1] - OEMITTED[:, IFREQ - I1]
+                        OEMITTED[:, IFREQ - I1] = EMITTED[:, IFREQ - I1]
+                    else:
+                        EMIT[:] = EMITTED[:, IFREQ - I1]
                     for level in range(c.LEVELS):
                         coeff = U.GL * PARSEC / (8.0 ** level) / launch.FACTOR
                         a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
@@ -455,8 +544,12 @@ class AbsorptionRun:
                         e.sync()
                     self.timers["Tkernel"] += time.time() - t0
                     self.packets += CELLS * BATCH
-                    if iteration == U.ITERATIONS - 1 and FABSORBED is not None:
-                        FABSORBED[:, IFREQ] += e.read_tally(1)
+                    if iteration == U.ITERATIONS - 1 and (FABSORBED is not None or U.SAVE_INTENSITY > 0):
+                        TMP = e.read_tally(1)
+                        if FABSORBED is not None:
+                            FABSORBED[:, IFREQ] += TMP
+                        if U.SAVE_INTENSITY > 0:                   # ASOC.py:1885-1908
+                            self._save_intensity(IFREQ, FREQ, ABS_f, TMP)
                 if deferred:
                     t0 = time.time()
                     e.batch_end()
@@ -466,9 +559,19 @@ class AbsorptionRun:
                     self.comm.all_reduce_tally(e, 0)
                     if ali:
                         self.comm.all_reduce_tally(e, 2)
-                EABS = e.read_tally(0) + CTABS
-                if ali:
-                    beta = (XEM - e.read_tally(2)) / XEM           # escape probability (ASOC.py:1939-1942)
+                if OEMITTED is not None:
+                    # the device holds the absorptions of EMITTED - OEMITTED: add what OEMITTED caused (ASOC.py:1965-1975)
+                    EABS = e.read_tally(0) + OTABS
+                    OTABS[:] = EABS
+                    EABS = EABS + CTABS
+                    if ali:                                        # ASOC.py:1925-1936
+                        OXAB += e.read_tally(2)
+                        OXEM += np.asarray(XEM, np.float32)
+                        beta = (OXEM - OXAB) / OXEM
+                else:
+                    EABS = e.read_tally(0) + CTABS
+                    if ali:
+                        beta = (XEM - e.read_tally(2)) / XEM       # escape probability (ASOC.py:1939-1942)
             else:
                 EABS = np.array(CTABS, np.float32)
             if solve:
@@ -484,6 +587,25 @@ class AbsorptionRun:
             if len(U.file_temperature) > 0:
                 files.write_temperature(U.file_temperature, c, TNEW)
             files.write_emitted(U.file_emitted, EMITTED)
+            if OEMITTED is not None and ref > 1:                   # for the run that continues this one (ASOC.py:2251-2253)
+                OEMITTED.tofile('OEMITTED.save')
+                OTABS.tofile('OTABS.save')
+        return TNEW, EMITTED
+
+    def emission_from_temperature_file(self):
+        """`loadtemp` with `iterations 0` (ASOC.py:700-764): the emission of an equilibrium dust from a stored temperature
+        file, through the Emission kernel; written to the `emitted` file and used for the maps"""
+        U, e, c = self.U, self.eng, self.cloud
+        if self.NDUST > 1:
+            raise ValueError("loadtemp recomputes the emission of a single equilibrium dust (ASOC.py:757-760 uses AFABS[0])")
+        m = np.nonzero((self.FFREQ >= U.REMIT_F[0]) & (self.FFREQ <= U.REMIT_F[1]))[0]
+        I1, I2 = int(m[0]), int(m[-1])
+        TNEW = files.read_temperature(U.file_temperature, c)
+        FACTOR_f, LENGTH_f = launch.kernel_literals(U.GL)
+        e.set_temperature(TNEW)
+        EMITTED = np.asarray(e.emission(self.FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], FACTOR_f, LENGTH_f), np.float32)
+        if self.rank == 0 and len(U.file_emitted) > 0:
+            files.write_emitted(U.file_emitted, EMITTED)
         return TNEW, EMITTED
 
     # ---------------------------------------------------------------------------------
@@ -491,11 +613,14 @@ class AbsorptionRun:
         """Surface-brightness maps from the emission (ASOC.py:2924-3177, the plain `Mapping` path): for every
         direction map_dir_XX.bin = int32 NPIX.x, NPIX.y + one float32 [NPIX.y, NPIX.x] image [Jy/sr] per selected
         frequency.  `perspective` gives the longitude x latitude image seen from that position.  Optical-depth
-        images for `savetau` frequencies are written as <file>_tau_<um>.bin.  FITS containers, Healpix maps
-        (NPIX.y <= 0), map interpolation, ROI maps and polarisation maps are not produced."""
+        images for `savetau` frequencies are written as <file>_tau_<um>.bin.  NPIX.y < 0: write_healpix_maps.  FITS
+        containers, map interpolation, ROI maps and polarisation maps are refused (_check_supported)."""
         U, e, c = self.U, self.eng, self.cloud
-        if U.NPIX[1] <= 0:
-            raise UnsupportedOption("Healpix emission maps (mapping with NPIX.y <= 0)")
+        if U.NPIX[1] == 0:
+            self.log("mapping with NPIX.y == 0: neither the flat (NPIX.y > 0, ASOC.py:2924) nor the Healpix branch (NPIX.y < 0, :3185)")
+            return
+        if U.NPIX[1] < 0:
+            return self.write_healpix_maps(EMITTED)
         NFREQ, FFREQ = self.NFREQ, self.FFREQ
         m = np.nonzero((FFREQ >= U.REMIT_F[0]) & (FFREQ <= U.REMIT_F[1]))[0]
         I1, I2 = int(m[0]), int(m[-1])
@@ -538,6 +663,39 @@ class AbsorptionRun:
         for fp in fps:
             fp.close()
 
+    def write_healpix_maps(self, EMITTED):
+        """`mapping NSIDE -1 dx`: all-sky map of the emission seen from `perspective` (HealpixMapping, kernel_ASOC_map.c),
+        file layout of ASOC.py:3185-3320: map_dir_00_H.bin = int32 [NPIX.x, NPIX.y], int32 [frequencies, LEVELS], then one
+        float32 [12*NSIDE^2] map [Jy/sr] per frequency of the emitted range inside `wavelength`.
+        The reference itself stops in this branch with a NameError (SAVE_COLDEN is never assigned, :3291/:3297) after
+        writing the two headers; this writes the file its loop describes, with SAVE_COLDEN = 0 (no column-density file:
+        its savetau tests compare a list with a float, :3303-3306)."""
+        U, e, c = self.U, self.eng, self.cloud
+        FFREQ = self.FFREQ
+        m = np.nonzero((FFREQ >= U.REMIT_F[0]) & (FFREQ <= U.REMIT_F[1]))[0]
+        I1, I2 = int(m[0]), int(m[-1])
+        NSIDE = int(U.NPIX[0])
+        _, ODIR, RA, DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+        centre = U.MAPCENTRE if U.MAPCENTRE[0] > -1e7 else (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)
+        KK = (1.0e23 / launch.FACTOR) * PLANCK / (4.0 * np.pi) * (U.GL * PARSEC)
+        _, LENGTH_f = launch.kernel_literals(U.GL)
+        sel = [i for i in range(I1, I2 + 1) if U.MAP_FREQ[0] <= float(FFREQ[i]) <= U.MAP_FREQ[1]]
+        fp = None
+        if self.rank == 0:
+            fp = open("map_dir_%02d_H.bin" % 0, "wb")              # NDIR = 1 for Healpix maps (ASOC.py:2917)
+            np.asarray([U.NPIX[0], U.NPIX[1]], np.int32).tofile(fp)
+            np.asarray([len(sel), c.LEVELS], np.int32).tofile(fp)
+        for IFREQ in sel:
+            FREQ = float(FFREQ[IFREQ])
+            ABS, SCA = self._optical_for(IFREQ)
+            EMIT = np.asarray(EMITTED[:, IFREQ - I1] * np.float32(KK) * np.float32(FREQ), np.float32)    # :3283
+            MAP, _ = e.map(EMIT, ODIR[0], RA[0], DE[0], U.NPIX, U.MAP_DX, centre, ABS, SCA, INTOBS=U.INTOBS, save_colden=0,
+                           LENGTH=LENGTH_f, healpix=NSIDE)
+            if fp:
+                np.asarray(MAP, np.float32).tofile(fp)
+        if fp:
+            fp.close()
+
     def _bcast_seed(self, seed):
         t = self.comm.torch.tensor([seed], dtype=self.comm.torch.float64,
                                    device="cuda" if self.comm.backend == "nccl" else "cpu")
@@ -554,8 +712,13 @@ class AbsorptionRun:
         self.TNEW, self.EMITTED = None, None
         if U.ITERATIONS > 0 and (self.CLPAC > 0 or ((not U.NOSOLVE) and U.NOABSORBED)) and hasattr(self.eng, "solve_temperature"):
             self.TNEW, self.EMITTED = self.emission_iterations(CTABS, FABSORBED)
+        elif U.LOAD_TEMPERATURE and U.ITERATIONS < 1 and hasattr(self.eng, "emission"):
+            self.TNEW, self.EMITTED = self.emission_from_temperature_file()
         if (not U.NOMAP) and self.EMITTED is not None and hasattr(self.eng, "map"):
             self.write_maps(self.EMITTED)
+        if self.rank == 0 and self.INTENSITY is not None:          # ASOC.py:2733-2757
+            files.finish_intensity_file(U.SAVE_INTENSITY_FILE, self.INTENSITY, self.cloud.CELLS, self.NFREQ, U.SAVE_INTENSITY == 2)
+            self.INTENSITY = None
         if self.rank == 0:
             if len(U.file_constant_save) > 0:
                 CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549

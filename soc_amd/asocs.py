@@ -40,6 +40,8 @@ class ScatteringRun(AbsorptionRun):
             self.NDIR = -int(U.OUT_NSIDE)
         else:
             self.NDIR, self.ODIR, self.RA, self.DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+        if U.FITS > 0 and self.NDIR == 1:
+            raise UnsupportedOption("fits (ASOCS.py:885-892 writes the images with astropy; drop the key for outcoming.socs)")
         if U.MAPCENTRE[0] < -1e7:                                  # ASOC_aux.py:791-793
             U.MAPCENTRE = (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)
         m = np.nonzero((self.FFREQ >= U.REMIT_F[0]) & (self.FFREQ <= U.REMIT_F[1]))[0]
@@ -77,6 +79,8 @@ class ScatteringRun(AbsorptionRun):
         e.set_features(with_int=0, ps_method=U.PS_METHOD, use_emweight=min(max(U.USE_EMWEIGHT, 0), 1))
         e.set_mirror(launch.mirror_mask(U.MIRROR))
         if self.WITH_ABU:
+            if U.OPT_IS_HALF or hasattr(e, "set_opt_half"):
+                e.set_opt_half(bool(U.OPT_IS_HALF))            # ASOCS.py:524-525
             e.set_abundances(self.ABU)                         # once; OPT per frequency on the device (ASOCS.py:519-523)
         if self.healpix:
             e.sca_set_healpix(U.OUT_NSIDE, U.INTOBS, U.FFS)
@@ -241,8 +245,6 @@ class ScatteringRun(AbsorptionRun):
                 k = float(self.FFREQ[IFREQ]) * 1.0e23 * PLANCK / (U.MAP_DX * U.MAP_DX)
             OUTCOMING[IFREQ] *= k
         if self.rank == 0:
-            if U.FITS > 0 and self.NDIR == 1:
-                self.log("fits output requested: writing outcoming.socs (same data; FITS container not produced)")
             if self.healpix:
                 files.write_outcoming_healpix("outcoming.socs", U.OUT_NSIDE, self.FFREQ, OUTCOMING)
             else:

@@ -37,11 +37,14 @@ struct soc_ctx {
     bool   have_optical = false;
     float2 *dOPT = nullptr;
     float *dEMIT = nullptr, *dEMWEI = nullptr, *dXAB = nullptr;
+    float *dINTV = nullptr;            // -D SAVE_INTENSITY=2: INTX | INTY | INTZ, CELLS floats each (with_int == 2)
+    size_t intv_cells = 0;
     int   *dEMINDEX = nullptr;
     bool   have_emit = false, have_emindex = false, with_ali = false;
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
     float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
     int    abu_ndust = 0, abu_single = 0;
+    bool   opt_half = false;          // -D OPT_IS_HALF: OPT rounded through fp16 (soc_set_opt_half)
     bool   opt_from_abu = false;       // dOPT and dAF hold the current frequency's soc_set_optical_abu values
     int    msf_ndust = 1;              // > 1: -D WITH_MSF, dCSC/dDSC hold [msf_ndust][BINS] (soc_set_scatter_tables)
     int    step_weight = 0;            // -D STEP_WEIGHT (soc_set_step_weight)
@@ -238,7 +241,7 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dINTslots, c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    void *bufs[] = { c->dINTslots, c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dINTV, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -317,6 +320,7 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
         // everything else that is sized by the cell count
         if (c->dT) { (void)hipFree(c->dT); c->dT = nullptr; }
         if (c->dXAB) { (void)hipFree(c->dXAB); c->dXAB = nullptr; }
+        if (c->dINTV) { (void)hipFree(c->dINTV); c->dINTV = nullptr;  c->intv_cells = 0;  if (c->with_int == 2) c->with_int = 1; }
         if (c->dEMINDEX) { (void)hipFree(c->dEMINDEX); c->dEMINDEX = nullptr; }
         c->have_T = false;  c->with_ali = false;  c->have_emindex = false;
         c->abu_ndust = 0;  c->abu_cells = 0;
@@ -337,7 +341,17 @@ int soc_set_features(soc_ctx *c, int with_int, int ps_method, int use_emweight)
         return fail(c, SOC_ERR_ARG, "soc_set_features: PS_METHOD %d not supported (0,1,2,4,5)", ps_method);
     if (use_emweight < 0 || use_emweight > 2)
         return fail(c, SOC_ERR_ARG, "soc_set_features: USE_EMWEIGHT %d not supported (0,1,2)", use_emweight);
-    c->with_int = with_int ? 1 : 0;
+    if (with_int == 2) {                                    // SAVE_INTENSITY == 2: three more tallies (kernel_ASOC.c:604-612)
+        if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_features: with_int 2 needs soc_set_grid first (it allocates INTX, INTY, INTZ)");
+        HIPCHK(c, hipSetDevice(c->device));
+        if (c->intv_cells != (size_t)c->G.CELLS) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_alloc(&c->dINTV, (size_t)3 * c->G.CELLS));
+            c->intv_cells = (size_t)c->G.CELLS;
+            HIPCHK(c, hipMemsetAsync(c->dINTV, 0, (size_t)3 * c->G.CELLS * 4, c->stream));
+        }
+    }
+    c->with_int = (with_int == 2) ? 2 : (with_int ? 1 : 0);
     c->ps_method = ps_method;
     c->use_emweight = use_emweight;
     return SOC_OK;
@@ -409,7 +423,15 @@ int soc_set_opt(soc_ctx *c, const float *OPT)
     }
     if (!c->dOPT) HIPCHK(c, dev_alloc(&c->dOPT, (size_t)c->G.CELLS));
     HIPCHK(c, hipMemcpyAsync(c->dOPT, OPT, (size_t)c->G.CELLS * 8, hipMemcpyHostToDevice, c->stream));
+    if (c->opt_half) HIPCHK(c, soc_launch_opt_half(c->G.CELLS, c->dOPT, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_set_opt_half(soc_ctx *c, int on)
+{
+    if (!c) return SOC_ERR_ARG;
+    c->opt_half = on != 0;                                  // applies to the next soc_set_opt / soc_set_optical_abu
     return SOC_OK;
 }
 
@@ -452,6 +474,7 @@ int soc_set_optical_abu(soc_ctx *c, const float *AFABS, const float *AFSCA, int 
     HIPCHK(c, hipMemcpyAsync(c->dAF, af, (size_t)2 * ndust * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));             // af is on the stack
     HIPCHK(c, soc_launch_opt(c->G.CELLS, ndust, c->abu_single, c->dABU, c->dAF, c->dOPT, c->stream));
+    if (c->opt_half) HIPCHK(c, soc_launch_opt_half(c->G.CELLS, c->dOPT, c->stream));
     c->opt_from_abu = true;
     return SOC_OK;
 }
@@ -560,6 +583,8 @@ static float *tally_buf(soc_ctx *c, int which)
     if (which == SOC_TALLY_TABS) return c->dTABS;
     if (which == SOC_TALLY_INT) return c->dINT;
     if (which == SOC_TALLY_XAB) return c->with_ali ? c->dXAB : nullptr;
+    if (which >= SOC_TALLY_INTX && which <= SOC_TALLY_INTZ)
+        return (c->with_int == 2 && c->dINTV) ? c->dINTV + (size_t)(which - SOC_TALLY_INTX) * c->G.CELLS : nullptr;
     return nullptr;
 }
 
@@ -574,6 +599,8 @@ int soc_zero(soc_ctx *c, int tag)
     HIPCHK(c, hipMemsetAsync(b, 0, (size_t)c->G.CELLS * 4, c->stream));
     if (tag == SOC_TALLY_TABS && c->with_ali && c->dXAB)           // ZeroAMC tag 0 clears TABS and XAB (kernel_ASOC_aux.c:664-668)
         HIPCHK(c, hipMemsetAsync(c->dXAB, 0, (size_t)c->G.CELLS * 4, c->stream));
+    if (tag == SOC_TALLY_INT && c->with_int == 2 && c->dINTV)      // ... tag 1 INT and the three vector sums (:676-681)
+        HIPCHK(c, hipMemsetAsync(c->dINTV, 0, (size_t)3 * c->G.CELLS * 4, c->stream));
     return SOC_OK;
 }
 
@@ -607,12 +634,13 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     S.TABS = c->dTABS; S.INT = c->dINT;
     S.stats = c->dStats;
     S.STEP_WEIGHT = c->step_weight;  S.SW_A = c->sw_a;  S.SW_B = c->sw_b;
+    S.INTV = (c->with_int == 2) ? c->dINTV : nullptr;  S.CELLS = c->G.CELLS;
     S.NDUST = c->msf_ndust;
     if (c->msf_ndust > 1) { S.MSF_SCA = c->dAF + c->msf_ndust;  S.ABU = c->dABU; }
     V.octree = c->G.LEVELS > 1;
     V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);   // DIMLIM, kernel_ASOC_aux.c:25-37
     V.abu = c->dOPT != nullptr;
-    V.wint = c->with_int;
+    V.wint = c->with_int ? 1 : 0;
 }
 
 // Point sources of one launch -> device.  xps_as_float: the scattered-light kernels declare
@@ -721,12 +749,12 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, roisave/roiload, > 15 levels or > 2^18 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, with_int 2, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
     const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
@@ -961,11 +989,11 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     // the brick sweep as for soc_sim_pb: the walk is SimRAM_PB's, only the creation of a packet differs
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2;
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, > 15 levels or > 2^18 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, with_int 2, > 15 levels or > 2^18 bricks)");
     const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0))
@@ -1020,12 +1048,12 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
-        return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
+        return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, with_int 2, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
     const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0))

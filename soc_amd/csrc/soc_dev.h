@@ -56,6 +56,8 @@ struct SocSim {
     int    NDUST;              /* > 1: -D WITH_MSF, CSC holds [NDUST][BINS] (kernel_ASOC.c:777-795)          */
     const float  *MSF_SCA;     /* [NDUST] scattering cross sections of the species, current frequency       */
     const float  *ABU;         /* [CELLS][NDUST] abundances                                                  */
+    float  *INTV;              /* -D SAVE_INTENSITY=2: INTX | INTY | INTZ (CELLS each), else NULL; direct kernels only */
+    int     CELLS;             /* stride of INTV                                                             */
 };
 
 #define SOC_SOURCE_HP 4        /* brick sweep only: the launch is a SimRAM_HP one (Healpix sky instead of BG) */
@@ -111,6 +113,7 @@ hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LE
 
 // OPT from abundances on the device (soc_emit.hip)
 hipError_t soc_launch_opt(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT, hipStream_t st);
+hipError_t soc_launch_opt_half(int cells, float2 *OPT, hipStream_t st);
 
 // map making (soc_map.hip): one launch of Mapping / HealpixMapping (kernel_ASOC_map.c:496-516, 890-910)
 struct SocMapArgs {

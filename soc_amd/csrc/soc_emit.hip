@@ -90,6 +90,25 @@ __global__ void soc_opt_kernel(int cells, int ndust, int single, const float *AB
     }
 }
 
+// -D OPT_IS_HALF: the reference keeps OPT as fp16 (numpy float32 -> float16, round to nearest even, ASOC.py:1158-1159)
+// and the kernels widen it again with vload_half (kernel_ASOC_aux.c:12-14).  Widening is exact, so a float array holding
+// the fp16-rounded values gives the kernels the same numbers.
+__global__ void soc_opt_half_kernel(int cells, float2 *OPT)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < cells; i += (long)gridDim.x * blockDim.x) {
+        const float2 o = OPT[i];
+        OPT[i] = make_float2((float)(_Float16)o.x, (float)(_Float16)o.y);
+    }
+}
+
+hipError_t soc_launch_opt_half(int cells, float2 *OPT, hipStream_t st)
+{
+    if (cells <= 0) return hipSuccess;
+    const int blocks = (cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384;
+    soc_opt_half_kernel<<<blocks, 256, 0, st>>>(cells, OPT);
+    return hipGetLastError();
+}
+
 hipError_t soc_launch_opt(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT, hipStream_t st)
 {
     if (cells <= 0) return hipSuccess;

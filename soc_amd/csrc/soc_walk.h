@@ -377,6 +377,14 @@ struct SocWalker {
         else                            soc_tally(S.TABS, oind, delta * S.TW);
     }
 
+    // -D SAVE_INTENSITY=2: the net flux through the cell, delta * DIR (kernel_ASOC.c:604-612, :724-732)
+    __device__ __forceinline__ void intensity_vector(const SocSim &S, int oind, float delta)
+    {
+        soc_tally(S.INTV, oind, delta * ux);
+        soc_tally(S.INTV + S.CELLS, oind, delta * uy);
+        soc_tally(S.INTV + 2 * (long)S.CELLS, oind, delta * uz);
+    }
+
     // after creation: kernel_ASOC.c:508-519
     __device__ __forceinline__ void begin(const SocSim &S)
     {
@@ -430,7 +438,10 @@ struct SocWalker {
         float e = soc_expf(-tauA);
         float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
         deposit(S, oind, delta);
-        if (WINT) soc_tally(S.INT, oind, delta);
+        if (WINT) {
+            soc_tally(S.INT, oind, delta);
+            if (S.INTV) intensity_vector(S, oind, delta);
+        }
         n_tally++;
         photons *= e;
         tau += dtau;
@@ -473,7 +484,10 @@ struct SocWalker {
         float e = soc_expf(-tauA);
         float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
         deposit(S, oind, delta);
-        if (WINT) soc_tally(S.INT, oind, delta);
+        if (WINT) {
+            soc_tally(S.INT, oind, delta);
+            if (S.INTV) intensity_vector(S, oind, delta);
+        }
         n_tally++;
         n_scat++;
         dx = soc_scale_up(dx, level);

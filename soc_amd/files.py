@@ -299,6 +299,24 @@ def write_temperature(filename, cloud, TNEW):
             TNEW[a:b].tofile(fp)
 
 
+def read_temperature(filename, cloud):
+    """temperature file (read_otfile, ASOC_aux.py:1420-1445) of this cloud -> T[CELLS].  A file that lacks the deepest
+    level is refused (the reference copies parent values down, ASOC.py:721-731)."""
+    with open(filename, 'rb') as fp:
+        nx, ny, nz, levels, cells = (int(v) for v in np.fromfile(fp, np.int32, 5))
+        if (nx, ny, nz, levels, cells) != (cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, cloud.CELLS):
+            raise FileError("%s: temperatures of a %dx%dx%d cloud with %d levels and %d cells, the model has %dx%dx%d, %d, %d" % (
+                filename, nx, ny, nz, levels, cells, cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, cloud.CELLS))
+        T = np.zeros(cells, np.float32)
+        for level in range(levels):
+            n = int(np.fromfile(fp, np.int32, 1)[0])
+            if n != int(cloud.LCELLS[level]):
+                raise FileError("%s: level %d holds %d cells, the model %d" % (filename, level, n, cloud.LCELLS[level]))
+            a = int(cloud.OFF[level])
+            T[a:a + n] = np.fromfile(fp, np.float32, n)
+    return T
+
+
 # ---------------------------------------------------------------------------------------
 # region-of-interest records (roisave / roiload): int32 (nx, ny, nz, nside, nfreq) + float32 [nfreq, nelem * 12*nside^2]
 # with nelem = nx*ny + ny*nz + nz*nx surface elements (ASOC.py:909-944)
@@ -331,3 +349,38 @@ def create_roi_save(filename, ROI, ROI_STEP, ROI_NSIDE, NFREQ):
     m = np.memmap(filename, dtype=np.float32, mode='r+', offset=20, shape=(NFREQ, npix))
     m[:, :] = 0.0
     return m
+
+
+# ---- intensity file (saveint / dustem keys; ASOC.py:990-1000, :2733-2757) ----------------------------------------
+def create_intensity_file(path, CELLS, NFREQ, vectors):
+    """Memory-mapped float32 body of the intensity file, zeroed: [CELLS, NFREQ] behind an 8-byte header (saveint 1) or
+    [CELLS, NFREQ, 4] = (I, Ix, Iy, Iz) behind a 12-byte header (saveint 2).  The header is written by
+    finish_intensity_file, as in the reference."""
+    shape, off = ((CELLS, NFREQ, 4), 12) if vectors else ((CELLS, NFREQ), 8)
+    m = np.memmap(path, dtype=np.float32, mode="w+", shape=shape, offset=off)
+    m[...] = 0.0
+    return m
+
+
+def finish_intensity_file(path, INTENSITY, CELLS, NFREQ, vectors):
+    """saveint 2: Ix, Iy, Iz become fractions of the total intensity (ASOC.py:2736-2738); then the header"""
+    if vectors:
+        for k in (1, 2, 3):
+            INTENSITY[:, :, k] /= (INTENSITY[:, :, 0] + 1.0e-33)
+    INTENSITY.flush()
+    del INTENSITY
+    with open(path, "r+b") as fp:
+        np.asarray([CELLS, NFREQ, 4] if vectors else [CELLS, NFREQ], np.int32).tofile(fp)
+
+
+def read_intensity(path):
+    """-> [CELLS, NFREQ] or [CELLS, NFREQ, 4] of the file saveint writes"""
+    with open(path, "rb") as fp:
+        cells, nfreq = (int(v) for v in np.fromfile(fp, np.int32, 2))
+        rest = os.path.getsize(path) - 8
+        if rest == 4 * cells * nfreq:
+            return np.fromfile(fp, np.float32).reshape(cells, nfreq)
+        four = int(np.fromfile(fp, np.int32, 1)[0])
+        if four != 4 or rest - 4 != 16 * cells * nfreq:
+            raise FileError("%s: not an intensity file" % path)
+        return np.fromfile(fp, np.float32).reshape(cells, nfreq, 4)

@@ -14,6 +14,7 @@ LIBNAME = os.path.join(HERE, "libsoc_hip.so")
 TALLY_TABS = 0
 TALLY_INT = 1
 TALLY_XAB = 2
+TALLY_INTX, TALLY_INTY, TALLY_INTZ = 3, 4, 5      # with_int == 2 (SAVE_INTENSITY 2)
 
 _F = C.POINTER(C.c_float)
 _I = C.POINTER(C.c_int32)
@@ -35,6 +36,7 @@ API = {
     "soc_set_optical": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
     "soc_set_opt": (C.c_int, [C.c_void_p, _F]),
     "soc_set_scatter_table": (C.c_int, [C.c_void_p, _F, _F, C.c_int]),
+    "soc_set_opt_half": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_scatter_tables": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_int]),
     "soc_set_step_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float]),
     "soc_set_emission": (C.c_int, [C.c_void_p, _F, _F]),
@@ -254,6 +256,10 @@ class Engine:
         a = np.ascontiguousarray(AFABS, np.float32).ravel()
         s = np.ascontiguousarray(AFSCA, np.float32).ravel()
         self._chk(self.lib.soc_set_optical_abu(self.h, _f(a), _f(s), int(a.size)))
+
+    def set_opt_half(self, on=True):
+        """-D OPT_IS_HALF: OPT of later set_opt / set_optical_abu calls is rounded to fp16 as the reference stores it"""
+        self._chk(self.lib.soc_set_opt_half(self.h, int(bool(on))))
 
     def read_opt(self):
         out = np.zeros((self.CELLS, 2), np.float32)

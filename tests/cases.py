@@ -168,6 +168,11 @@ CASES = {
                                                 EMIT=_emit(_oct8()), WITH_ALI=1)),
     "cl_c8": ("c8", 1, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=4, SEED=0.35, GLOBAL=64,
                                      EMIT=_emit(_c8()))),
+    # -D SAVE_INTENSITY=2: INT and the vector sums INTX, INTY, INTZ (kernel_ASOC.c:604-612, :724-732)
+    "bg_c8_int2": ("c8int2", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=20, SEED=0.123, WITH_INT=2, TW=2.5)),
+    "cl_oct8_int2": ("oct8int2", 1, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=2, BATCH=3, SEED=0.9, GLOBAL=128,
+                                                 EMIT=_emit(_oct8()), WITH_INT=2)),
+    "hp_oct8_int2": ("oct8int2", 2, lambda: _hpjob(_oct8(), False, BATCH=4, SEED=0.11, GLOBAL=3072, WITH_INT=2)),
     # weighted free paths (-D STEP_WEIGHT=1|2 with SW_A, SW_B: kernel_ASOC.c:516-535) and per-dust scattering functions
     "bg_c8_sw1": ("c8sw1", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=30, SEED=0.44, STEP_WEIGHT=(1, 0.5, 0.0))),
     "bg_oct8_sw2": ("oct8sw2", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=1, BATCH=20, SEED=0.45,

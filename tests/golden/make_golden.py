@@ -85,6 +85,8 @@ def main():
         out[name + "_TABS"] = T
         if job.WITH_INT:
             out[name + "_INT"] = I
+        if job.INTV is not None:
+            out[name + "_INTV"] = job.INTV.copy()
         if job.WITH_ALI:
             out[name + "_XAB"] = job.XAB.copy()
         if job.ROI is not None:

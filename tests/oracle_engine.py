@@ -27,6 +27,7 @@ class OracleEngine:
 
     def set_features(self, with_int=0, ps_method=0, use_emweight=0):
         self.feat = dict(with_int=with_int, ps_method=ps_method, use_emweight=use_emweight)
+        self.INTV = np.zeros((3, self.cloud.CELLS), np.float32) if with_int == 2 else None
 
     def set_mirror(self, mask=0):
         self.mirror = int(mask)
@@ -51,8 +52,13 @@ class OracleEngine:
             for d in range(ABU.shape[1]):
                 OPT[:, 0] += ABU[:, d] * np.float32(AFABS[d])
                 OPT[:, 1] += ABU[:, d] * np.float32(AFSCA[d])
+        if getattr(self, "opt_half", False):
+            OPT = np.asarray(np.asarray(OPT, np.float16), np.float32)
         self.OPT = OPT
         self.af = (np.asarray(AFABS, np.float32).copy(), np.asarray(AFSCA, np.float32).copy())
+
+    def set_opt_half(self, on=True):
+        self.opt_half = bool(on)
 
     def read_opt(self):
         return self.OPT.copy()
@@ -75,6 +81,8 @@ class OracleEngine:
         self.T[tag][:] = 0
         if tag == 0:
             self.T[2][:] = 0
+        if tag == 1 and getattr(self, "INTV", None) is not None:
+            self.INTV[:] = 0
 
     def set_ali(self, with_ali=1):
         self.ali = int(with_ali)
@@ -143,12 +151,15 @@ class OracleEngine:
         msf = None
         if getattr(self, "msf_csc", None) is not None:
             msf = (self.af[0], self.af[1], self.msf_csc, self.ABU.reshape(self.cloud.CELLS, -1))
-        return Job(self.cloud, self.CSC, ABS=self.ABS, SCA=self.SCA, SOURCE=SOURCE, BATCH=BATCH, SEED=SEED, BG=BG,
+        job = Job(self.cloud, self.CSC, ABS=self.ABS, SCA=self.SCA, SOURCE=SOURCE, BATCH=BATCH, SEED=SEED, BG=BG,
                    TW=TW, GLOBAL=GLOBAL, PACKETS=PACKETS, PSPOS=PSPOS if SOURCE == 0 else None,
                    PS=PS if SOURCE == 0 else None, PS_METHOD=self.feat["ps_method"], XPS=XPS if SOURCE == 0 else None,
                    OPT=self.OPT, EMIT=self.EMIT, EMWEI=self.EMWEI, USE_EMWEIGHT=self.feat["use_emweight"],
                    WITH_INT=self.feat["with_int"], DSC=self.DSC, MIRROR=getattr(self, "mirror", 0),
                    STEP_WEIGHT=getattr(self, "step_weight", None), MSF=msf)
+        if job.INTV is not None:
+            job.INTV = self.INTV
+        return job
 
     def sim_pb(self, SOURCE, PACKETS, BATCH, SEED, BG, TW, PSPOS=None, PS=None, XPS=None, GLOBAL=None,
                gid_first=0, gid_count=None):
@@ -242,6 +253,8 @@ class OracleEngine:
         pass
 
     def read_tally(self, which=0):
+        if which >= 3:
+            return self.INTV[which - 3].copy()
         return self.T[which].copy()
 
     def write_tally(self, which, values):

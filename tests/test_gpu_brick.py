@@ -10,7 +10,7 @@ from util import run_engine, assert_tally_close
 
 pytestmark = pytest.mark.gpu
 
-CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n and "mirror" not in n and "roi" not in n]
+CART = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 0 and "oct" not in n and "mirror" not in n and "roi" not in n and "int2" not in n]
 
 
 @pytest.mark.parametrize("name", CART)
@@ -298,7 +298,7 @@ def test_brick_sweep_on_a_clustered_rectangular_hierarchy(cap, engine, oracle_so
     engine.set_exec(-1, 4)
 
 
-HP = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 2 and "mirror" not in n]
+HP = [n for n, (ref, kind, mk) in sorted(cases.CASES.items()) if kind == 2 and "mirror" not in n and "int2" not in n]
 
 
 @pytest.mark.parametrize("name", HP)
@@ -370,7 +370,7 @@ def test_brick_sweep_octree_weighting_and_species(name, engine, oracle_soc, tune
 
 
 CLB = [n for n, (ref, kind, mk) in sorted(cases.CASES.items())
-       if kind == 1 and not any(t in n for t in ("mirror", "emw2", "ali", "roi"))]
+       if kind == 1 and not any(t in n for t in ("mirror", "emw2", "ali", "roi", "int2"))]
 
 
 @pytest.mark.parametrize("name", CLB)

@@ -109,6 +109,12 @@ def test_simulation_vs_oracle(name, engine, oracle_soc):
         assert_tally_close(Ig, I, rtol=1e-5)
     else:
         assert not Ig.any()
+    if job.WITH_INT == 2:
+        # signed sums: cancellation makes the per-cell relative error meaningless where |sum| << sum of |terms| = INT
+        assert np.abs(job.INTV).sum() > 0
+        for k in range(3):
+            assert np.abs(job.INTV_gpu[k] - job.INTV[k]).max() <= 2e-6 * np.abs(I).max()
+            assert np.all(np.abs(job.INTV_gpu[k] - job.INTV[k]) <= 1e-5 * np.maximum(I, 1e-3 * I.max()))
     if job.WITH_ALI:
         assert_tally_close(job.XAB_gpu, job.XAB, rtol=1e-5)      # job.XAB was filled by the oracle run above
     if job.ROI is not None:
@@ -187,6 +193,45 @@ def test_errors_are_reported_not_fatal(engine):
         engine.set_scatter_table(None, np.linspace(1, -1, 100))
         engine.set_optical(1e-3, 1e-3)
         engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=100, gid_first=90, gid_count=20)
+
+
+def test_opt_is_half(engine, oracle_soc):
+    """-D OPT_IS_HALF: OPT rounded to fp16 exactly as numpy does for the reference's upload (ASOC.py:1158-1159), for the
+    device-built and the uploaded OPT, including values fp16 holds as subnormals, zeros, and overflow to inf"""
+    cl = cases._c8()
+    rr = np.random.default_rng(9)
+    ABU = rr.uniform(0.0, 1.0, (cl.CELLS, 2)).astype(np.float32)
+    AFABS = np.asarray([1e-4, 3e-7], np.float32)
+    AFSCA = np.asarray([3e-4, 2e-8], np.float32)
+    OPT = np.zeros((cl.CELLS, 2), np.float32)
+    for d in range(2):
+        OPT[:, 0] += ABU[:, d] * AFABS[d]
+        OPT[:, 1] += ABU[:, d] * AFSCA[d]
+    H = np.asarray(np.asarray(OPT, np.float16), np.float32)
+    assert not np.array_equal(H, OPT)
+    engine.set_cloud(cl)
+    engine.set_opt_half(True)
+    try:
+        engine.set_abundances(ABU)
+        engine.set_optical_abu(AFABS, AFSCA)
+        assert np.array_equal(engine.read_opt().view(np.uint32), H.view(np.uint32))
+        X = OPT.copy()
+        X.ravel()[:8] = [0.0, 1e-9, 6e-8, 5.96e-8, 65504.0, 65519.9, 65520.0, 1e6]     # -> 0, 0, subnormals, max, max, inf, inf
+        with np.errstate(over="ignore"):
+            XH = np.asarray(np.asarray(X, np.float16), np.float32)
+        engine.set_opt(X)
+        assert np.array_equal(engine.read_opt().view(np.uint32), XH.view(np.uint32))
+        # a launch with the rounded opacities is the oracle's launch with them
+        job = Job(cl, cases._CSC, SOURCE=1, BATCH=6, SEED=0.3, OPT=H)
+        T, _, n = oracle_soc.sim(job, 0)
+        engine.set_opt(OPT)
+        Tg, _, st = run_engine(engine, job, 0)       # uploads job.OPT = H (already fp16 values: rounding is idempotent)
+        assert st["tally_events"] == n
+        assert_tally_close(Tg, T, rtol=1e-5)
+    finally:
+        engine.set_opt_half(False)
+        engine.set_abundances(None)
+        engine.set_opt(None)
 
 
 @pytest.mark.parametrize("single", [False, True])

@@ -187,7 +187,10 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n"):
+    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\n", "polmap bx by bz\n",
+                  "mapping 12 10 0.8 2\n", "mapint 1\n", "interpolate 1\n", "threshold 1\n", "CR_HEATING 1e-17\n", "pssavetau ps 0.55\n",
+                  "externalmask m.bin\n", "sourcemap s.bin\n", "bgmethod 1\n", "yshear 0.1\n", "DEFS -D X=1\n",
+                  "reference 1\nsaveint 1\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
 
@@ -333,6 +336,15 @@ def test_abundance_run(single, tmp_path):
                   GLOBAL=L["GLOBAL"], WITH_INT=1, OPT=OPT)
         Oracle("soc").sim(job, 0, TABS=T)
     assert T.sum() > 0 and np.allclose(CT, T, rtol=2e-6)
+    if not single:
+        # `optishalf`: the same run with OPT rounded to fp16 (-D OPT_IS_HALF, ASOC.py:1158-1159)
+        open(ini, "a").write("optishalf\n")
+        U = User(ini)
+        assert U.OPT_IS_HALF == 1
+        eng = OracleEngine("soc")
+        CH, _ = AbsorptionRun(U, eng).run()
+        assert np.array_equal(eng.OPT, np.asarray(np.asarray(OPT, np.float16), np.float32))
+        assert not np.array_equal(CH, CT) and abs(CH.sum(dtype=np.float64) / CT.sum(dtype=np.float64) - 1) < 1e-2
 
 
 def test_stepweight_key(tmp_path):
@@ -409,6 +421,56 @@ def test_several_scattering_functions(tmp_path):
         Oracle("soc").sim(job, 0, TABS=T)
     assert T.sum() > 0 and np.array_equal(CT, T)
     # without abundances the reference stops (ASOC.py:168-170)
-    open(ini, "w").write(open(ini).read().replace(" %s/a.abu" % d, ""))
-    with pytest.raises(ValueError):
+    txt = open(ini).read().replace(" %s/a.abu" % d, "")
+    open(ini, "w").write(txt)
+    with pytest.raises(ValueError, match="variable abundances"):
         AbsorptionRun(User(ini), OracleEngine("soc"))
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_saveint_writes_the_intensity_file(mode, tmp_path):
+    """`saveint 1|2 file`: mean intensity per cell and frequency from the INT tally, with saveint 2 also the net flux
+    direction (INTX, INTY, INTZ over INT) -- ASOC.py:990-1000, :1499-1515, :2733-2757"""
+    from oracle_engine import OracleEngine
+    from oracle.pyoracle import Job, Oracle
+    d = str(tmp_path)
+    os.chdir(d)
+    cloud = synth.octree_cloud(5, levels=2, frac=0.1, seed=4)
+    U = User(_write_model(d, cloud, nfreq=2, with_ps=True, extra="saveint %d %s/isrf.dat\n" % (mode, d)))
+    assert U.SAVE_INTENSITY == mode
+    run = AbsorptionRun(U, OracleEngine("soc"))
+    run.run()
+    got = files.read_intensity(os.path.join(d, "isrf.dat"))
+    assert got.shape == ((cloud.CELLS, 2) if mode == 1 else (cloud.CELLS, 2, 4))
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    FDSC, FCSC = files.read_scattering_functions([os.path.join(d, "m.dsc")], 2, 500)
+    IBG = np.fromfile(os.path.join(d, "bg.bin"), np.float32)
+    LPS = np.fromfile(os.path.join(d, "ps.bin"), np.float32)
+    Lb = launch.bg_launch(run.BGPAC, cloud.AREA)
+    Lp = launch.ps_launch(run.PSPAC, 1, 0.5, run.GLOBAL_0)
+    want = np.zeros((cloud.CELLS, 2, 4), np.float32)
+    orc = Oracle("soc")
+    for i in range(2):
+        FREQ = float(FFREQ[i])
+        kw = dict(ABS=AFABS[0][i], SCA=AFSCA[0][i], SEED=launch.launch_seed(math.pi / 4, i), TW=launch.trapezoid_weight(FFREQ, i),
+                  WITH_INT=2)
+        jobs = [Job(cloud, FCSC[0, i], SOURCE=0, BATCH=Lp["BATCH"], GLOBAL=Lp["GLOBAL"], PSPOS=np.array([[3.3, 3.2, 3.1]], np.float32),
+                    PS=np.asarray([LPS[i]], np.float32) * np.float32(Lp["WPS"]) / np.float32(FREQ), **kw),
+                Job(cloud, FCSC[0, i], SOURCE=1, BATCH=Lb["BATCH"], GLOBAL=Lb["GLOBAL"],
+                    BG=np.float32(float(IBG[i]) * Lb["WBG"] / FREQ), **kw)]
+        for job in jobs:
+            _, I, _ = orc.sim(job, 0)
+            for k, v in enumerate([I, job.INTV[0], job.INTV[1], job.INTV[2]]):
+                for level in range(cloud.LEVELS):
+                    a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+                    coeff = np.float32(launch.PLANCK * FREQ) / np.float32(AFABS[0][i]) * np.float32(8.0 ** level)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        want[a:b, i, k] += coeff * v[a:b] / cloud.DENS[a:b]
+    leaf = cloud.DENS > 0
+    if mode == 1:
+        assert np.array_equal(got[leaf], want[leaf][:, :, 0]) and (got[leaf] > 0).mean() > 0.5
+    else:
+        for k in (1, 2, 3):
+            want[:, :, k] /= (want[:, :, 0] + 1.0e-33)
+        assert np.array_equal(got[leaf], want[leaf])
+        assert np.abs(got[leaf][:, :, 1:]).max() <= 1.0 + 1e-5 and np.abs(got[leaf][:, :, 1:]).mean() > 0.01

@@ -100,6 +100,42 @@ def test_map_files_of_the_driver(tmp_path):
     assert np.array_equal(maps[i].ravel(), want)
 
 
+def test_healpix_map_file_of_the_driver(tmp_path):
+    """`mapping 4 -1 1.0` + `perspective x y z`: map_dir_00_H.bin = int32 [NSIDE, -1], int32 [frequencies, LEVELS], one
+    float32 [12*NSIDE^2] all-sky map per emitted frequency inside `wavelength` (the loop of ASOC.py:3240-3309)"""
+    from oracle_engine import OracleEngine
+    from soc_amd import files
+    from soc_amd.asoc import AbsorptionRun
+    from soc_amd.ini import User
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    extra = ("noabsorbed\niterations 1\ntemperature %s/T.bin\nemitted %s/em.bin\nmapping 4 -1 1.0\nperspective 0.5 3.1 2.9\n"
+             "wavelength 0.6 0.8\n" % (d, d))
+    ini = _write_model(d, cloud, extra=extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("nomap\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+    U = User(ini)
+    assert U.NPIX[1] < 0
+    run = AbsorptionRun(U, OracleEngine("soc"), verbose=0)
+    run.run()
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    sel = [i for i in range(3) if U.MAP_FREQ[0] <= FFREQ[i] <= U.MAP_FREQ[1]]
+    assert 0 < len(sel) < 3                                   # `wavelength` restricts the frequencies in the file
+    head = np.fromfile("map_dir_00_H.bin", np.int32, 4)
+    assert list(head) == [4, -1, len(sel), cloud.LEVELS]
+    maps = np.fromfile("map_dir_00_H.bin", np.float32, offset=16).reshape(len(sel), 12 * 16)
+    assert (maps >= 0).all() and (maps[0] > 0).mean() > 0.5   # the observer sits in a heated surface cell of this opaque toy cloud
+    KK = (1.0e23 / launch.FACTOR) * launch.PLANCK / (4.0 * np.pi) * 0.5 * launch.PARSEC
+    i = sel[0]
+    emit = np.asarray(run.EMITTED[:, i] * np.float32(KK) * np.float32(FFREQ[i]), np.float32)
+    _, OD, RA, DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+    job = Job(cloud, CSC, ABS=AFABS[0][i], SCA=AFSCA[0][i])
+    want, _ = oracle_mapping(Oracle("soc"), job, emit, OD[0], RA[0], DE[0], (4, -1), 1.0, (3.0, 3.0, 3.0), U.INTOBS, 0, 1.0, 4)
+    assert np.array_equal(maps[0], want.ravel())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(MAP_CASES))
 def test_map_hip_bit_identical_to_oracle(name, engine, oracle_soc):

@@ -80,6 +80,8 @@ def test_simulation_libm_bit_exact(name, oracle_libm):
     assert np.array_equal(T.view(np.uint32), SIMS[name + "_TABS"].view(np.uint32))
     if job.WITH_INT:
         assert np.array_equal(I.view(np.uint32), SIMS[name + "_INT"].view(np.uint32))
+    if job.INTV is not None:                                  # SAVE_INTENSITY == 2: INTX, INTY, INTZ
+        assert np.abs(job.INTV).sum() > 0 and np.array_equal(job.INTV.view(np.uint32), SIMS[name + "_INTV"].view(np.uint32))
     if job.WITH_ALI:
         assert job.XAB.sum() > 0 and np.array_equal(job.XAB.view(np.uint32), SIMS[name + "_XAB"].view(np.uint32))
     if job.ROI is not None:

@@ -12,13 +12,18 @@ pytestmark = pytest.mark.skipif(not Ref.available("c8"), reason="reference build
 
 
 @pytest.mark.parametrize("name", ["bg_c8", "bg_oct8", "ps_ext2_c8", "cl_oct8_emw", "bg_c8_sw1", "bg_oct8_sw2", "cl_oct8_sw2", "bg_oct8_msf",
-                                  "cl_oct8_msf", "hp_oct8_msf"])
+                                  "cl_oct8_msf", "hp_oct8_msf", "bg_c8_int2", "cl_oct8_int2"])
 def test_live_bit_exact(name, oracle_libm):
     ref, kind, mk = cases.CASES[name]
     job = mk()
     T, I, _ = oracle_libm.sim(job, kind)
+    V = None if job.INTV is None else job.INTV.copy()
+    if V is not None:
+        job.INTV[:] = 0
     T2, I2 = Ref(ref).sim(job, kind)
     assert np.array_equal(T.view(np.uint32), T2.view(np.uint32))
+    if V is not None:
+        assert np.abs(V).sum() > 0 and np.array_equal(V.view(np.uint32), job.INTV.view(np.uint32))
 
 
 def test_double_index_path_bit_exact(oracle_libm):

@@ -171,6 +171,45 @@ def test_emweight2_and_ali_iterations_on_oracle_engine(tmp_path):
     assert (run.TNEW > a).all() and np.abs(run.TNEW / a - 1).max() < 0.4
 
 
+def test_reference_field_iterations_on_oracle_engine(tmp_path):
+    """`reference 1` (ASOC.py:796-812, :1607-1632, :1728-1735, :1965-1975): the packets carry EMITTED - k*previous, the
+    host adds k*(absorptions of the previous emission) back.  One iteration: k = 0, the plain run bit for bit; three
+    iterations: the same temperatures to Monte Carlo accuracy; `reference 300` writes the state a run with
+    `reference 302` continues from."""
+    from oracle_engine import OracleEngine
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(5, seed=2)
+    os.chdir(d)
+
+    def go(extra, iterations):
+        if os.path.exists(os.path.join(d, "em.bin")):
+            os.remove(os.path.join(d, "em.bin"))
+        ini = _iter_ini(d, cloud, "cellpackets %d\n" % (40 * cloud.CELLS) + extra)
+        txt = open(ini).read().replace("iterations 2\n", "iterations %d\n" % iterations)
+        open(ini, "w").write(txt)
+        run = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+        run.run()
+        return run
+    plain1, ref1 = go("", 1), go("reference 1\n", 1)
+    assert np.array_equal(plain1.TNEW, ref1.TNEW)
+    plain3, ref3 = go("", 3), go("reference 1\n", 3)
+    assert not np.array_equal(plain3.TNEW, ref3.TNEW)
+    assert np.abs(ref3.TNEW / plain3.TNEW - 1).max() < 0.03
+    # AABB form: 3 iterations in total, this run starts at iteration 0 -> same damping as `reference 1`, state saved
+    cont = go("reference 300\n", 2)
+    assert os.path.getsize(os.path.join(d, "OEMITTED.save")) == 4 * cloud.CELLS * 3
+    OT = np.fromfile(os.path.join(d, "OTABS.save"), np.float32)
+    assert OT.shape == (cloud.CELLS,) and (OT >= 0).all() and (OT > 0).mean() > 0.5
+    em = np.array(cont.EMITTED)
+    ini = _iter_ini(d, cloud, "cellpackets %d\nreference 302\n" % (40 * cloud.CELLS))      # keeps em.bin of the first part
+    txt = open(ini).read().replace("iterations 2\n", "iterations 1\n")
+    open(ini, "w").write(txt)
+    last = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+    last.run()
+    assert np.abs(last.TNEW / plain3.TNEW - 1).max() < 0.03
+    assert not np.array_equal(np.fromfile(os.path.join(d, "OTABS.save"), np.float32), OT) and em.shape == last.EMITTED.shape
+
+
 def test_host_temperature_solve_matches_device_formula_away_from_its_quirk():
     """launch.solve_temperature_host (the reference's host loop) lands within one table step of the device kernel"""
     o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)

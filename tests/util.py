@@ -61,6 +61,8 @@ def run_engine(eng, job, kind=0, gid_first=0, gid_count=None, zero=True, exec_mo
         eng.set_scatter_table(None, job.MSF[2][0])
         eng.set_opt(None)
         eng.set_abundances(None)
+    if job.WITH_INT == 2:
+        job.INTV_gpu = np.stack([eng.read_tally(3 + k) for k in range(3)])
     return eng.read_tally(0), eng.read_tally(1), eng.stats()
 
 
