@@ -236,3 +236,109 @@ def test_c1_known_answer(engine):
         assert abs(T.sum(dtype=np.float64) / 1.844163e4 - 1.0) < 5e-3
         assert 0.44 < T.min() and T.max() < 0.70                   # reference: min 0.4785, max 0.6499
     engine.set_exec(-1, 4)
+
+
+def test_c4_scattered_light_on_the_c3_geometry(engine, c3):
+    """BASELINE configs[3] at its stated size: the scattered-light kernels (forced first scattering, peel-off towards three
+    observers, 256^2 pixels) on the 256^3-root octree -- background, point-source and cell-emission launches.  No oracle at
+    this size; the properties that hold for any size: work-item ranges add up to the whole launch (same streams, integer
+    counts equal), images are linear in the source strength (a factor two is exact in fp32), nothing but finite,
+    non-negative pixels."""
+    import math
+    from soc_amd import launch
+    cloud = c3["cloud"]
+    N = cloud.NX
+    s = c3["step"](60)
+    engine.set_cloud(cloud)
+    engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_opt(None)
+    engine.set_optical(s["ABS"], s["SCA"])
+    engine.set_scatter_table(s["DSC"], s["CSC"])
+    th = [math.radians(30 + 25 * i) for i in range(3)]
+    ph = [math.radians(40 * i) for i in range(3)]
+    _, OD, RA, DE = launch.set_observer_directions(th, ph)
+    engine.sca_set_view(OD, RA, DE, (256, 256), 1.5, (N / 2, N / 2, N / 2), 1)
+    AREA = 6 * N * N
+    GLOBAL = launch.Fix(8 * AREA, 64)
+    emit = np.where(cloud.DENS > 0, 1.0e-3 * cloud.DENS, 0).astype(np.float32)
+
+    def shoot(kind, scale, first, count):
+        engine.stats(reset=True)
+        if kind == "bg":
+            engine.sca_sim_pb(1, 8 * AREA, 1, 0.31, scale, GLOBAL=GLOBAL, gid_first=first, gid_count=count)
+        elif kind == "ps":
+            engine.sca_sim_ps(1048576 * 2, 2, 0.32, 0.0, s["PSPOS"], [scale * float(s["PS"][0])], GLOBAL=1048576, gid_first=first, gid_count=count)
+        else:
+            engine.set_emission(emit * np.float32(scale))
+            engine.sca_sim_cl(2, cloud.CELLS, 1, 0.33, 1048576, gid_first=first, gid_count=count)
+        engine.sync()
+        return engine.stats()
+    for kind, G in (("bg", GLOBAL), ("ps", 1048576), ("cl", 1048576)):
+        engine.sca_zero()
+        st = shoot(kind, 1.0, 0, G)
+        whole = engine.sca_read_out()
+        assert np.isfinite(whole).all() and (whole >= 0).all() and whole.sum() > 0 and st["tally_events"] > 1e5, kind
+        if kind == "bg":
+            assert st["packets"] == 8 * AREA
+        elif kind == "cl":
+            assert st["packets"] == cloud.CELLS
+        # two work-item ranges into one image
+        engine.sca_zero()
+        cut = G // 3 + 11
+        sa = shoot(kind, 1.0, 0, cut)
+        sb = shoot(kind, 1.0, cut, G - cut)
+        both = engine.sca_read_out()
+        assert all(sa[k] + sb[k] == st[k] for k in ("packets", "tally_events", "scatterings")), kind
+        tol = 2e-5 * np.abs(whole) + 1e-9 * whole.max()
+        assert (np.abs(both - whole) <= tol).mean() > 0.9999 and abs(both.sum(dtype=np.float64) / whole.sum(dtype=np.float64) - 1) < 1e-6, kind
+        # linearity
+        engine.sca_zero()
+        st2 = shoot(kind, 2.0, 0, G)
+        twice = engine.sca_read_out()
+        assert st2 == st, kind
+        assert (np.abs(twice - 2.0 * whole) <= 2.0 * tol).mean() > 0.9999, kind
+    engine.set_emission(emit)
+
+
+def test_c5_stochastic_heating_at_its_stated_size(engine, c3, oracle_soc):
+    """BASELINE configs[4] at its stated size: 128 enthalpy bins x 50 frequencies, absorptions of 65536 cells taken from a
+    point-source launch on the config-3 geometry (so that the dynamic range is the real one: cells next to the source
+    down to cells that saw a few packets).  Cells are independent; a sample of them -- spread over the range, including
+    the brightest and the faintest -- must equal the CPU oracle bit for bit, and the cell batch must not matter."""
+    from oracle.pyoracle import a2e_oracle_dosolve
+    from soc_amd import synth
+    cloud = c3["cloud"]
+    engine.set_cloud(cloud)
+    engine.set_features(1, 0, 0)
+    engine.set_opt(None)
+    engine.set_exec(-1, 4)
+    engine.zero(0)
+    engine.zero(1)
+    _c3_launch(engine, c3, 60, 0, 4194304, 2)
+    INT = engine.read_tally(1)
+    engine.set_features(0, 0, 0)
+    NE, NFREQ, NCELL = 128, 50, 65536
+    sol = synth.synth_solver(NFREQ=NFREQ, NE=NE, NSIZE=2, seed=5)
+    # the 65536 cells around the source cell along the storage order of the root grid, refined cells left out
+    src = (128 * 256 + 128) * 256 + 128
+    pick = np.arange(src - NCELL, src + NCELL)
+    pick = pick[cloud.DENS[pick] > 0][:NCELL]
+    a = INT[pick].astype(np.float64)
+    assert (a > 0).mean() > 0.5 and a.max() / a[a > 0].min() > 1e4
+    shape = (sol["FREQ"] / 1e13) ** -1.0 * np.random.default_rng(1).lognormal(0, 0.3, NFREQ)
+    ABS = np.asarray(1e-3 * (a / a[a > 0].mean())[:, None] * shape[None, :], np.float32)
+    AF = synth.a2e_absorption_fraction(sol, 1)
+    engine.a2e_set_size(NE, NFREQ, sol["sizes"][1], AF)
+    got = engine.a2e_solve(ABS)
+    assert got.shape == (NCELL, NFREQ)
+    order = np.argsort(a)
+    sample = np.unique(np.concatenate([order[:8], order[-8:], order[np.linspace(0, NCELL - 1, 48).astype(int)]]))
+    want = a2e_oracle_dosolve(oracle_soc, NE, NFREQ, sol["sizes"][1], AF, ABS[sample])
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got[sample]), ok)
+    assert np.array_equal(got[sample][ok].view(np.uint32), want[ok].view(np.uint32))
+    lit = a > 0
+    assert np.isfinite(got[lit]).all() and (got[lit] >= 0).all() and got[lit].sum() > 0
+    again = engine.a2e_solve(ABS[1000:1777])                 # another batch size and offset: same cells, same bits
+    assert np.array_equal(again.view(np.uint32), got[1000:1777].view(np.uint32))

@@ -89,9 +89,9 @@ def test_sca_split_launch_adds_up(engine, oracle_soc):
 
 
 def test_sca_full_size_properties(engine):
-    """C2-like size (128^3, 8 work items per surface element): flux is conserved -- the
-    image of an optically thin uniform cloud seen from the six axis directions has equal totals
-    by symmetry, and doubling BG doubles every pixel bit for bit (power of two)."""
+    """A uniform 64^3 Cartesian cloud, 8 work items per surface element: the image of an optically thin uniform cloud
+    seen along the three axes has equal totals by symmetry, and doubling BG doubles every pixel (power of two).
+    (Config 4 at its stated size -- 256^3-root octree, three launch kinds -- is tests/test_gpu_fullsize.py.)"""
     from oracle.pyoracle import Job
     from soc_amd import synth
     cloud = synth.cartesian_cloud(64, uniform=1.0)
