@@ -133,8 +133,7 @@ struct SocBrickArgs {
     float lt_thr[SOC_MAXL];      // 2^(k + level - 30), see soc_lt_degenerate
 };
 
-#define SOC_SLOT_BITS 14
-#define SOC_SLOT_MASK ((1u << SOC_SLOT_BITS) - 1u)
+#include "soc_octbricks.h"     // SOC_SLOT_BITS, SocOctBuilder
 #define SOC_LVL_SHIFT 16         // packet word C.z: tally slot | level << 16 | launch << 20
 #define SOC_LCH_SHIFT 20
 
@@ -1399,111 +1398,6 @@ static void soc_oct_release(int device)
     o = SocOctBricks();
 }
 
-namespace {
-struct OctBuilder {
-    const SocGrid &G;
-    const std::vector<float> &D;
-    std::vector<uint32_t> sub;                 // leaves in the subtree of every cell
-    std::vector<uint32_t> slotmap;
-    std::vector<int> bcell, bbase;
-    int CAP, fill = 0;
-
-    OctBuilder(const SocGrid &g, const std::vector<float> &d, int cap) : G(g), D(d), CAP(cap) {}
-
-    static int link(float d) { float m = -d;  int i;  memcpy(&i, &m, 4);  return i; }
-
-    void count()
-    {
-        sub.assign((size_t)G.CELLS, 0u);
-        for (int l = G.LEVELS - 1; l >= 0; l--) {
-            const size_t o = (size_t)G.OFF[l];
-            for (int i = 0; i < G.LCELLS[l]; i++) {
-                const float d = D[o + i];
-                if (d > 0.0f) { sub[o + i] = 1;  continue; }
-                uint32_t n = 1;                              // the refined cell itself holds a slot too (see place_subtree)
-                if (l + 1 < G.LEVELS) {
-                    const size_t c = (size_t)G.OFF[l + 1] + link(d);
-                    for (int k = 0; k < 8; k++) n += sub[c + k];
-                }
-                sub[o + i] = n;
-            }
-        }
-    }
-    void open(uint32_t need)
-    {
-        if (fill > 0 && fill + (long long)need > CAP) { bbase.push_back((int)bcell.size());  fill = 0; }
-    }
-    void place_subtree(int l, int i)            // all leaves below (l, i) into the open brick
-    {
-        const size_t a = (size_t)G.OFF[l] + i;
-        if (D[a] > 0.0f) {
-            slotmap[a] = ((uint32_t)(bbase.size() - 1) << SOC_SLOT_BITS) | (uint32_t)fill;
-            bcell.push_back((int)a);
-            fill++;
-            return;
-        }
-        // A refined cell takes no part in the transfer -- except that SimRAM_CL without emission weights sends
-        // packets from EVERY cell index (kernel_ASOC.c:1318-1355 has no leaf test there): such a packet starts "in"
-        // the refined cell, with the link as its density, and its first step is tallied there.  So it has a slot.
-        place_cell(a);
-        if (l + 1 >= G.LEVELS) return;
-        const int c = link(D[a]);
-        for (int k = 0; k < 8; k++) place_subtree(l + 1, c + k);
-    }
-    void place_cell(size_t a)
-    {
-        slotmap[a] = ((uint32_t)(bbase.size() - 1) << SOC_SLOT_BITS) | (uint32_t)fill;
-        bcell.push_back((int)a);
-        fill++;
-    }
-    void assign_subtree(int l, int i)
-    {
-        const uint32_t n = sub[(size_t)G.OFF[l] + i];
-        if (n == 0) return;
-        if (n <= (uint32_t)CAP) { open(n);  place_subtree(l, i);  return; }
-        open(1);
-        place_cell((size_t)G.OFF[l] + i);                    // the refined cell itself, then its children one by one
-        const int c = link(D[(size_t)G.OFF[l] + i]);
-        for (int k = 0; k < 8; k++) assign_subtree(l + 1, c + k);
-    }
-    unsigned long long count_cube(int x0, int y0, int z0, int s) const
-    {
-        unsigned long long n = 0;
-        for (int z = z0; z < std::min(z0 + s, G.NZ); z++)
-            for (int y = y0; y < std::min(y0 + s, G.NY); y++)
-                for (int x = x0; x < std::min(x0 + s, G.NX); x++) n += sub[((size_t)z * G.NY + y) * G.NX + x];
-        return n;
-    }
-    void assign_cube(int x0, int y0, int z0, int s)
-    {
-        if (x0 >= G.NX || y0 >= G.NY || z0 >= G.NZ) return;
-        const unsigned long long n = count_cube(x0, y0, z0, s);
-        if (n == 0) return;
-        if (n <= (unsigned long long)CAP) {
-            open((uint32_t)n);
-            for (int z = z0; z < std::min(z0 + s, G.NZ); z++)
-                for (int y = y0; y < std::min(y0 + s, G.NY); y++)
-                    for (int x = x0; x < std::min(x0 + s, G.NX); x++) place_subtree(0, (z * G.NY + y) * G.NX + x);
-            return;
-        }
-        if (s == 1) { assign_subtree(0, (z0 * G.NY + y0) * G.NX + x0);  return; }
-        const int h = s / 2;
-        for (int k = 0; k < 8; k++) assign_cube(x0 + (k & 1) * h, y0 + ((k >> 1) & 1) * h, z0 + (k >> 2) * h, h);
-    }
-    void build()
-    {
-        count();
-        slotmap.assign((size_t)G.CELLS, 0xffffffffu);
-        bcell.clear();
-        bbase.assign(1, 0);
-        fill = 0;
-        for (int z = 0; z < G.NZ; z += 16)
-            for (int y = 0; y < G.NY; y += 16)
-                for (int x = 0; x < G.NX; x += 16) assign_cube(x, y, z, 16);
-        if (fill > 0) bbase.push_back((int)bcell.size());
-    }
-};
-}  // namespace
 
 static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream_t st, bool verbose)
 {
@@ -1512,7 +1406,7 @@ static hipError_t soc_oct_build(int device, const SocGrid &G, int CAP, hipStream
     std::vector<float> D((size_t)G.CELLS);
     BCHK(hipStreamSynchronize(st));
     BCHK(hipMemcpy(D.data(), G.DENS, (size_t)G.CELLS * 4, hipMemcpyDeviceToHost));
-    OctBuilder B(G, D, CAP);
+    SocOctBuilder B(G.NX, G.NY, G.NZ, G.LEVELS, G.CELLS, G.LCELLS, G.OFF, D.data(), CAP);
     B.build();
     const int NB = (int)B.bbase.size() - 1;
     if (NB < 1 || NB >= (1 << (32 - SOC_SLOT_BITS))) return hipErrorNotSupported;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../soc_amd/csrc/soc_lbricks.h"
+#include "../soc_amd/csrc/soc_octbricks.h"
 
 #define PEPS 1.0e-4f
 
@@ -120,6 +121,36 @@ int lt_trace(void *h, const float *pos, const float *dir, int maxsteps, int *lev
     if (n >= maxsteps && *status == 0) *status = 1;
     endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
     return n;
+}
+
+// soc_octbricks.h (bricks of the sweep that reads the hierarchy from global memory): build, then check what the device
+// relies on -- every cell owns exactly one (brick, slot) word, slots of a brick are dense and below 2^SOC_SLOT_BITS,
+// a brick exceeds `cap` cells only when it is a single refined cell standing for an oversized subtree's head,
+// bcell lists the cells in brick order.  Returns 0 or the number of the violated check; nbricks / largest brick out.
+int ob_check(int NX, int NY, int NZ, int LEVELS, const int *LCELLS, const int *OFF, const float *DENS, int cap, int *nbricks, int *largest)
+{
+    int cells = 0;
+    for (int l = 0; l < LEVELS; l++) cells += LCELLS[l];
+    SocOctBuilder B(NX, NY, NZ, LEVELS, cells, LCELLS, OFF, DENS, cap);
+    B.build();
+    const int NB = (int)B.bbase.size() - 1;
+    *nbricks = NB;
+    *largest = 0;
+    if (NB < 1 || B.bbase[0] != 0 || B.bbase[NB] != (int)B.bcell.size()) return 1;
+    if ((long)B.bcell.size() != (long)cells) return 2;                       // every cell, refined ones included, holds a slot
+    std::vector<char> seen((size_t)cells, 0);
+    for (int b = 0; b < NB; b++) {
+        const int n = B.bbase[b + 1] - B.bbase[b];
+        if (n < 1 || n > cap || n > (int)(SOC_SLOT_MASK + 1u)) return 3;
+        if (n > *largest) *largest = n;
+        for (int k = 0; k < n; k++) {
+            const int a = B.bcell[(size_t)B.bbase[b] + k];
+            if (a < 0 || a >= cells || seen[a]) return 4;
+            seen[a] = 1;
+            if (B.slotmap[a] != (((uint32_t)b << SOC_SLOT_BITS) | (uint32_t)k)) return 5;
+        }
+    }
+    return 0;
 }
 
 }  // extern "C"

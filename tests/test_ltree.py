@@ -19,7 +19,7 @@ _F, _I = C.POINTER(C.c_float), C.POINTER(C.c_int)
 def _harness(sanitize=False):
     out = os.path.join(REPO, "oracle", "_build", "libltree_host%s.so" % ("_san" if sanitize else ""))
     src = os.path.join(HERE, "ltree_host.cpp")
-    deps = [src] + [os.path.join(REPO, "soc_amd", "csrc", f) for f in ("soc_ltree.h", "soc_lbricks.h", "soc_math.h")]
+    deps = [src] + [os.path.join(REPO, "soc_amd", "csrc", f) for f in ("soc_ltree.h", "soc_lbricks.h", "soc_octbricks.h", "soc_math.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         cmd = ["g++", "-O1" if sanitize else "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-Wall",
@@ -157,3 +157,15 @@ def _sanitized_body(lib):
     deep = synth.octree_cloud(4, levels=4, frac=0.5, seed=1)
     lt = LTree(deep, 64, lib=lib)
     assert not lt.h
+    # the older brick builder (hierarchy in global memory: abundance runs, > 8 levels, forced with global_tree): subtrees
+    # larger than the cap are split below their refined head cell
+    L = C.CDLL(lib)
+    L.ob_check.argtypes = [C.c_int] * 4 + [_I, _I, _F, C.c_int, _I, _I]
+    for cloud, cap in ((synth.octree_cloud(19, levels=4, frac=0.2, seed=2), 8), (synth.octree_cloud(19, levels=4, frac=0.2, seed=2), 600),
+                       (synth.octree_cloud(40, levels=3, frac=0.1, seed=4), 5000), (deep, 16), (synth.kat_octree(), 8)):
+        nb, big = C.c_int(0), C.c_int(0)
+        lc, off = np.ascontiguousarray(cloud.LCELLS, np.int32), np.ascontiguousarray(cloud.OFF, np.int32)
+        dens = np.ascontiguousarray(cloud.DENS, np.float32)
+        rc = L.ob_check(cloud.NX, cloud.NY, cloud.NZ, cloud.LEVELS, lc.ctypes.data_as(_I), off.ctypes.data_as(_I), dens.ctypes.data_as(_F), cap,
+                        C.byref(nb), C.byref(big))
+        assert rc == 0 and nb.value >= cloud.CELLS // cap and 0 < big.value <= cap, (rc, nb.value, big.value)
