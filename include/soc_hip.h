@@ -13,6 +13,9 @@
  *     int32 / float32.  SEED, BG, TW are float32 at the boundary.
  *   - a handle is bound to one GPU and is not thread-safe; launches are asynchronous on the
  *     handle's stream; soc_read_tally() and soc_sync() synchronise.
+ *   - the scratch of the brick sweep (packet queues, the brick tables of the current grid) is kept per GPU, shared by
+ *     the handles of that GPU and freed when the last of them is destroyed: calls on DIFFERENT handles of one GPU must
+ *     not overlap in time either (one process drives one GPU from one thread -- the layout of soc_amd/dist.py).
  */
 #ifndef SOC_HIP_H
 #define SOC_HIP_H

@@ -1493,13 +1493,9 @@ template <bool OCT, bool DBL, bool ABU, bool WINT, int KIND>
 static void soc_brick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                  const SocBrickArgs &A, int nwalk, int slices)
 {
-    if (lds > 64 * 1024) {                         // more dynamic LDS than the default limit: once per kernel
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void *)soc_brick_pass<OCT, DBL, ABU, WINT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = true;
-        }
-    }
+    if (lds > 64 * 1024)                           // more dynamic LDS than the default limit; the attribute is per device, so it is set
+        (void)hipFuncSetAttribute((const void *)soc_brick_pass<OCT, DBL, ABU, WINT, KIND>,     // on every launch (microseconds)
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     soc_brick_pass<OCT, DBL, ABU, WINT, KIND><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices);
 }
 

@@ -194,6 +194,8 @@ const char *soc_version(void) { return "soc_hip 0.1 (gfx950)"; }
 
 const char *soc_last_error(const soc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+static int g_handles[64];              // live handles per GPU: the brick scratch of a GPU goes with the last one
+
 int soc_create(int device, soc_ctx **out)
 {
     if (!out) return fail(nullptr, SOC_ERR_ARG, "soc_create: out is NULL");
@@ -214,6 +216,7 @@ int soc_create(int device, soc_ctx **out)
         return r;
     }
     c->stream = c->own_stream;
+    if (device < 64) g_handles[device]++;
     // seed tables: T[k][b] = G^(b*256^k) mod M with G = A^(2^38) mod M  (soc_rng.h)
     std::vector<uint64_t> tab(1024);
     soc_build_seed_table(tab.data());
@@ -249,7 +252,7 @@ void soc_destroy(soc_ctx *c)
     if (c->own_OUT && c->dOUT) (void)hipFree(c->dOUT);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    soc_brick_release(c->device);
+    if (c->device >= 64 || --g_handles[c->device] <= 0) soc_brick_release(c->device);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
