@@ -24,10 +24,20 @@ def cloud104():
 kw_form = {}
 
 
+@pytest.fixture(autouse=True, params=[0, 96, 24], ids=["lanes", "pool96", "pool24"])
+def walk_form(request, engine):
+    """every test of this file runs on both forms of the walk: packets bound to lanes, and packet pools per wave"""
+    engine.set_tuning(pool_slots=request.param)
+    kw_form["base"] = 4 if request.param else 3
+    yield
+    engine.set_tuning(pool_slots=0)
+    kw_form.pop("base", None)
+
+
 def _sweep(engine, job, kind, **kw):
     T, I, st = run_engine(engine, job, kind, exec_mode=1, **kw)
     assert engine.last_passes() > 0
-    assert engine.last_form() == kw_form.get("form", 3)
+    assert engine.last_form() == kw_form.get("form", kw_form.get("base", 3))
     return T, I, st
 
 
@@ -69,7 +79,7 @@ def test_older_sweep_is_a_second_witness(engine, tuned):
     try:
         Tb, _, sb = _sweep(engine, job, 0, gid_first=g0, gid_count=g1 - g0)
     finally:
-        kw_form.clear()
+        kw_form.pop("form", None)
     assert sa["tally_events"] == sb["tally_events"] and sa["packets"] == sb["packets"] and sa["scatterings"] == sb["scatterings"]
     assert_tally_close(Ta, Tb, rtol=1e-5)
     engine.set_exec(-1, 4)
@@ -148,7 +158,7 @@ def test_deferred_launches_with_and_without_int(engine, oracle_soc):
             e.sim_pb(1, 0, j.BATCH, j.SEED, j.BG, j.TW, GLOBAL=j.GLOBAL, gid_first=g0, gid_count=g1 - g0)
         e.batch_end()
         st = e.stats()
-        assert e.last_passes() > 0 and e.last_form() == 3 and st["tally_events"] == n
+        assert e.last_passes() > 0 and e.last_form() == kw_form.get("base", 3) and st["tally_events"] == n
         assert_tally_close(e.read_tally(0), want, rtol=1e-5)
         if keep_int:
             for k, I in enumerate(ints):

@@ -93,11 +93,12 @@ def main():
             if prof:
                 prof(buf, 0)
                 p = list(buf)
-                tt = max(sum(p[8:13]), 1)
+                tt = max(sum(p[8:16]), 1)
                 print("   wave-iterations %.3e: stepping lanes %.1f, idle lanes %.1f | swap arm every %.1f iterations with %.1f lanes | "
                       "deferred Index every %.1f with %.1f lanes | wave cycles: swap %.1f %%, step %.1f %%, climb %.1f %%" % (
                           p[0], p[1] / max(p[0], 1), p[7] / max(p[0], 1), p[0] / max(p[4], 1), p[5] / max(p[4], 1),
                           p[0] / max(p[2], 1), p[3] / max(p[2], 1), 100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
+                print("   exchange arm every %.1f iterations; wave cycles: exchange %.1f %%, loop head %.1f %%" % (p[0] / max(p[6], 1), 100 * p[11] / tt, 100 * p[14] / tt), flush=True)
         eng.set_tuning(**reset)
     eng.close()
 
