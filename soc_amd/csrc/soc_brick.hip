@@ -669,7 +669,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     soc_f4v na = { 0.0f, 0.0f, 0.0f, 0.0f }, nb = na, nc = na;
     soc_u2v ndzw = { 0u, 0u };
     uint32_t nwid = 0, nnwid = 0;
-    int   nslot = 0, nnslot = 0, kraw = 0;
+    int   nslot = 0, nnslot = 0;
     bool  nnhave = false;                                                    // the packet after the prefetched one: its id is on the way
     unsigned int n_tally = 0;
     SOC_PROF_DECL;
@@ -691,12 +691,16 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     // A lane holds three packets: the one it walks, the next one, whose record was asked for when the
                     // current one was taken up, and the one after that, of which the id has been asked for -- each a
                     // visit ahead of its use, so nothing in this arm waits for global memory (the brick a leaving packet
-                    // goes to was asked for when it left: kraw).  The chunk itself is never copied: ids, queues and
+                    // goes to is looked up here).  The chunk itself is never copied: ids, queues and
                     // places stay in global memory (idq, keyq, posq), so a chunk may be the whole queue of the brick.
                     asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed: no later use waits behind the stores below
                     if (have) {
                         SocPk2 *q = pk + wid;
-                        if (key < 0) key = qbase + kraw;
+                        // the brick of the root cell a leaving packet goes to: one load + wait per entry of this arm.  (Loaded in
+                        // the block below, when the packet leaves, it made EVERY iteration wait for all loads in flight: the
+                        // branches that do not load must not overwrite a register with a load pending -- 19 % of the wave's
+                        // cycles, rocprof wave counters, profiles/)
+                        if (key < 0) key = qbase + A.rbrick[-1 - key];
                         soc_st4(&q->A, make_float4(px, py, pz, photons));
                         soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
                         q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
@@ -743,6 +747,9 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     // the record of the packet after it (its id has arrived)
                     nhave = nnhave;
                     nwid = nnwid;  nslot = nnslot;
+                    asm volatile("" : "+v"(nwid) :: "memory");                // (the copy is made HERE: nnwid is dead below and the load at the end of the arm lands
+                                                                              //  in its register; left to itself the compiler loads into a fresh register, waits for
+                                                                              //  EVERY load in flight -- the records just asked for -- and copies: 14 % of the cycles)
                     if (nhave) {
                         // (vector-typed loop variables: the loads land in the registers that carry the values around the loop)
                         const SocPk2 *q = pk + nwid;
@@ -874,7 +881,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 nvisit++;
                 if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
             } else if (r == SOC_LT_LEAVE) {
-                mode = SOC_BM_SWAP;  key = -1;  kraw = A.rbrick[(Rz * NY + Ry) * NX + Rx];  dw |= SOC_LT_ARRIVE;      // (the value is used in the swap arm)
+                mode = SOC_BM_SWAP;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;      // (the brick of that root cell: looked up in the swap arm)
             } else if (r == SOC_LT_EXIT) {
                 mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
             } else {

@@ -98,7 +98,7 @@ def main():
                       "deferred Index every %.1f with %.1f lanes | wave cycles: swap %.1f %%, step %.1f %%, climb %.1f %%" % (
                           p[0], p[1] / max(p[0], 1), p[7] / max(p[0], 1), p[0] / max(p[4], 1), p[5] / max(p[4], 1),
                           p[0] / max(p[2], 1), p[3] / max(p[2], 1), 100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
-                print("   exchange arm every %.1f iterations; wave cycles: exchange %.1f %%, loop head %.1f %%" % (p[0] / max(p[6], 1), 100 * p[11] / tt, 100 * p[14] / tt), flush=True)
+                print("   switch / exchange arm every %.1f iterations; wave cycles: switch / exchange %.1f %%, loop head %.1f %%, outcome %.1f %%" % (p[0] / max(p[6], 1), 100 * p[11] / tt, 100 * p[14] / tt, 100 * p[13] / tt), flush=True)
         eng.set_tuning(**reset)
     eng.close()
 
