@@ -285,6 +285,7 @@ def ref_models():
     for k in (1, 2, 4, 5):
         m["c8ps%d" % k] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=k, NO_PS=2)
     m["c8ps0"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, PS_METHOD=0, NO_PS=2)
+    m["oct8ps0"] = dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, PS_METHOD=0, NO_PS=2, NOABSORBED=0)   # point sources inside a hierarchy
     # weighted sampling and per-dust scattering functions (kernel_ASOC.c:516-535,736-799; -D values as ASOC.py:348,357-358 prints them)
     m["c8sw1"] = dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, STEP_WEIGHT=1, SW_A=0.5, SW_B=0.0)
     m["oct8sw2"] = dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, STEP_WEIGHT=2, SW_A=0.7, SW_B=0.4)

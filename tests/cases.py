@@ -37,6 +37,17 @@ _XPS5 = (np.array([1, 0], np.int32), np.array([4, 0, 0, 0, 0, 0], np.int32),
          np.array([0.9, 1, 1, 1, 1, 1], np.float32))
 
 
+def _ps_in_oct8():
+    """one source in an unrefined root cell of the oct8 cloud, one inside a refined one"""
+    c = _oct8()
+    root = np.asarray(c.DENS[:512])
+    leafs, refined = np.flatnonzero(root > 0), np.flatnonzero(root <= 0)
+    out = []
+    for i, frac in ((int(leafs[len(leafs) // 2]), (0.3, 0.2, 0.1)), (int(refined[len(refined) // 2]), (0.31, 0.77, 0.52))):
+        out.append([i % 8 + frac[0], (i // 8) % 8 + frac[1], i // 64 + frac[2]])
+    return np.asarray(out, np.float32)
+
+
 def _emit(cloud):
     return np.where(cloud.DENS > 0, cloud.DENS * 1e-3, 0).astype(np.float32)
 
@@ -136,6 +147,9 @@ CASES = {
     "bg_oct4": ("oct4", 0, lambda: Job(synth.kat_octree(), _CSC, ABS=2e-3, SCA=4e-3, SOURCE=1, BATCH=40, SEED=0.51)),
     "ps_in_c8": ("c8ps0", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
                                            PSPOS=_PS_IN, PS=[1.0, 2.0])),
+    # point sources inside a hierarchy (config 3's source sits in one): the second source lies in a refined root cell
+    "ps_in_oct8": ("oct8ps0", 0, lambda: Job(_oct8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.21, GLOBAL=256,
+                                              PSPOS=_ps_in_oct8(), PS=[1.0, 2.0], WITH_INT=1, TW=1.5)),
     "ps_ext0_c8": ("c8ps0", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,
                                              PSPOS=_PS_EXT, PS=[1.0, 2.0], PS_METHOD=0, XPS=_XPS2)),
     "ps_ext1_c8": ("c8ps1", 0, lambda: Job(_c8(), _CSC, ABS=1e-4, SCA=3e-4, SOURCE=0, BATCH=40, SEED=0.2, GLOBAL=256,

@@ -355,7 +355,7 @@ def test_deferred_healpix_launches(engine, oracle_soc):
     assert_tally_close(engine.read_tally(0), T, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["bg_oct8_sw2", "bg_oct8_msf"])
+@pytest.mark.parametrize("name", ["bg_oct8_sw2", "bg_oct8_msf", "ps_in_oct8"])
 def test_brick_sweep_octree_weighting_and_species(name, engine, oracle_soc, tuned):
     """-D STEP_WEIGHT and -D WITH_MSF in the sweep's event workgroups (hierarchy in global memory; per-cell opacities)"""
     tuned(brick_cells=100)

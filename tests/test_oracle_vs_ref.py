@@ -12,7 +12,7 @@ pytestmark = pytest.mark.skipif(not Ref.available("c8"), reason="reference build
 
 
 @pytest.mark.parametrize("name", ["bg_c8", "bg_oct8", "ps_ext2_c8", "cl_oct8_emw", "bg_c8_sw1", "bg_oct8_sw2", "cl_oct8_sw2", "bg_oct8_msf",
-                                  "cl_oct8_msf", "hp_oct8_msf", "bg_c8_int2", "cl_oct8_int2"])
+                                  "cl_oct8_msf", "hp_oct8_msf", "bg_c8_int2", "cl_oct8_int2", "ps_in_oct8"])
 def test_live_bit_exact(name, oracle_libm):
     ref, kind, mk = cases.CASES[name]
     job = mk()
