@@ -191,7 +191,7 @@ def measured_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong", "auto"], default="auto",
                     help="auto = strong for N > 1 (work-item ranges of every launch), weak = replicas with per-rank seeds")

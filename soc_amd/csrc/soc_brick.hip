@@ -2085,8 +2085,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         // measured: about 5300 packets per brick on Cartesian grids (C2, 512 bricks: 2.7e6 -> 8.5e8 packets/s, 2.1e6 and
         // 3.1e6 -> 8.1e8; 256^3, 4096 bricks: 2.6e7 -> 1.09e11 steps/s, 2.7e6 -> 8.1e10), 2.6e7 on the 256^3-root
         // hierarchy (1.3e7 -> 3.7e10 steps/s, 5.0e7 -> 4.0e10)
-        // brick-local hierarchies: 1e8 (256^3 roots, 4 levels, 11.5e3 bricks: 5.0e7 -> 5.4e10 steps/s, 1.0e8 -> 5.7e10)
-        const long long p = A.LT ? 100000000LL : V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
+        // brick-local hierarchies: 3e8 (256^3 roots, 4 levels, 8194 bricks: 5.0e7 -> 4.6e10 steps/s, 1.0e8 -> 5.0e10, 3.0e8 -> 5.3e10:
+        // the longer a workgroup lives, the less its last iterations -- lanes running dry -- weigh)
+        const long long p = A.LT ? 300000000LL : V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
         population = (int)std::min(p, 2000000000LL);
     }
     if (tune.POP > 0) population = tune.POP;
