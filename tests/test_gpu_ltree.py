@@ -24,13 +24,15 @@ def cloud104():
 kw_form = {}
 
 
-@pytest.fixture(autouse=True, params=[0, 96, 24], ids=["lanes", "pool96", "pool24"])
+@pytest.fixture(autouse=True, params=[(0, 0), (96, 0), (24, 0), (0, 128), (0, 64)], ids=["lanes", "pool96", "pool24", "shared128", "shared64"])
 def walk_form(request, engine):
-    """every test of this file runs on both forms of the walk: packets bound to lanes, and packet pools per wave"""
-    engine.set_tuning(pool_slots=request.param)
-    kw_form["base"] = 4 if request.param else 3
+    """every test of this file runs on all forms of the walk: packets bound to lanes, packet pools per wave, one pool
+    per workgroup"""
+    pool, shared = request.param
+    engine.set_tuning(pool_slots=pool, shared_pool=shared)
+    kw_form["base"] = 5 if shared else (4 if pool else 3)
     yield
-    engine.set_tuning(pool_slots=0)
+    engine.set_tuning(pool_slots=0, shared_pool=0)
     kw_form.pop("base", None)
 
 
