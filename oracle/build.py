@@ -28,6 +28,18 @@ def _newer(target, sources):
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
+def _link_atomically(cmd, so):
+    """run the link with a private output name, then rename: several test processes (pytest -n) may find the same
+    library stale at the same time, and none may ever load a half-written file"""
+    tmp = "%s.%d.tmp" % (so, os.getpid())
+    try:
+        subprocess.check_call(cmd + ["-o", tmp])
+        os.replace(tmp, so)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build_oracle(force=False):
     """Compile both math modes of the CPU restatement.  Returns {mode: path}."""
     if os.environ.get("SOC_ORACLE_LIB_DIR"):
@@ -44,8 +56,8 @@ def build_oracle(force=False):
             continue
         cmd = ["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                "-fno-fast-math", "-mfma", "-msse4.1", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"] \
-            + flag + ["-o", so, srcs[0], srcs[1], "-lm"]
-        subprocess.check_call(cmd)
+            + flag + [srcs[0], srcs[1], "-lm"]
+        _link_atomically(cmd, so)
     return out
 
 
@@ -88,14 +100,14 @@ def build_ref(tag, force=False, **model):
             and os.path.exists(stamp)
             and open(stamp).read() == " ".join(defs)):
         return so
-    kobj = os.path.join(REF_DIR, "k_%s.o" % tag)
-    sobj = os.path.join(REF_DIR, "shim_%s.o" % tag)
+    kobj = os.path.join(REF_DIR, "k_%s.%d.o" % (tag, os.getpid()))
+    sobj = os.path.join(REF_DIR, "shim_%s.%d.o" % (tag, os.getpid()))
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
                            "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
     sdefs = ["-DREF_ROI_LOAD=%d" % int(model.get("WITH_ROI_LOAD", 0)), "-DREF_ROI_SAVE=%d" % int(model.get("WITH_ROI_SAVE", 0))]
     subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + sdefs + ["-c", shim, "-o", sobj])
-    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
     os.remove(kobj)
     os.remove(sobj)
     with open(stamp, "w") as fp:
@@ -118,13 +130,13 @@ def build_ref_a2e(tag, NE, NFREQ, LOCAL, CELLS, NIP=5000, force=False):
     if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
             and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
         return so
-    kobj = os.path.join(REF_DIR, "ka2e_%s.o" % tag)
-    sobj = os.path.join(REF_DIR, "da2e_%s.o" % tag)
+    kobj = os.path.join(REF_DIR, "ka2e_%s.%d.o" % (tag, os.getpid()))
+    sobj = os.path.join(REF_DIR, "da2e_%s.%d.o" % (tag, os.getpid()))
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
                            "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
     subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
-    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
     os.remove(kobj)
     os.remove(sobj)
     with open(stamp, "w") as fp:
@@ -159,8 +171,8 @@ def build_ref_sca(tag, force=False, **model):
     if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
             and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
         return so
-    kobj = os.path.join(REF_DIR, "ksca_%s.o" % tag)
-    sobj = os.path.join(REF_DIR, "dsca_%s.o" % tag)
+    kobj = os.path.join(REF_DIR, "ksca_%s.%d.o" % (tag, os.getpid()))
+    sobj = os.path.join(REF_DIR, "dsca_%s.%d.o" % (tag, os.getpid()))
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     # SimRAM_CL reads the local `idust` without ever setting it when WITH_MSF==0
     # (kernel_ASOC_sca.c:1151, used in DSC[idust*BINS+...] :1385): undefined behaviour that GPU
@@ -168,7 +180,7 @@ def build_ref_sca(tag, force=False, **model):
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
                            "-ftrivial-auto-var-init=zero", "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
     subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
-    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
     os.remove(kobj)
     os.remove(sobj)
     with open(stamp, "w") as fp:
@@ -190,13 +202,13 @@ def build_ref_map(tag, force=False, NSIDE=8, **model):
     if (not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc])
             and os.path.exists(stamp) and open(stamp).read() == " ".join(defs)):
         return so
-    kobj = os.path.join(REF_DIR, "kmap_%s.o" % tag)
-    sobj = os.path.join(REF_DIR, "dmap_%s.o" % tag)
+    kobj = os.path.join(REF_DIR, "kmap_%s.%d.o" % (tag, os.getpid()))
+    sobj = os.path.join(REF_DIR, "dmap_%s.%d.o" % (tag, os.getpid()))
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header", "-ftrivial-auto-var-init=zero",
                            "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
     subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
-    subprocess.check_call([CLANG + "++", "-shared", "-Wl,-z,defs", "-o", so, kobj, sobj, "-lm", "-lpthread"])
+    _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
     os.remove(kobj)
     os.remove(sobj)
     with open(stamp, "w") as fp:
