@@ -193,6 +193,36 @@ def test_errors_are_reported_not_fatal(engine):
         engine.set_scatter_table(None, np.linspace(1, -1, 100))
         engine.set_optical(1e-3, 1e-3)
         engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=100, gid_first=90, gid_count=20)
+    # the switches of round 2: arguments are checked, state that does not fit is reported at the launch
+    with pytest.raises(SocError, match="SW_A"):
+        engine.set_step_weight(1, 0.0, 0.0)            # `stepweight 0.5 ...`: the reference passes -D SW_A=int(0.5)=0 and divides by it
+    with pytest.raises(SocError, match="SW_B"):
+        engine.set_step_weight(2, 0.7, 1.0)
+    with pytest.raises(SocError, match="mode"):
+        engine.set_step_weight(3, 0.7, 0.5)
+    engine.set_step_weight(0)
+    csc2 = np.stack([np.linspace(1, -1, 100), np.linspace(1, -1, 100)]).astype(np.float32)
+    engine.set_scatter_tables(None, csc2)               # two species ...
+    with pytest.raises(SocError, match="WITH_MSF"):
+        engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=96)   # ... but no abundances / per-species cross sections
+    engine.set_abundances(np.ones((c.CELLS, 3), np.float32))
+    engine.set_optical_abu([1e-3] * 3, [1e-3] * 3)
+    with pytest.raises(SocError, match="WITH_MSF"):
+        engine.sim_pb(1, 0, 1, 0.5, 1.0, 1.0, GLOBAL=96)   # three species of abundances, two tables
+    engine.set_abundances(None)
+    engine.set_opt(None)
+    engine.set_scatter_table(None, np.linspace(1, -1, 100))
+    with pytest.raises(SocError, match="soc_set_grid first|with_int 2"):
+        from soc_amd.lib import Engine
+        e2 = Engine(0)
+        try:
+            e2.set_features(2, 0, 0)                    # intensity vectors are sized by the grid
+        finally:
+            e2.close()
+    with pytest.raises(SocError):
+        engine.read_tally(3)                            # INTX without with_int == 2
+    with pytest.raises(SocError, match="tuning|unknown|name"):
+        engine.set_tuning(no_such_knob=1)
 
 
 def test_opt_is_half(engine, oracle_soc):
