@@ -72,8 +72,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("bgmethod")
     if USER.Y_SHEAR != 0.0:
         bad.append("yshear")
-    if getattr(USER, "FITS", 0) > 0 and not USER.NOMAP:
-        bad.append("fits (FITS containers need astropy, which the reference imports for them; drop the key for the .bin files)")
     if USER.LOAD_TEMPERATURE and USER.ITERATIONS > 0 and USER.WITH_ALI:
         bad.append("loadtemp with ALI iterations (the old temperatures enter the escape-probability correction, ASOC.py:2064-2071)")
     if bad:
@@ -613,8 +611,9 @@ class AbsorptionRun:
         """Surface-brightness maps from the emission (ASOC.py:2924-3177, the plain `Mapping` path): for every
         direction map_dir_XX.bin = int32 NPIX.x, NPIX.y + one float32 [NPIX.y, NPIX.x] image [Jy/sr] per selected
         frequency.  `perspective` gives the longitude x latitude image seen from that position.  Optical-depth
-        images for `savetau` frequencies are written as <file>_tau_<um>.bin.  NPIX.y < 0: write_healpix_maps.  FITS
-        containers, map interpolation, ROI maps and polarisation maps are refused (_check_supported)."""
+        images for `savetau` frequencies are written as <file>_tau_<um>.bin, the column density (`savetau file -1`) as
+        <file>_colden.fits; `fits` with `mapum` gives one FITS image per direction and frequency instead.  NPIX.y < 0:
+        write_healpix_maps.  Map interpolation, ROI maps and polarisation maps are refused (_check_supported)."""
         U, e, c = self.U, self.eng, self.cloud
         if U.NPIX[1] == 0:
             self.log("mapping with NPIX.y == 0: neither the flat (NPIX.y > 0, ASOC.py:2924) nor the Healpix branch (NPIX.y < 0, :3185)")
@@ -628,23 +627,34 @@ class AbsorptionRun:
         centre = U.MAPCENTRE if U.MAPCENTRE[0] > -1e7 else (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)   # ASOC_aux.py:791-793
         KK = (1.0e23 / launch.FACTOR) * PLANCK / (4.0 * np.pi) * (U.GL * PARSEC)                 # ASOC.py:2997-2998
         _, LENGTH_f = launch.kernel_literals(U.GL)
+        singles = np.asarray(getattr(U, "SINGLE_MAP_FREQ", []), np.float64)
+        savetau = np.asarray(getattr(U, "savetau_freq", []), np.float64)
+        # `fits` together with `mapum`: one FITS file per direction and selected frequency instead of map_dir_XX.bin
+        # (ASOC.py:2977-2996); the header is MakeFits' (files.write_fits), the pixel GL*MAP_DX over the distance (1 kpc unless given)
+        using_fits = (getattr(U, "FITS", 0) > 0) and (len(singles) > 0)
+        pix = U.GL * U.MAP_DX / (U.DISTANCE if U.DISTANCE > 0.0 else 1000.0)
         fps = []
-        if self.rank == 0:
+        if self.rank == 0 and not using_fits:
             for idir in range(NDIR):
                 fp = open("map_dir_%02d.bin" % idir, "wb")
                 np.asarray([U.NPIX[0], U.NPIX[1]], np.int32).tofile(fp)
                 fps.append(fp)
-        singles = np.asarray(getattr(U, "SINGLE_MAP_FREQ", []), np.float64)
-        savetau = np.asarray(getattr(U, "savetau_freq", []), np.float64)
+        first_freq = True
         for IFREQ in range(NFREQ):
             FREQ = float(FFREQ[IFREQ])
             save_spe = (IFREQ >= I1) and (IFREQ <= I2)
             if (FREQ < U.MAP_FREQ[0]) or (FREQ > U.MAP_FREQ[1]):
                 continue
-            save_tau = int(len(savetau) > 0 and np.min(np.abs((savetau - FREQ) / FREQ)) < 0.001)
+            save_tau, save_colden = 0, 0
+            if len(savetau) > 0:                                   # ASOC.py:3048-3058
+                if np.min(np.abs((savetau - FREQ) / FREQ)) < 0.001:
+                    save_tau = 1
+                if (save_tau == 0) and first_freq and (np.min(savetau) <= 0.0):
+                    save_colden = 1                                # `savetau file -1`: column density, with the first mapped frequency
+            first_freq = False
             if len(singles) > 0 and np.min(np.abs(FREQ - singles)) / FREQ > 0.005:
                 save_spe = False
-            if not save_spe and not save_tau:
+            if not save_spe and not save_tau and not save_colden:
                 continue
             ABS, SCA = self._optical_for(IFREQ)
             EMIT = np.asarray(KK * FREQ * EMITTED[:, IFREQ - I1], np.float32) if save_spe else np.zeros(c.CELLS, np.float32)
@@ -652,14 +662,24 @@ class AbsorptionRun:
             ums = '%.0f' % um if um > 20.0 else ('%.1f' % um if um > 2.0 else '%.2f' % um)
             for idir in range(NDIR):
                 MAP, TAU = e.map(EMIT, ODIR[idir], RA[idir], DE[idir], U.NPIX, U.MAP_DX, centre, ABS, SCA,
-                                 INTOBS=U.INTOBS, save_colden=0, LENGTH=LENGTH_f)
+                                 INTOBS=U.INTOBS, save_colden=save_colden, LENGTH=LENGTH_f)
                 if self.rank != 0:
                     continue
+                suffix = '_dir%d' % idir if NDIR > 1 else ''
+                tail = '' if NDIR == 1 else '_%03d' % idir
                 if save_spe:
-                    np.asarray(MAP, np.float32).tofile(fps[idir])
-                if save_tau:
-                    name = '%s_tau_%s.bin' % (U.file_savetau, ums) if NDIR == 1 else '%s_tau_%s_dir%d_%03d.bin' % (U.file_savetau, ums, idir, idir)
-                    np.asarray(TAU, np.float32).tofile(name)
+                    if using_fits:                                  # :3143-3148
+                        files.write_fits("%s_%s%s.fits" % (U.FITS_PREFIX, ums, tail), MAP, U.FITS_RA, U.FITS_DE, pix)
+                    else:
+                        np.asarray(MAP, np.float32).tofile(fps[idir])
+                if save_colden:                                     # always a FITS image in the reference (:3152-3159)
+                    files.write_fits('%s_colden%s%s.fits' % (U.file_savetau, suffix, tail), TAU, U.FITS_RA, U.FITS_DE, pix)
+                if save_tau:                                        # :3160-3171
+                    name = '%s_tau_%s%s%s' % (U.file_savetau, ums, suffix, tail)
+                    if using_fits:
+                        files.write_fits(name + '.fits', TAU, U.FITS_RA, U.FITS_DE, pix)
+                    else:
+                        np.asarray(TAU, np.float32).tofile(name + '.bin')
         for fp in fps:
             fp.close()
 

@@ -40,8 +40,6 @@ class ScatteringRun(AbsorptionRun):
             self.NDIR = -int(U.OUT_NSIDE)
         else:
             self.NDIR, self.ODIR, self.RA, self.DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
-        if U.FITS > 0 and self.NDIR == 1:
-            raise UnsupportedOption("fits (ASOCS.py:885-892 writes the images with astropy; drop the key for outcoming.socs)")
         if U.MAPCENTRE[0] < -1e7:                                  # ASOC_aux.py:791-793
             U.MAPCENTRE = (0.5 * c.NX, 0.5 * c.NY, 0.5 * c.NZ)
         m = np.nonzero((self.FFREQ >= U.REMIT_F[0]) & (self.FFREQ <= U.REMIT_F[1]))[0]
@@ -249,6 +247,9 @@ class ScatteringRun(AbsorptionRun):
                 files.write_outcoming_healpix("outcoming.socs", U.OUT_NSIDE, self.FFREQ, OUTCOMING)
             else:
                 files.write_outcoming("outcoming.socs", self.FFREQ, OUTCOMING)
+                if U.FITS > 0 and self.NDIR == 1:                  # ASOCS.py:882-892: the cube of the one direction, frequencies as comments
+                    pix = U.GL * U.MAP_DX / (U.DISTANCE if U.DISTANCE > 0.0 else 1000.0)
+                    files.write_fits('%s.fits' % U.file_scattering, OUTCOMING[:, 0], U.FITS_RA, U.FITS_DE, pix, freq=self.FFREQ)
         if self.rank == 0 and self.verbose:
             print("Tkernel %.3f  Tpush %.3f  Tpull %.3f" % (self.timers["Tkernel"], self.timers["Tpush"], self.timers["Tpull"]))
             if self.timers["Tkernel"] > 0:

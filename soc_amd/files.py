@@ -384,3 +384,91 @@ def read_intensity(path):
         if four != 4 or rest - 4 != 16 * cells * nfreq:
             raise FileError("%s: not an intensity file" % path)
         return np.fromfile(fp, np.float32).reshape(cells, nfreq, 4)
+
+
+# ---- FITS images (fits key; the reference builds them with astropy.io.fits through ASOC_aux.MakeFits, :1723-1790) ----
+def _fits_card(key, value, comment=""):
+    if isinstance(value, bool):
+        v = "%20s" % ("T" if value else "F")
+    elif isinstance(value, (int, np.integer)):
+        v = "%20d" % int(value)
+    elif isinstance(value, (float, np.floating)):
+        t = repr(float(value)).upper()
+        if "E" not in t and "." not in t and "INF" not in t and "NAN" not in t:
+            t += ".0"
+        v = "%20s" % t
+    else:
+        v = "'%-8s'" % str(value).replace("'", "''")
+        v = "%-20s" % v
+    card = "%-8s= %s" % (key, v)
+    if comment:
+        card += " / " + comment
+    return card[:80].ljust(80)
+
+
+def write_fits(path, data, lon, lat, pix, freq=(), galactic=False):
+    """One primary HDU with the header MakeFits gives its images: data[n, m] (or [nchn, n, m] with `freq`), float32
+    big-endian; tangent projection centred on (lon, lat) [deg], pixel `pix` [rad].  Written by hand (80-character cards,
+    2880-byte blocks) -- the image has no astropy."""
+    a = np.asarray(data, np.float32)
+    cube = a.ndim == 3
+    n, m = a.shape[-2], a.shape[-1]
+    cards = [_fits_card("SIMPLE", True, "conforms to FITS standard"), _fits_card("BITPIX", -32, "array data type"),
+             _fits_card("NAXIS", 3 if cube else 2, "number of array dimensions"), _fits_card("NAXIS1", m), _fits_card("NAXIS2", n)]
+    if cube:
+        cards.append(_fits_card("NAXIS3", a.shape[0]))
+    cards += [_fits_card("EXTEND", True),
+              _fits_card("CRVAL1", float(lon)), _fits_card("CRVAL2", float(lat)),
+              _fits_card("CDELT1", -float(pix) * 180.0 / np.pi), _fits_card("CDELT2", float(pix) * 180.0 / np.pi),
+              _fits_card("CRPIX1", 0.5 * (m + 1) + 0.5), _fits_card("CRPIX2", 0.5 * (n + 1) + 0.5)]
+    if galactic:
+        cards += [_fits_card("CTYPE1", "GLON-TAN"), _fits_card("CTYPE2", "GLAT-TAN"), _fits_card("COORDSYS", "GALACTIC")]
+    else:
+        cards += [_fits_card("CTYPE1", "RA---TAN"), _fits_card("CTYPE2", "DEC--TAN"), _fits_card("COORDSYS", "EQUATORIAL"),
+                  _fits_card("EQUINOX", 2000.0)]
+    if cube:
+        cards += [_fits_card("CRPIX3", 1), _fits_card("CRVAL3", 0.0), _fits_card("CDELT3", 1), _fits_card("CTYPE3", "channel")]
+        for i, f in enumerate(freq):
+            cards.append(("COMMENT F[ %3d ] = %.4e" % (i, float(f))).ljust(80))
+    cards.append("END".ljust(80))
+    head = "".join(cards)
+    head += " " * (-len(head) % 2880)
+    body = a.astype(">f4").tobytes()
+    body += b"\0" * (-len(body) % 2880)
+    with open(path, "wb") as fp:
+        fp.write(head.encode("ascii"))
+        fp.write(body)
+
+
+def read_fits(path):
+    """-> (header dict, data) of a file write_fits wrote (primary HDU, BITPIX -32)"""
+    with open(path, "rb") as fp:
+        raw = fp.read()
+    hdr, pos, done = {}, 0, False
+    comments = []
+    while not done:
+        block = raw[pos:pos + 2880].decode("ascii")
+        pos += 2880
+        for i in range(0, 2880, 80):
+            card = block[i:i + 80]
+            key = card[:8].strip()
+            if key == "END":
+                done = True
+                break
+            if key == "COMMENT":
+                comments.append(card[8:].strip())
+            elif card[8:10] == "= ":
+                v = card[10:].split(" / ")[0].strip()
+                if v.startswith("'"):
+                    hdr[key] = v.strip("'").strip()
+                elif v in ("T", "F"):
+                    hdr[key] = (v == "T")
+                else:
+                    hdr[key] = float(v) if any(c in v for c in ".EN") else int(v)
+    if hdr["BITPIX"] != -32:
+        raise FileError("%s: BITPIX %s" % (path, hdr["BITPIX"]))
+    shape = [hdr["NAXIS%d" % k] for k in range(hdr["NAXIS"], 0, -1)]
+    n = int(np.prod(shape))
+    data = np.frombuffer(raw, ">f4", n, pos).astype(np.float32).reshape(shape)
+    hdr["COMMENT"] = comments
+    return hdr, data

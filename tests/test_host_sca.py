@@ -205,3 +205,24 @@ def test_scattering_run_with_several_scattering_functions(tmp_path):
         want = img.reshape(2, 10, 12) * np.float32(FREQ * 1.0e23 * launch.PLANCK / (0.8 * 0.8))
         assert n > 1000
         np.testing.assert_allclose(OUTC[i], want, rtol=1e-6)
+
+
+def test_scattering_run_writes_the_fits_cube(tmp_path):
+    """`fits` with ONE direction: <scattering>.fits, a cube [frequency, y, x] of the images with the frequencies as header
+    comments (ASOCS.py:882-892, MakeFits), beside outcoming.socs"""
+    from oracle_engine import OracleEngine
+    d = str(tmp_path)
+    cloud = synth.cartesian_cloud(5, seed=2)
+    ini = _write_model(d, cloud, nfreq=2, extra="mapping 12 10 0.8\ndirection 30 40\nfits 10.0 20.0\nscattering %s/sca\n" % d)
+    os.chdir(d)
+    U = User(ini)
+    assert U.FITS == 1 and U.file_scattering == os.path.join(d, "sca")
+    run = ScatteringRun(U, OracleEngine("soc"))
+    OUTC = run.run()
+    hdr, cube = files.read_fits(os.path.join(d, "sca.fits"))
+    assert cube.shape == (2, 10, 12) and np.array_equal(cube, OUTC[:, 0]) and cube.sum() > 0
+    assert hdr["NAXIS3"] == 2 and hdr["CTYPE3"] == "channel" and hdr["CRVAL1"] == 10.0 and hdr["CRVAL2"] == 20.0
+    assert abs(hdr["CDELT2"] - (0.5 * 0.8 / 1000.0) * 180.0 / math.pi) < 1e-15              # nominal 1 kpc without `distance`
+    FFREQ, _, _, _ = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    assert hdr["COMMENT"] == ["F[ %3d ] = %.4e" % (i, f) for i, f in enumerate(FFREQ)]
+    assert os.path.exists("outcoming.socs")

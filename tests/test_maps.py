@@ -100,6 +100,56 @@ def test_map_files_of_the_driver(tmp_path):
     assert np.array_equal(maps[i].ravel(), want)
 
 
+def test_fits_maps_and_column_density(tmp_path):
+    """`fits ra de prefix` + `mapum`: one FITS image per selected frequency instead of map_dir_00.bin (ASOC.py:2977-2996,
+    3143-3148); `savetau file -1 <um>`: column density with the first mapped frequency, always a FITS image (:3152-3159),
+    optical depth at <um> (:3160-3171).  Headers as MakeFits writes them (ASOC_aux.py:1723-1768)."""
+    from oracle_engine import OracleEngine
+    from soc_amd import files
+    from soc_amd.asoc import AbsorptionRun
+    from soc_amd.ini import User
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    extra = ("noabsorbed\niterations 1\ntemperature %s/T.bin\nemitted %s/em.bin\nmapping 12 10 0.8\ndirection 30 40\n"
+             "fits 83.8 -5.4 img\nmapum 0.641\nsavetau %s/sv -1 0.75\ndistance 400\n" % (d, d, d))
+    ini = _write_model(d, cloud, extra=extra)
+    txt = open(ini).read().replace("nosolve\n", "").replace("nomap\n", "").replace("absorbed %s/abs.data\n" % d, "")
+    open(ini, "w").write(txt)
+    os.chdir(d)
+    U = User(ini)
+    assert U.FITS == 1 and len(U.SINGLE_MAP_FREQ) == 1
+    run = AbsorptionRun(U, OracleEngine("soc"), verbose=0)
+    run.run()
+    assert not os.path.exists("map_dir_00.bin")
+    hdr, img = files.read_fits("img_0.64.fits")
+    assert img.shape == (10, 12) and hdr["CTYPE1"] == "RA---TAN" and hdr["CRVAL1"] == 83.8 and hdr["CRVAL2"] == -5.4
+    pix = 0.5 * 0.8 / 400.0
+    assert abs(hdr["CDELT2"] - pix * 180.0 / math.pi) < 1e-15 and hdr["CDELT1"] == -hdr["CDELT2"] and hdr["CRPIX1"] == 7.0 and hdr["CRPIX2"] == 6.0
+    assert not os.path.exists("img_0.75.fits") and not os.path.exists("img_0.56.fits")      # mapum picks one frequency
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    KK = (1.0e23 / launch.FACTOR) * launch.PLANCK / (4.0 * np.pi) * 0.5 * launch.PARSEC
+    _, OD, RA, DE = launch.set_observer_directions([math.radians(30)], [math.radians(40)])
+    i = 1
+    emit = np.asarray(KK * float(FFREQ[i]) * run.EMITTED[:, i], np.float32)
+    want, _ = oracle_mapping(Oracle("soc"), Job(cloud, CSC, ABS=AFABS[0][i], SCA=AFSCA[0][i]), emit, OD[0], RA[0], DE[0], (12, 10), 0.8, (3.0, 3.0, 3.0))
+    assert np.array_equal(img.ravel(), want)
+    # column density (first mapped frequency, 0.75 um, which also asks for tau: tau wins there, ASOC.py:3056) ...
+    _, tau = files.read_fits(os.path.join(d, "sv_tau_0.75.fits"))
+    _, wtau = oracle_mapping(Oracle("soc"), Job(cloud, CSC, ABS=AFABS[0][0], SCA=AFSCA[0][0]), np.zeros(cloud.CELLS, np.float32), OD[0], RA[0], DE[0],
+                             (12, 10), 0.8, (3.0, 3.0, 3.0))
+    assert np.array_equal(tau.ravel(), wtau) and tau.max() > 0
+    assert not os.path.exists(os.path.join(d, "sv_colden.fits"))
+    # ... and without a tau request at the first frequency the column density is written
+    open(ini, "w").write(txt.replace("savetau %s/sv -1 0.75" % d, "savetau %s/sv -1" % d))
+    AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    _, col = files.read_fits(os.path.join(d, "sv_colden.fits"))
+    _, LENGTH = launch.kernel_literals(0.5)
+    _, wcol = oracle_mapping(Oracle("soc"), Job(cloud, CSC, ABS=AFABS[0][0], SCA=AFSCA[0][0]), np.zeros(cloud.CELLS, np.float32), OD[0], RA[0], DE[0],
+                             (12, 10), 0.8, (3.0, 3.0, 3.0), save_colden=1, LENGTH=LENGTH)
+    assert np.array_equal(col.ravel(), wcol) and col.max() > 0
+
+
 def test_healpix_map_file_of_the_driver(tmp_path):
     """`mapping 4 -1 1.0` + `perspective x y z`: map_dir_00_H.bin = int32 [NSIDE, -1], int32 [frequencies, LEVELS], one
     float32 [12*NSIDE^2] all-sky map per emitted frequency inside `wavelength` (the loop of ASOC.py:3240-3309)"""
