@@ -48,8 +48,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("SUBITERATIONS (sub-iterations of the reference field, ASOC.py:2261-2720)")
     # keys the parser knows (soc_amd/ini.py keeps the reference's keyword set) whose effect is not built: refused, so that
     # an ini file using them stops here instead of finishing with products missing or different
-    if USER.ABSTHIN > 1:
-        bad.append("absthin (absorptions of every n:th cell only)")
+    if 'nnmake' in USER.KEYS:
+        bad.append("nnmake (training data for the driver's neural-network shortcut: thinned absorptions, ASOC.py:100-105,632-638; `absthin` alone is ignored, as in the reference)")
     if USER.POLMAP or USER.POLSIM or len(USER.BFILES) > 0 or len(getattr(USER, "file_polred", "")) > 0:
         bad.append("polmap / polred / magnetic-field files (polarisation maps)")
     if USER.FAST_MAP >= 2:

@@ -187,12 +187,13 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\n", "polmap bx by bz\n",
+    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\nnnmake 1\n", "polmap bx by bz\n",
                   "mapping 12 10 0.8 2\n", "mapint 1\n", "interpolate 1\n", "threshold 1\n", "CR_HEATING 1e-17\n", "pssavetau ps 0.55\n",
                   "externalmask m.bin\n", "sourcemap s.bin\n", "bgmethod 1\n", "yshear 0.1\n", "DEFS -D X=1\n",
                   "reference 1\nsaveint 1\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
+    AbsorptionRun(User(_write_model(d, cloud, extra="absthin 4\n")), OracleEngine("soc"))     # without nnmake the reference resets it (ASOC.py:100-101)
 
 
 def test_healpix_background_block(tmp_path):
