@@ -292,6 +292,14 @@ int   soc_sca_bind_out(soc_ctx *ctx, void *device_ptr);
 
 /* ---- equilibrium dust temperature and emission (ASOC.py `CLT`/`CLE` paths) ---- */
 
+/* -D CR_HEATING=1 -D CR_HEATING_RATE=<rate> (ini key CR_HEATING; ASOC.py:352,362; kernel_ASOC_aux.c:769-773): soc_solve_temperature
+ * adds 1e-27 * FACTOR * rate to the energy a cell absorbs.  rate = 0 switches it off. */
+int soc_set_cr_heating(soc_ctx *ctx, float rate);
+
+/* -D LEVEL_THRESHOLD=<level> (ini key threshold; kernel_ASOC_map.c:825-834): soc_map (flat maps; HealpixMapping has no such
+ * test) leaves out the emission of cells on levels below `level`; they still absorb.  0 switches it off. */
+int soc_set_map_threshold(soc_ctx *ctx, int level);
+
 /* replaces the EqTemperature launches per level (ASOC.py:2024-2040 -> kernel_ASOC_aux.c:745-790):
  * EABS[CELLS] = integrated absorbed energy per cell (the array the reference calls EMIT at this
  * point: TABS of the dust-emission iteration + CTABS), TTT[NE] the host's E->T table with

@@ -44,6 +44,7 @@ class OrcModel(C.Structure):
         ("STEP_WEIGHT", C.c_int), ("SW_A", C.c_float), ("SW_B", C.c_float),
         ("MSF_NDUST", C.c_int), ("MSF_SCA", _F), ("ABU", _F),
         ("INTV", _F),
+        ("LEVEL_THRESHOLD", C.c_int), ("CR_HEATING_RATE", C.c_float),
     ]
 
 
@@ -184,6 +185,8 @@ class Oracle:
         m.WITH_ABU = int(job.OPT is not None)
         m.WITH_INT, m.USE_EMWEIGHT = int(job.WITH_INT > 0), job.USE_EMWEIGHT
         m.INTV = _fp(job.INTV) if job.INTV is not None else None
+        m.LEVEL_THRESHOLD = int(getattr(job, "LEVEL_THRESHOLD", 0))
+        m.CR_HEATING_RATE = float(getattr(job, "CR_HEATING_RATE", 0.0))
         m.DOUBLE_INDEX = double_index(cl.NX, cl.LEVELS)
         m.LCELLS, m.OFF, m.DENS = _ip(job.LCELLS), _ip(job.OFF), _fp(job.DENS)
         if job.PAR is None:

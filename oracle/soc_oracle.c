@@ -130,6 +130,8 @@ typedef struct {
     int   MSF_NDUST;
     const float *MSF_SCA, *ABU;
     float *INTV;                      /* -D SAVE_INTENSITY=2: INTX | INTY | INTZ, CELLS floats each (kernel_ASOC.c:604-612) */
+    int   LEVEL_THRESHOLD;            /* -D LEVEL_THRESHOLD: Mapping ignores the emission of coarser levels (kernel_ASOC_map.c:825-834) */
+    float CR_HEATING_RATE;            /* -D CR_HEATING=1 -D CR_HEATING_RATE: EqTemperature adds 1e-27*FACTOR*rate (kernel_ASOC_aux.c:769-773); 0 = off */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -1593,12 +1595,16 @@ __attribute__((visibility("default"))) void orc_mapping(const orc_model *M, int 
         }
         IndexG(M, &POS, &level, &ind);
         while (ind >= 0) {
+            const int olevel = level;
             oind = M->OFF[level] + ind;
             sx   = GetStepMap(M, &POS, &TMP, &level, &ind);
             dens = M->DENS[oind];
             emit = EMIT[oind];
             if (M->WITH_ABU) DTAU = sx * dens * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
             else             DTAU = sx * dens * (M->SCA + M->ABS);
+            if ((mode == 0) && (M->LEVEL_THRESHOLD > 0) && (olevel < M->LEVEL_THRESHOLD)) {
+                /* Mapping with -D LEVEL_THRESHOLD: no emission from coarser levels, extinction as usual (:825-834); HealpixMapping has no such test */
+            } else
             if (DTAU < 1.0e-3f) PHOTONS += M_EXP(-TAU) * (1.0f - 0.5f * DTAU) * sx * emit * dens;
             else                PHOTONS += M_EXP(-TAU) * ((1.0f - M_EXP(-DTAU)) / DTAU) * sx * emit * dens;
             TAU += DTAU;
@@ -1759,7 +1765,8 @@ EXPORT void orc_eqtemp(const orc_model *M, float adhoc, float kE, float Emin, in
     for (int level = 0; level < M->LEVELS; level++) {
         for (int i = 0; i < M->LCELLS[level]; i++) {
             const int   ind = M->OFF[level] + i;
-            const float Ein = (scale / adhoc) * EABS[ind] * M_POWN(8.0f, level) / M->DENS[ind];
+            float Ein = (scale / adhoc) * EABS[ind] * M_POWN(8.0f, level) / M->DENS[ind];
+            if (M->CR_HEATING_RATE > 0.0f) Ein += 1.0e-27f * FACTOR * M->CR_HEATING_RATE;       /* kernel_ASOC_aux.c:769-773 */
             const float a   = M_FLOOR(oplgkE * M_LOG10((Ein / beta) / Emin));
             int   iE = (a != a) ? 0 : ((a < 0.0f) ? 0 : ((a > (float)(NE - 2)) ? NE - 2 : (int)a));
             const float wi  = (Emin * M_POWN(kE, iE + 1) - (Ein / beta)) / (Emin * M_POWN(kE, iE) * (kE - 1.0f));

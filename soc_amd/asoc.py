@@ -54,24 +54,15 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("polmap / polred / magnetic-field files (polarisation maps)")
     if USER.FAST_MAP >= 2:
         bad.append("mapping with a fourth argument >= 2 (FAST_MAP: all frequencies at once / one map per hierarchy level)")
-    if USER.MAP_INTERPOLATION > 0 or USER.INTERPOLATE > 0:
-        bad.append("mapint / interpolate (interpolated map integration)")
-    if USER.LEVEL_THRESHOLD > 0:
-        bad.append("threshold (maps without the coarse hierarchy levels)")
-    if USER.CR_HEATING > 0:
-        bad.append("CR_HEATING")
+    if USER.MAP_INTERPOLATION > 0:
+        bad.append("mapint (interpolated map integration, kernel_ASOC_map.c:656-761)")
     if len(USER.kernel_defs.strip()) > 0:
         bad.append("DEFS (extra -D options for the OpenCL compiler)")
     if len(USER.file_pssavetau) > 0:
         bad.append("pssavetau (optical depths towards the point sources)")
-    if len(USER.file_external_mask) > 0:
-        bad.append("externalmask (SUBITERATIONS)")
-    if len(USER.file_sourcemap) > 0:
-        bad.append("sourcemap")
-    if USER.BG_METHOD != 0:
-        bad.append("bgmethod")
-    if USER.Y_SHEAR != 0.0:
-        bad.append("yshear")
+    # accepted without effect, because they have none in the reference either: `interpolate` and `yshear` reach only the
+    # per-level map kernel (kernel_ASOC_map_H.c, FAST_MAP >= 999: refused above), `externalmask` only the SUBITERATIONS
+    # branch (refused above), `sourcemap` is parsed and never read (ASOC_aux.py:322), `bgmethod` is a -D that no kernel tests
     if USER.LOAD_TEMPERATURE and USER.ITERATIONS > 0 and USER.WITH_ALI:
         bad.append("loadtemp with ALI iterations (the old temperatures enter the escape-probability correction, ASOC.py:2064-2071)")
     if bad:
@@ -174,6 +165,12 @@ class AbsorptionRun:
         sw = int(U.STEP_WEIGHT[2])
         if sw > 0 or hasattr(e, "set_step_weight"):
             e.set_step_weight(sw, float("%.3e" % int(U.STEP_WEIGHT[0])), float("%.3e" % U.STEP_WEIGHT[1]))
+        if U.CR_HEATING > 0 or hasattr(e, "set_cr_heating"):
+            # -D CR_HEATING=%d -D CR_HEATING_RATE=%.3ef with (USER.CR_HEATING>0), USER.CR_HEATING (ASOC.py:352,362): device solve only,
+            # as in the reference (its host loop, used with ALI, has no such term)
+            e.set_cr_heating(float("%.3e" % U.CR_HEATING) if U.CR_HEATING > 0 else 0.0)
+        if U.LEVEL_THRESHOLD > 0 or hasattr(e, "set_map_threshold"):
+            e.set_map_threshold(max(0, int(U.LEVEL_THRESHOLD)))      # -D LEVEL_THRESHOLD (ASOC.py:349,359)
         if self.WITH_ABU:
             if U.OPT_IS_HALF or hasattr(e, "set_opt_half"):
                 e.set_opt_half(bool(U.OPT_IS_HALF))            # OPT as fp16 (ASOC.py:1158-1159)

@@ -44,6 +44,8 @@ struct soc_ctx {
     float *dHPBG = nullptr, *dHPBGP = nullptr;    // Healpix sky of the current frequency (NSIDE 64)
     float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
     int    abu_ndust = 0, abu_single = 0;
+    int    map_level_threshold = 0;    // -D LEVEL_THRESHOLD (soc_set_map_threshold)
+    float  cr_rate = 0.0f;             // -D CR_HEATING_RATE with -D CR_HEATING=1 (soc_set_cr_heating); 0 = off
     bool   opt_half = false;          // -D OPT_IS_HALF: OPT rounded through fp16 (soc_set_opt_half)
     bool   opt_from_abu = false;       // dOPT and dAF hold the current frequency's soc_set_optical_abu values
     int    msf_ndust = 1;              // > 1: -D WITH_MSF, dCSC/dDSC hold [msf_ndust][BINS] (soc_set_scatter_tables)
@@ -1447,10 +1449,26 @@ int soc_solve_temperature(soc_ctx *c, float adhoc, float kE, float Emin, int NE,
     if (c->ebuf_cap < cells) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dev_alloc(&c->dEbuf, cells)); c->ebuf_cap = cells; }
     HIPCHK(c, hipMemcpyAsync(c->dTTT, TTT, (size_t)NE * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dEbuf, EABS, cells * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, soc_launch_eqtemp(c->G, adhoc, kE, Emin, NE, FACTOR, LENGTH, c->dTTT, c->dEbuf, c->dT, c->stream));
+    HIPCHK(c, soc_launch_eqtemp(c->G, adhoc, kE, Emin, NE, FACTOR, LENGTH, c->cr_rate, c->dTTT, c->dEbuf, c->dT, c->stream));
     if (TNEW) HIPCHK(c, hipMemcpyAsync(TNEW, c->dT, cells * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_T = true;
+    return SOC_OK;
+}
+
+int soc_set_cr_heating(soc_ctx *c, float rate)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!(rate >= 0.0f) || !std::isfinite(rate)) return fail(c, SOC_ERR_ARG, "soc_set_cr_heating: rate %g (>= 0; 0 switches it off)", (double)rate);
+    c->cr_rate = rate;
+    return SOC_OK;
+}
+
+int soc_set_map_threshold(soc_ctx *c, int level)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (level < 0 || level > SOC_MAXL) return fail(c, SOC_ERR_ARG, "soc_set_map_threshold: level %d", level);
+    c->map_level_threshold = level;
     return SOC_OK;
 }
 
@@ -1530,6 +1548,7 @@ int soc_map(soc_ctx *c, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const
     memset(&A, 0, sizeof A);
     A.mode = healpix ? 1 : 0;
     A.NPIX_X = NPIX_X;  A.NPIX_Y = healpix ? 1 : NPIX_Y;  A.SAVE_COLDEN = save_colden;
+    A.LEVEL_THRESHOLD = c->map_level_threshold;
     A.MAP_DX = MAP_DX;  A.ABS = ABS;  A.SCA = SCA;  A.LENGTH = LENGTH;
     for (int k = 0; k < 3; k++) {
         A.DIR[k] = DIR ? DIR[k] : 0.0f;  A.RA[k] = RA ? RA[k] : 0.0f;  A.DE[k] = DE ? DE[k] : 0.0f;

@@ -106,7 +106,7 @@ struct SocSca {
 hipError_t soc_launch_sca(const SocGrid &G, const SocSim &S, const SocSca &V, const SocVariant &X, hipStream_t st);
 
 // equilibrium temperature and thermal emission (soc_emit.hip)
-hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH,
+hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH, float cr_rate,
                              const float *TTT, const float *EABS, float *TNEW, hipStream_t st);
 hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
                                const float *T, float *EMIT, hipStream_t st);
@@ -119,6 +119,7 @@ hipError_t soc_launch_opt_half(int cells, float2 *OPT, hipStream_t st);
 struct SocMapArgs {
     int   mode;                    // 0 Mapping, 1 HealpixMapping (NSIDE = NPIX_X)
     int   NPIX_X, NPIX_Y, SAVE_COLDEN;
+    int   LEVEL_THRESHOLD;         // Mapping: no emission from levels below it (-D LEVEL_THRESHOLD, kernel_ASOC_map.c:825-834)
     float MAP_DX, ABS, SCA, LENGTH;
     float DIR[3], RA[3], DE[3], CENTRE[3], INTOBS[3];
     const float  *EMIT;

@@ -11,7 +11,7 @@
 
 // TNEW[cell] from the absorbed energy per cell (array "EMIT" in the reference), all levels in one launch
 __global__ void soc_eqtemp_kernel(const SocGrid G, const float adhoc, const float kE, const float Emin, const int NE,
-                                  const float FACTOR, const float LENGTH, const float *TTT, const float *EABS, float *TNEW)
+                                  const float FACTOR, const float LENGTH, const float cr_rate, const float *TTT, const float *EABS, float *TNEW)
 {
     __shared__ int sOFF[SOC_MAXL + 1];
     if (threadIdx.x <= SOC_MAXL) sOFF[threadIdx.x] = (threadIdx.x < G.LEVELS) ? G.OFF[threadIdx.x] : G.CELLS;
@@ -24,7 +24,8 @@ __global__ void soc_eqtemp_kernel(const SocGrid G, const float adhoc, const floa
         int level = 0;
         while (level + 1 < G.LEVELS && ind >= sOFF[level + 1]) level++;
         const float d   = G.DENS[ind];
-        const float Ein = (scale / adhoc) * EABS[ind] * soc_pownf(8.0f, level) / d;
+        float Ein = (scale / adhoc) * EABS[ind] * soc_pownf(8.0f, level) / d;
+        if (cr_rate > 0.0f) Ein += 1.0e-27f * FACTOR * cr_rate;           // -D CR_HEATING=1 -D CR_HEATING_RATE (kernel_ASOC_aux.c:769-773)
         int iE = (int)soc_floorf(oplgkE * soc_log10f((Ein / beta) / Emin));
         iE = iE < 0 ? 0 : (iE > NE - 2 ? NE - 2 : iE);
         const float wi = (Emin * soc_pownf(kE, iE + 1) - (Ein / beta)) / (Emin * soc_pownf(kE, iE) * (kE - 1.0f));
@@ -45,12 +46,12 @@ __global__ void soc_emission_kernel(const int c0, const int c1, const int nfreq,
     }
 }
 
-hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH,
+hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin, int NE, float FACTOR, float LENGTH, float cr_rate,
                              const float *TTT, const float *EABS, float *TNEW, hipStream_t st)
 {
     if (G.CELLS <= 0) return hipSuccess;
     const int blocks = (int)(((long)G.CELLS + 255) / 256 < 65536 ? ((long)G.CELLS + 255) / 256 : 65536);
-    soc_eqtemp_kernel<<<blocks, 256, 0, st>>>(G, adhoc, kE, Emin, NE, FACTOR, LENGTH, TTT, EABS, TNEW);
+    soc_eqtemp_kernel<<<blocks, 256, 0, st>>>(G, adhoc, kE, Emin, NE, FACTOR, LENGTH, cr_rate, TTT, EABS, TNEW);
     return hipGetLastError();
 }
 

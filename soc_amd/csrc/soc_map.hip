@@ -178,14 +178,16 @@ __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const Soc
     soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens);
     while (ind >= 0) {
         const int   oind = sOFF[level] + ind;
+        const int   olevel = level;
         const float d0 = dens;
         const float sx = soc_map_getstep<OCT, DBL>(G, sOFF, px, py, pz, tx, ty, tz, level, ind, dens);
         const float emit = A.EMIT[oind];
         float DTAU;
         if (ABU) { const float2 o = A.OPT[oind];  DTAU = sx * d0 * (o.x + o.y); }
         else     DTAU = sx * d0 * (A.SCA + A.ABS);
-        if (DTAU < 1.0e-3f) PHOTONS += soc_expf(-TAU) * (1.0f - 0.5f * DTAU) * sx * emit * d0;
-        else                PHOTONS += soc_expf(-TAU) * ((1.0f - soc_expf(-DTAU)) / DTAU) * sx * emit * d0;
+        if (!A.mode && (olevel < A.LEVEL_THRESHOLD)) { }                  // `threshold`: coarse levels do not emit (they still absorb); Mapping only
+        else if (DTAU < 1.0e-3f) PHOTONS += soc_expf(-TAU) * (1.0f - 0.5f * DTAU) * sx * emit * d0;
+        else                     PHOTONS += soc_expf(-TAU) * ((1.0f - soc_expf(-DTAU)) / DTAU) * sx * emit * d0;
         TAU += DTAU;
         if (A.mode || (A.SAVE_COLDEN > 0)) colden += sx * d0;
     }

@@ -83,6 +83,8 @@ API = {
     "soc_timer_start": (C.c_int, [C.c_void_p]),
     "soc_timer_stop": (C.c_int, [C.c_void_p, _F]),
     "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
+    "soc_set_cr_heating": (C.c_int, [C.c_void_p, C.c_float]),
+    "soc_set_map_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
     "soc_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int,
@@ -256,6 +258,14 @@ class Engine:
         a = np.ascontiguousarray(AFABS, np.float32).ravel()
         s = np.ascontiguousarray(AFSCA, np.float32).ravel()
         self._chk(self.lib.soc_set_optical_abu(self.h, _f(a), _f(s), int(a.size)))
+
+    def set_cr_heating(self, rate):
+        """-D CR_HEATING_RATE (with -D CR_HEATING=1): added to the absorbed energy in solve_temperature; 0 = off"""
+        self._chk(self.lib.soc_set_cr_heating(self.h, float(rate)))
+
+    def set_map_threshold(self, level):
+        """-D LEVEL_THRESHOLD: flat maps leave out the emission of coarser levels; 0 = off"""
+        self._chk(self.lib.soc_set_map_threshold(self.h, int(level)))
 
     def set_opt_half(self, on=True):
         """-D OPT_IS_HALF: OPT of later set_opt / set_optical_abu calls is rounded to fp16 as the reference stores it"""

@@ -187,8 +187,15 @@ class OracleEngine:
         self.events += n
 
     # ---- temperature and emission ----
+    def set_cr_heating(self, rate):
+        self.cr_rate = float(rate)
+
+    def set_map_threshold(self, level):
+        self.map_threshold = int(level)
+
     def solve_temperature(self, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS):
         job = Job(self.cloud, np.linspace(1, -1, 8))
+        job.CR_HEATING_RATE = getattr(self, "cr_rate", 0.0)
         self.Tdust = self.orc.eqtemp(job, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS)
         return self.Tdust.copy()
 
@@ -201,6 +208,7 @@ class OracleEngine:
     # ---- map making ----
     def map(self, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, ABS, SCA, INTOBS=None, save_colden=0, LENGTH=1.0, healpix=0):
         job = Job(self.cloud, np.linspace(1, -1, 8), ABS=ABS, SCA=SCA, OPT=self.OPT)
+        job.LEVEL_THRESHOLD = getattr(self, "map_threshold", 0)
         io = NO_INTOBS if (INTOBS is None or INTOBS[0] < -1e10) else INTOBS
         m, t = oracle_mapping(self.orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, io, save_colden, LENGTH, healpix)
         shape = (m.size,) if healpix else (int(NPIX[1]), int(NPIX[0]))

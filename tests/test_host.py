@@ -188,12 +188,14 @@ def test_unsupported_options_fail_loudly(tmp_path):
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
     for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\nnnmake 1\n", "polmap bx by bz\n",
-                  "mapping 12 10 0.8 2\n", "mapint 1\n", "interpolate 1\n", "threshold 1\n", "CR_HEATING 1e-17\n", "pssavetau ps 0.55\n",
-                  "externalmask m.bin\n", "sourcemap s.bin\n", "bgmethod 1\n", "yshear 0.1\n", "DEFS -D X=1\n",
+                  "mapping 12 10 0.8 2\n", "mapint 1\n", "pssavetau ps 0.55\n", "DEFS -D X=1\n",
                   "reference 1\nsaveint 1\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))
-    AbsorptionRun(User(_write_model(d, cloud, extra="absthin 4\n")), OracleEngine("soc"))     # without nnmake the reference resets it (ASOC.py:100-101)
+    # keys without effect in the reference are accepted: absthin without nnmake (ASOC.py:100-101), and keys that only reach
+    # branches refused above or nothing at all
+    AbsorptionRun(User(_write_model(d, cloud, extra="absthin 4\ninterpolate 1\nexternalmask m.bin\nsourcemap s.bin\nbgmethod 1\nyshear 0.1\n")),
+                  OracleEngine("soc"))
 
 
 def test_healpix_background_block(tmp_path):

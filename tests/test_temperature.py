@@ -58,6 +58,13 @@ def test_oracle_bit_exact_vs_reference_kernels():
     assert np.abs(T[leaf] - T_target[leaf]).max() < 0.01 and (T[~leaf] == 10.0).all()
     E = ol.emission(FF, FABS, FACTOR, LENGTH, T)
     assert np.array_equal(E.view(np.uint32), Ref("oct8").emission(job, FF, FABS, T).view(np.uint32))
+    # -D CR_HEATING=1 -D CR_HEATING_RATE=2.5 (ini key CR_HEATING): a constant added to the absorbed energy (kernel_ASOC_aux.c:769-773)
+    job.CR_HEATING_RATE = 2.5
+    Tc = ol.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, 1e-6 * EABS)
+    assert np.array_equal(Tc.view(np.uint32), Ref("oct8cr").eqtemp(job, 1.0, kE, Emin, TTT, 1e-6 * EABS).view(np.uint32))
+    job.CR_HEATING_RATE = 0.0
+    T0 = ol.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, 1e-6 * EABS)
+    assert (Tc[leaf] >= T0[leaf] - 1e-3).all() and (Tc[leaf] > T0[leaf]).mean() > 0.5
     # product math: same algorithm, last-bit differences in log10/pown/exp only
     Ts = Oracle("soc").eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, EABS)
     assert np.abs(Ts[leaf] / T[leaf] - 1).max() < 2e-5
@@ -110,6 +117,17 @@ def test_hip_temperature_and_emission_match_oracle(engine):
     assert np.array_equal(T.view(np.uint32), want.view(np.uint32))          # same header, same operation order
     E = engine.emission(FF, FABS, FACTOR, LENGTH)
     assert np.array_equal(E.view(np.uint32), osoc.emission(FF, FABS, FACTOR, LENGTH, want).view(np.uint32))
+    # CR_HEATING: a constant term in the absorbed energy (kernel_ASOC_aux.c:769-773)
+    engine.set_cr_heating(2.5)
+    try:
+        Tc = engine.solve_temperature(1.0, kE, Emin, TTT, FACTOR, LENGTH, 1e-6 * EABS)
+    finally:
+        engine.set_cr_heating(0.0)
+    job.CR_HEATING_RATE = 2.5
+    wc = osoc.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, 1e-6 * EABS)
+    assert np.array_equal(Tc.view(np.uint32), wc.view(np.uint32))
+    job.CR_HEATING_RATE = 0.0
+    assert not np.array_equal(wc, osoc.eqtemp(job, 1.0, kE, Emin, TTT, FACTOR, LENGTH, 1e-6 * EABS))
 
 
 @pytest.mark.gpu
