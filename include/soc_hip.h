@@ -332,6 +332,12 @@ int soc_map(soc_ctx *ctx, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, con
 
 /* ---- stochastically heated grains: A2E.py / kernel_A2E.c ---- */
 
+/* replaces the PSTau launch of ASOC.py:3576-3645 (ini key pssavetau; kernel_ASOC_map.c:1545-1584): for every point source
+ * the column density (x LENGTH) and the optical depth (ABS + SCA, or the per-cell OPT of soc_set_opt) along the ray from the
+ * source towards the observer direction DIR[3].  PSPOS: 4 floats per source (cl float3). */
+int soc_ps_tau(soc_ctx *ctx, int NO_PS, const float *PSPOS, const float *DIR, float ABS, float SCA, float LENGTH,
+               float *pscolden, float *pstau);
+
 /* replaces the per-size uploads of A2E.py:338-371 (AF, Iw, L1, L2, Tdown, EA, Ibeg) and the
  * -D NE -D NFREQ build of A2E.py:283-304.  L1/L2 are [NE*NE] indexed l*NE+u, Iw holds noIw
  * weights in (l, u, i) loop order, EA is [NFREQ*NE]. */

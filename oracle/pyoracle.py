@@ -688,6 +688,19 @@ def oracle_mapping(orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, INTOBS=NO_
     return MAP, TAU
 
 
+def oracle_pstau(orc, job, PSPOS, DIR, LENGTH=1.0):
+    """PSTau: (column density * LENGTH, optical depth) from every point source towards the observer direction DIR"""
+    L = orc.lib
+    L.orc_pstau.argtypes = [C.POINTER(OrcModel), C.c_int, _F, _F, C.c_float, _F, _F]
+    m = orc._model(job)
+    P = np.zeros((len(PSPOS), 4), np.float32)
+    P[:, :3] = np.asarray(PSPOS, np.float32)[:, :3]
+    d = np.ascontiguousarray(np.asarray(DIR, np.float32).ravel()[:3])
+    col, tau = np.zeros(len(P), np.float32), np.zeros(len(P), np.float32)
+    L.orc_pstau(C.byref(m), len(P), _fp(P), _fp(d), np.float32(LENGTH), _fp(col), _fp(tau))
+    return col, tau
+
+
 class RefMap:
     """x86 build of kernel_ASOC_map.c for one model: oracle/_ref/refmap_<tag>.so"""
 
@@ -708,6 +721,23 @@ class RefMap:
             return True
         except (FileNotFoundError, OSError, KeyError):
             return False
+
+    def pstau(self, job, PAR, PSPOS, DIR):
+        """the build's -D LENGTH applies to the column density"""
+        a = MArgs()
+        for name, val in (("DIR", DIR), ("RA", DIR), ("DE", DIR)):
+            v = np.zeros(4, np.float32)
+            v[:3] = np.asarray(val, np.float32).ravel()[:3]
+            setattr(a, name, (C.c_float * 4)(*v))
+        a.ABS, a.SCA = np.float32(job.ABS), np.float32(job.SCA)
+        a.LCELLS, a.OFF, a.PAR, a.DENS = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR), _fp(job.DENS)
+        a.OPT = _fp(job.OPT) if job.OPT is not None else None
+        P = np.zeros((len(PSPOS), 4), np.float32)
+        P[:, :3] = np.asarray(PSPOS, np.float32)[:, :3]
+        col, tau = np.zeros(len(P), np.float32), np.zeros(len(P), np.float32)
+        self.lib.ref_pstau.argtypes = [C.POINTER(MArgs), C.c_int, _F, _F, _F]
+        self.lib.ref_pstau(C.byref(a), len(P), _fp(P), _fp(col), _fp(tau))
+        return col, tau
 
     def mapping(self, job, PAR, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, INTOBS=NO_INTOBS, save_colden=0, healpix=0):
         a = MArgs()

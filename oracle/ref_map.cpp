@@ -12,6 +12,9 @@ void HealpixMapping(float MAP_DX, int2 NPIX, float *MAP, float *EMIT, float3 DIR
                     int *OFF, int *PAR, float *DENS, float ABS, float SCA, float3 CENTRE, float3 INTOBS, float *OPT,
                     float *SAVETAU, int SAVE_COLDEN);
 
+void PSTau(int no, float3 *PSPOS, float3 DIR, float3 RA, float3 DE, int *LCELLS, int *OFF, int *PAR, float *DENS, float ABS,
+           float SCA, float *OPT, float *pscolden, float *pstau);
+
 struct map_args {
     int   NPIX_X, NPIX_Y, SAVE_COLDEN, healpix;
     float MAP_DX, ABS, SCA;
@@ -37,6 +40,18 @@ void ref_map(const map_args *a, int npixels)
         else
             Mapping(a->MAP_DX, NPIX, a->MAP, a->EMIT, f3of(a->DIR), f3of(a->RA), f3of(a->DE), a->LCELLS, a->OFF, a->PAR, a->DENS,
                     a->ABS, a->SCA, f3of(a->CENTRE), f3of(a->INTOBS), a->OPT ? a->OPT : dummy, a->SAVETAU, a->SAVE_COLDEN);
+    }
+}
+
+// PSTau: one work item per point source; PSPOS = cl float3 array (16 bytes per source)
+void ref_pstau(const map_args *a, int no, float *PSPOS, float *pscolden, float *pstau)
+{
+    float dummy[8] = { 0 };
+    g_gsize = (size_t)no;
+    for (int id = 0; id < no; id++) {
+        g_gid = (size_t)id;
+        PSTau(no, (float3 *)PSPOS, f3of(a->DIR), f3of(a->RA), f3of(a->DE), a->LCELLS, a->OFF, a->PAR, a->DENS, a->ABS, a->SCA,
+              a->OPT ? a->OPT : dummy, pscolden, pstau);
     }
 }
 }

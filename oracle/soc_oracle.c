@@ -1775,6 +1775,29 @@ EXPORT void orc_eqtemp(const orc_model *M, float adhoc, float kE, float Emin, in
     }
 }
 
+/* PSTau (kernel_ASOC_map.c:1545-1584): column density and optical depth from every point source towards the observer,
+ * with the map kernels' GetStep.  PSPOS: 4 floats per source (cl float3). */
+EXPORT void orc_pstau(const orc_model *M, int no, const float *PSPOS, const float *DIRv, float LENGTH, float *pscolden, float *pstau)
+{
+    const f3 DIR = { DIRv[0], DIRv[1], DIRv[2] };
+    for (int id = 0; id < no; id++) {
+        float DTAU, TAU = 0.0f, colden = 0.0f, sx;
+        f3    POS = { PSPOS[4 * id], PSPOS[4 * id + 1], PSPOS[4 * id + 2] };
+        int   ind, level = 0, oind;
+        IndexG(M, &POS, &level, &ind);
+        while (ind >= 0) {
+            oind = M->OFF[level] + ind;
+            sx   = GetStepMap(M, &POS, &DIR, &level, &ind);
+            if (M->WITH_ABU) DTAU = sx * M->DENS[oind] * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
+            else             DTAU = sx * M->DENS[oind] * (M->SCA + M->ABS);
+            TAU += DTAU;
+            colden += sx * M->DENS[oind];
+        }
+        pscolden[id] = colden * LENGTH;
+        pstau[id]    = TAU;
+    }
+}
+
 /* Emission2 (kernel_ASOC_aux.c:862-888): EMIT[(icell-c0)*nfreq+ifreq] */
 EXPORT void orc_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
                          const float *T, float *EMIT)

@@ -58,8 +58,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("mapint (interpolated map integration, kernel_ASOC_map.c:656-761)")
     if len(USER.kernel_defs.strip()) > 0:
         bad.append("DEFS (extra -D options for the OpenCL compiler)")
-    if len(USER.file_pssavetau) > 0:
-        bad.append("pssavetau (optical depths towards the point sources)")
     # accepted without effect, because they have none in the reference either: `interpolate` and `yshear` reach only the
     # per-level map kernel (kernel_ASOC_map_H.c, FAST_MAP >= 999: refused above), `externalmask` only the SUBITERATIONS
     # branch (refused above), `sourcemap` is parsed and never read (ASOC_aux.py:322), `bgmethod` is a -D that no kernel tests
@@ -680,6 +678,22 @@ class AbsorptionRun:
         for fp in fps:
             fp.close()
 
+    def write_ps_tau(self):
+        """`pssavetau file um`: for every observer direction <file>_<idir>.dat with one line per point source -- its index,
+        the column density [cm-2 per unit density] and the optical depth towards the observer at the frequency of the grid
+        closest to `um` (ASOC.py:3576-3645, PSTau)"""
+        U, e = self.U, self.eng
+        IFREQ = int(np.argmin(np.abs(self.FFREQ - U.pssavetau_freq)))
+        ABS, SCA = self._optical_for(IFREQ)
+        NDIR, ODIR, RA, DE = launch.set_observer_directions(U.OBS_THETA, U.OBS_PHI)
+        _, LENGTH_f = launch.kernel_literals(U.GL)
+        for idir in range(NDIR):
+            col, tau = e.ps_tau(U.PSPOS[:U.NO_PS, :3], ODIR[idir], ABS, SCA, LENGTH_f)
+            if self.rank == 0:
+                with open("%s_%d.dat" % (U.file_pssavetau, idir), "w") as fp:
+                    for i in range(U.NO_PS):
+                        fp.write('%6d  %12.4e  %12.4e\n' % (i, col[i], tau[i]))
+
     def write_healpix_maps(self, EMITTED):
         """`mapping NSIDE -1 dx`: all-sky map of the emission seen from `perspective` (HealpixMapping, kernel_ASOC_map.c),
         file layout of ASOC.py:3185-3320: map_dir_00_H.bin = int32 [NPIX.x, NPIX.y], int32 [frequencies, LEVELS], then one
@@ -733,6 +747,8 @@ class AbsorptionRun:
             self.TNEW, self.EMITTED = self.emission_from_temperature_file()
         if (not U.NOMAP) and self.EMITTED is not None and hasattr(self.eng, "map"):
             self.write_maps(self.EMITTED)
+        if U.NO_PS > 0 and U.pssavetau_freq > 0.0 and U.NPIX[1] > 0 and hasattr(self.eng, "ps_tau"):
+            self.write_ps_tau()
         if self.rank == 0 and self.INTENSITY is not None:          # ASOC.py:2733-2757
             files.finish_intensity_file(U.SAVE_INTENSITY_FILE, self.INTENSITY, self.cloud.CELLS, self.NFREQ, U.SAVE_INTENSITY == 2)
             self.INTENSITY = None

@@ -1564,6 +1564,27 @@ int soc_map(soc_ctx *c, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const
     return SOC_OK;
 }
 
+int soc_ps_tau(soc_ctx *c, int NO_PS, const float *PSPOS, const float *DIR, float ABS, float SCA, float LENGTH, float *pscolden, float *pstau)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_ps_tau: call soc_set_grid first");
+    if (NO_PS < 1 || NO_PS > 1000000 || !PSPOS || !DIR || !pscolden || !pstau) return fail(c, SOC_ERR_ARG, "soc_ps_tau: need NO_PS >= 1 sources, DIR and the two output arrays");
+    for (int k = 0; k < 3; k++) if (!std::isfinite(DIR[k]) || DIR[k] == 0.0f) return fail(c, SOC_ERR_ARG, "soc_ps_tau: DIR[%d] = %g", k, (double)DIR[k]);
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr;                                     // PSPOS (4 floats per source) | colden | tau
+    const size_t n = (size_t)NO_PS;
+    if (hipMalloc((void **)&d, n * 6 * 4) != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_ps_tau: allocation");
+    hipError_t e = hipMemcpyAsync(d, PSPOS, n * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = soc_launch_pstau(c->G, NO_PS, (const float4 *)d, DIR, ABS, SCA, c->dOPT, LENGTH, d + 4 * n, d + 5 * n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pscolden, d + 4 * n, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pstau, d + 5 * n, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_ps_tau: %s", hipGetErrorString(e));
+    return SOC_OK;
+}
+
 int soc_a2e_set_size(soc_ctx *c, int NE, int NFREQ, int noIw, const float *Iw, const int32_t *L1,
                      const int32_t *L2, const float *Tdown, const float *EA, const int32_t *Ibeg, const float *AF)
 {

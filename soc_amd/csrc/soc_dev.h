@@ -127,6 +127,8 @@ struct SocMapArgs {
     float *MAP, *SAVETAU;
 };
 hipError_t soc_launch_map(const SocGrid &G, const SocMapArgs &A, bool abu, hipStream_t st);
+hipError_t soc_launch_pstau(const SocGrid &G, int no, const float4 *PSPOS, const float *DIR, float ABS, float SCA, const float2 *OPT, float LENGTH,
+                            float *pscolden, float *pstau, hipStream_t st);
 
 // stochastic-heating solver (soc_a2e.hip)
 struct SocA2EArgs {

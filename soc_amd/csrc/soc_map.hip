@@ -195,6 +195,47 @@ __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const Soc
     A.SAVETAU[id] = A.SAVE_COLDEN ? (colden * A.LENGTH) : TAU;
 }
 
+// PSTau (kernel_ASOC_map.c:1545-1584): column density and optical depth from every point source towards the observer
+template <bool OCT, bool DBL, bool ABU>
+__global__ __launch_bounds__(64) void soc_pstau_kernel(const SocGrid G, const int no, const float4 *PSPOS, const float ux, const float uy, const float uz,
+                                                       const float ABS, const float SCA, const float2 *OPT, const float LENGTH, float *pscolden, float *pstau)
+{
+    __shared__ int sOFF[SOC_MAXL];
+    if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
+    __syncthreads();
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= no) return;
+    float px = PSPOS[id].x, py = PSPOS[id].y, pz = PSPOS[id].z, TAU = 0.0f, colden = 0.0f, dens = 0.0f;
+    int   level = 0, ind = -1;
+    soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens);
+    while (ind >= 0) {
+        const int   oind = sOFF[level] + ind;
+        const float d0 = dens;
+        const float sx = soc_map_getstep<OCT, DBL>(G, sOFF, px, py, pz, ux, uy, uz, level, ind, dens);
+        float DTAU;
+        if (ABU) { const float2 o = OPT[oind];  DTAU = sx * d0 * (o.x + o.y); }
+        else     DTAU = sx * d0 * (SCA + ABS);
+        TAU += DTAU;
+        colden += sx * d0;
+    }
+    pscolden[id] = colden * LENGTH;
+    pstau[id]    = TAU;
+}
+
+hipError_t soc_launch_pstau(const SocGrid &G, int no, const float4 *PSPOS, const float *DIR, float ABS, float SCA, const float2 *OPT, float LENGTH,
+                            float *pscolden, float *pstau, hipStream_t st)
+{
+    if (no <= 0) return hipSuccess;
+    const dim3 grid((no + 63) / 64), block(64);
+    const bool oct = G.LEVELS > 1, dbl = oct && (G.NX > 100), abu = OPT != nullptr;
+#define SOC_PT(O, D, A) soc_pstau_kernel<O, D, A><<<grid, block, 0, st>>>(G, no, PSPOS, DIR[0], DIR[1], DIR[2], ABS, SCA, OPT, LENGTH, pscolden, pstau)
+    if (!oct)      { if (abu) SOC_PT(false, false, true); else SOC_PT(false, false, false); }
+    else if (!dbl) { if (abu) SOC_PT(true, false, true);  else SOC_PT(true, false, false); }
+    else           { if (abu) SOC_PT(true, true, true);   else SOC_PT(true, true, false); }
+#undef SOC_PT
+    return hipGetLastError();
+}
+
 hipError_t soc_launch_map(const SocGrid &G, const SocMapArgs &A, bool abu, hipStream_t st)
 {
     const int npix = A.mode ? 12 * A.NPIX_X * A.NPIX_X : A.NPIX_X * A.NPIX_Y;

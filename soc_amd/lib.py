@@ -89,6 +89,7 @@ API = {
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
     "soc_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int,
                           C.c_float, _F, _F]),
+    "soc_ps_tau": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, C.c_float, _F, _F]),
     "soc_a2e_set_size": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _F, _I, _I, _F, _F, _I, _F]),
     "soc_a2e_solve": (C.c_int, [C.c_void_p, C.c_int, _F, _F]),
     "soc_a2e_upload": (C.c_int, [C.c_void_p, C.c_int, _F]),
@@ -432,6 +433,15 @@ class Engine:
                                    _f(v[3]), _f(v[4]), np.float32(ABS), np.float32(SCA), int(save_colden), np.float32(LENGTH),
                                    _f(MAP), _f(TAU)))
         return MAP, TAU
+
+    def ps_tau(self, PSPOS, DIR, ABS, SCA, LENGTH=1.0):
+        """PSTau: (column density * LENGTH, optical depth) from every point source towards the observer direction DIR"""
+        P = np.zeros((len(PSPOS), 4), np.float32)
+        P[:, :3] = np.asarray(PSPOS, np.float32)[:, :3]
+        d = np.ascontiguousarray(np.asarray(DIR, np.float32).ravel()[:3])
+        col, tau = np.zeros(len(P), np.float32), np.zeros(len(P), np.float32)
+        self._chk(self.lib.soc_ps_tau(self.h, len(P), _f(P), _f(d), np.float32(ABS), np.float32(SCA), np.float32(LENGTH), _f(col), _f(tau)))
+        return col, tau
 
     # ---- scattered-light images (ASOCS) ----
     @staticmethod

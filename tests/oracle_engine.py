@@ -214,6 +214,11 @@ class OracleEngine:
         shape = (m.size,) if healpix else (int(NPIX[1]), int(NPIX[0]))
         return m.reshape(shape), t.reshape(shape)
 
+    def ps_tau(self, PSPOS, DIR, ABS, SCA, LENGTH=1.0):
+        from oracle.pyoracle import oracle_pstau
+        job = Job(self.cloud, np.linspace(1, -1, 8), ABS=ABS, SCA=SCA, OPT=self.OPT)
+        return oracle_pstau(self.orc, job, PSPOS, DIR, LENGTH)
+
     # ---- scattered-light images ----
     def sca_set_view(self, ODIR, RA, DE, NPIX, MAP_DX, CENTRE, FFS=1):
         self.view = ScaView(ODIR, RA, DE, NPIX=NPIX, MAP_DX=MAP_DX, CENTRE=CENTRE, FFS=FFS)

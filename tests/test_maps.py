@@ -152,6 +152,68 @@ def test_fits_maps_and_column_density(tmp_path):
     assert np.array_equal(col.ravel(), wcol) and col.max() > 0
 
 
+_PS4 = np.array([[4.3, 4.2, 4.1], [2.5, 6.5, 3.3], [0.2, 0.3, 7.9], [7.7, 0.4, 0.6]], np.float32)
+
+
+@pytest.mark.skipif(not RefMap.available("oct8"), reason="reference builds (oracle/_ref) not present")
+def test_pstau_oracle_bit_exact_vs_reference(oracle_libm):
+    """PSTau (kernel_ASOC_map.c:1545-1584) compiled from the reference, scalar and per-cell opacities"""
+    from oracle.pyoracle import oracle_pstau
+    o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
+    LEN = float("%.5e" % (0.01 * 3.08567758e18))              # the -D LENGTH of the build (oracle/build.py)
+    for ref, opt in (("oct8", None), ("c8abu", True)):
+        cloud = o8 if ref == "oct8" else synth.cartesian_cloud(8, seed=3)
+        job = Job(cloud, CSC, ABS=1e-3, SCA=3e-3, OPT=_opt(cloud.CELLS) if opt else None)
+        for k in range(N):
+            c, t = oracle_pstau(oracle_libm, job, _PS4, OD[k], LEN)
+            c2, t2 = RefMap(ref).pstau(job, oracle_libm.parents(job), _PS4, OD[k])
+            assert np.array_equal(c.view(np.uint32), c2.view(np.uint32)) and np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+            assert (t > 0).all() and (c > 0).all()
+
+
+@pytest.mark.gpu
+def test_pstau_hip_bit_identical_to_oracle(engine, oracle_soc):
+    from oracle.pyoracle import oracle_pstau
+    for cloud, opt in ((synth.octree_cloud(8, levels=3, frac=0.15, seed=7), False), (synth.cartesian_cloud(8, seed=3), True),
+                       (synth.octree_cloud(104, levels=3, frac=0.002, seed=11), False)):
+        job = Job(cloud, CSC, ABS=1e-3, SCA=3e-3, OPT=_opt(cloud.CELLS) if opt else None)
+        ps = _PS4 * np.float32(cloud.NX / 8.0)
+        engine.set_cloud(cloud)
+        engine.set_opt(job.OPT)
+        for k in range(N):
+            c, t = engine.ps_tau(ps, OD[k], job.ABS, job.SCA, LENGTH)
+            c2, t2 = oracle_pstau(oracle_soc, job, ps, OD[k], LENGTH)
+            assert np.array_equal(c.view(np.uint32), c2.view(np.uint32)) and np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+    engine.set_opt(None)
+
+
+def test_pssavetau_file_of_the_driver(tmp_path):
+    """`pssavetau file um`: <file>_<idir>.dat, one line per point source (ASOC.py:3576-3645)"""
+    from oracle.pyoracle import oracle_pstau
+    from oracle_engine import OracleEngine
+    from soc_amd import files
+    from soc_amd.asoc import AbsorptionRun
+    from soc_amd.ini import User
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _write_model(d, cloud, with_ps=True, extra="mapping 12 10 0.8\ndirection 30 40\ndirection 90 0\npssavetau %s/pst 0.64\n" % d)
+    os.chdir(d)
+    U = User(ini)
+    run = AbsorptionRun(U, OracleEngine("soc"), verbose=0)
+    run.run()
+    FFREQ, _, AFABS, AFSCA = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    i = int(np.argmin(np.abs(FFREQ - U.pssavetau_freq)))
+    assert i == 1
+    _, OD2, _, _ = launch.set_observer_directions([math.radians(30), math.radians(90)], [math.radians(40), 0.0])
+    _, LEN = launch.kernel_literals(0.5)
+    for idir in (0, 1):
+        rows = [l.split() for l in open(os.path.join(d, "pst_%d.dat" % idir))]
+        assert len(rows) == 1 and rows[0][0] == "0"
+        c, t = oracle_pstau(Oracle("soc"), Job(cloud, CSC, ABS=AFABS[0][i], SCA=AFSCA[0][i]), U.PSPOS[:1, :3], OD2[idir], LEN)
+        assert rows[0][1] == "%.4e" % c[0] and rows[0][2] == "%.4e" % t[0] and t[0] > 0
+
+
 def test_healpix_map_file_of_the_driver(tmp_path):
     """`mapping 4 -1 1.0` + `perspective x y z`: map_dir_00_H.bin = int32 [NSIDE, -1], int32 [frequencies, LEVELS], one
     float32 [12*NSIDE^2] all-sky map per emitted frequency inside `wavelength` (the loop of ASOC.py:3240-3309)"""
