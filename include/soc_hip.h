@@ -300,6 +300,11 @@ int soc_set_cr_heating(soc_ctx *ctx, float rate);
  * test) leaves out the emission of cells on levels below `level`; they still absorb.  0 switches it off. */
 int soc_set_map_threshold(soc_ctx *ctx, int level);
 
+/* -D ROI_MAP=1 and the ROI argument of Mapping / HealpixMapping (ini key roimap with roi; ASOC.py:2941-2956,3126-3133;
+ * kernel_ASOC_map.c:37-56,821-823,947-949): soc_map counts the emission of cells whose root cell lies inside
+ * ROI = [x0,x1,y0,y1,z0,z1] (inclusive) only; extinction as usual.  NULL switches it off. */
+int soc_set_map_roi(soc_ctx *ctx, const int32_t *ROI);
+
 /* replaces the EqTemperature launches per level (ASOC.py:2024-2040 -> kernel_ASOC_aux.c:745-790):
  * EABS[CELLS] = integrated absorbed energy per cell (the array the reference calls EMIT at this
  * point: TABS of the dust-emission iteration + CTABS), TTT[NE] the host's E->T table with

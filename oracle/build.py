@@ -68,11 +68,11 @@ def build_oracle(force=False):
 def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
              USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
              GL=0.01, HPBG_WEIGHTED=0, WITH_ALI=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0,
-             STEP_WEIGHT=-1, SW_A=0.0, SW_B=0.0, DIR_WEIGHT=-1, DW_A=0.0, LEVEL_THRESHOLD=0, CR_HEATING=0.0):
+             STEP_WEIGHT=-1, SW_A=0.0, SW_B=0.0, DIR_WEIGHT=-1, DW_A=0.0, LEVEL_THRESHOLD=0, CR_HEATING=0.0, ROI_MAP=0):
     """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
     d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=WITH_ALI, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
-             CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS), WITH_ABU=WITH_ABU, ROI_MAP=0, MAX_SPLIT=4300,
+             CELLS=CELLS, AREA=AREA, NO_PS=max(1, NO_PS), WITH_ABU=WITH_ABU, ROI_MAP=ROI_MAP, MAX_SPLIT=4300,
              SELEM=0, ROI_STEP=ROI_STEP, ROI_NSIDE=ROI_NSIDE, WITH_ROI_LOAD=WITH_ROI_LOAD, WITH_ROI_SAVE=WITH_ROI_SAVE,
              AXY="%.5ff" % (NX * NY / AREA), AXZ="%.5ff" % (NX * NZ / AREA), AYZ="%.5ff" % (NY * NZ / AREA),
              LEVELS=LEVELS, LENGTH="%.5ef" % (GL * 3.08567758e18), DO_SPLIT=0, POLSTAT=0,
@@ -207,7 +207,7 @@ def build_ref_map(tag, force=False, NSIDE=8, **model):
     common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
     subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header", "-ftrivial-auto-var-init=zero",
                            "-w", "-I", REFERENCE] + common + defs + ["-c", ksrc, "-o", kobj])
-    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-DROI_MAP=%d" % model.get("ROI_MAP", 0), "-c", drv, "-o", sobj])
     _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
     os.remove(kobj)
     os.remove(sobj)
@@ -227,6 +227,7 @@ def map_ref_models():
         "oct8": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS),
         "oct104": dict(NX=104, NY=104, NZ=104, LEVELS=oct104.LEVELS, CELLS=oct104.CELLS),
         "c208": dict(NX=208, NY=208, NZ=208, LEVELS=1, CELLS=208 ** 3),
+        "oct8roi": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, ROI_MAP=1),
         "oct8thr": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, LEVEL_THRESHOLD=1),
     }
 

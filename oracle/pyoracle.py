@@ -44,7 +44,7 @@ class OrcModel(C.Structure):
         ("STEP_WEIGHT", C.c_int), ("SW_A", C.c_float), ("SW_B", C.c_float),
         ("MSF_NDUST", C.c_int), ("MSF_SCA", _F), ("ABU", _F),
         ("INTV", _F),
-        ("LEVEL_THRESHOLD", C.c_int), ("CR_HEATING_RATE", C.c_float),
+        ("LEVEL_THRESHOLD", C.c_int), ("ROI_MAP", C.c_int), ("CR_HEATING_RATE", C.c_float),
     ]
 
 
@@ -187,6 +187,11 @@ class Oracle:
         m.INTV = _fp(job.INTV) if job.INTV is not None else None
         m.LEVEL_THRESHOLD = int(getattr(job, "LEVEL_THRESHOLD", 0))
         m.CR_HEATING_RATE = float(getattr(job, "CR_HEATING_RATE", 0.0))
+        m.ROI_MAP = 0
+        if getattr(job, "ROI_MAP", None) is not None:        # maps of the emission inside ROI = [x0,x1,y0,y1,z0,z1] only
+            m.ROI_MAP = 1
+            for k in range(6):
+                m.ROI[k] = int(job.ROI_MAP[k])
         m.DOUBLE_INDEX = double_index(cl.NX, cl.LEVELS)
         m.LCELLS, m.OFF, m.DENS = _ip(job.LCELLS), _ip(job.OFF), _fp(job.DENS)
         if job.PAR is None:
@@ -667,7 +672,7 @@ class MArgs(C.Structure):
                 ("DIR", C.c_float * 4), ("RA", C.c_float * 4), ("DE", C.c_float * 4), ("CENTRE", C.c_float * 4),
                 ("INTOBS", C.c_float * 4),
                 ("LCELLS", _I), ("OFF", _I), ("PAR", _I),
-                ("DENS", _F), ("EMIT", _F), ("OPT", _F), ("MAP", _F), ("SAVETAU", _F)]
+                ("DENS", _F), ("EMIT", _F), ("OPT", _F), ("MAP", _F), ("SAVETAU", _F), ("ROI", _I)]
 
 
 NO_INTOBS = (-1.0e12, 0.0, 0.0)
@@ -755,5 +760,10 @@ class RefMap:
         a.LCELLS, a.OFF, a.PAR = _ip(job.LCELLS), _ip(job.OFF), _ip(PAR)
         a.DENS, a.EMIT, a.MAP, a.SAVETAU = _fp(job.DENS), _fp(EMIT), _fp(MAP), _fp(TAU)
         a.OPT = _fp(job.OPT) if job.OPT is not None else None
+        roi = getattr(job, "ROI_MAP", None)
+        assert (roi is not None) == bool(self.model.get("ROI_MAP", 0))
+        if roi is not None:
+            roi = np.ascontiguousarray(roi, np.int32)
+            a.ROI = _ip(roi)
         self.lib.ref_map(C.byref(a), n)
         return MAP, TAU

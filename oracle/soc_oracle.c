@@ -131,6 +131,7 @@ typedef struct {
     const float *MSF_SCA, *ABU;
     float *INTV;                      /* -D SAVE_INTENSITY=2: INTX | INTY | INTZ, CELLS floats each (kernel_ASOC.c:604-612) */
     int   LEVEL_THRESHOLD;            /* -D LEVEL_THRESHOLD: Mapping ignores the emission of coarser levels (kernel_ASOC_map.c:825-834) */
+    int   ROI_MAP;                    /* -D ROI_MAP: the map kernels count the emission of cells inside ROI only (kernel_ASOC_map.c:821-823,947-949) */
     float CR_HEATING_RATE;            /* -D CR_HEATING=1 -D CR_HEATING_RATE: EqTemperature adds 1e-27*FACTOR*rate (kernel_ASOC_aux.c:769-773); 0 = off */
 } orc_model;
 
@@ -1602,6 +1603,9 @@ __attribute__((visibility("default"))) void orc_mapping(const orc_model *M, int 
             emit = EMIT[oind];
             if (M->WITH_ABU) DTAU = sx * dens * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
             else             DTAU = sx * dens * (M->SCA + M->ABS);
+            if (M->ROI_MAP && (InRoi(M, olevel, oind - M->OFF[olevel]) < 0)) {
+                /* -D ROI_MAP: emission from ROI only (Mapping and HealpixMapping alike) */
+            } else
             if ((mode == 0) && (M->LEVEL_THRESHOLD > 0) && (olevel < M->LEVEL_THRESHOLD)) {
                 /* Mapping with -D LEVEL_THRESHOLD: no emission from coarser levels, extinction as usual (:825-834); HealpixMapping has no such test */
             } else

@@ -38,8 +38,6 @@ def _check_supported(USER, NDUST, WITH_MSF):
         bad.append("stepweight with a third argument > 2 (the kernel then uses an uninitialised free path, kernel_ASOC.c:516-535)")
     if USER.DIR_WEIGHT[0] > 0:
         bad.append("direweight (-D DIR_WEIGHT > 0 does not compile in the reference: pweight, pind undeclared, kernel_ASOC.c:770-775)")
-    if USER.ROI_MAP:
-        bad.append("roimap")
     if USER.PS_METHOD == 3:
         bad.append("psmethod 3 (does not compile in the reference either)")
     if USER.WITH_REFERENCE and USER.SAVE_INTENSITY > 0:
@@ -167,6 +165,8 @@ class AbsorptionRun:
             # -D CR_HEATING=%d -D CR_HEATING_RATE=%.3ef with (USER.CR_HEATING>0), USER.CR_HEATING (ASOC.py:352,362): device solve only,
             # as in the reference (its host loop, used with ALI, has no such term)
             e.set_cr_heating(float("%.3e" % U.CR_HEATING) if U.CR_HEATING > 0 else 0.0)
+        if U.ROI_MAP or hasattr(e, "set_map_roi"):
+            e.set_map_roi(U.ROI if U.ROI_MAP else None)              # -D ROI_MAP (ASOC.py:345,354; :3126-3133)
         if U.LEVEL_THRESHOLD > 0 or hasattr(e, "set_map_threshold"):
             e.set_map_threshold(max(0, int(U.LEVEL_THRESHOLD)))      # -D LEVEL_THRESHOLD (ASOC.py:349,359)
         if self.WITH_ABU:

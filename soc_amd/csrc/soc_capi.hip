@@ -45,6 +45,7 @@ struct soc_ctx {
     float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
     int    abu_ndust = 0, abu_single = 0;
     int    map_level_threshold = 0;    // -D LEVEL_THRESHOLD (soc_set_map_threshold)
+    int    map_roi_on = 0, map_roi[6] = { 0, 0, 0, 0, 0, 0 };   // -D ROI_MAP (soc_set_map_roi)
     float  cr_rate = 0.0f;             // -D CR_HEATING_RATE with -D CR_HEATING=1 (soc_set_cr_heating); 0 = off
     bool   opt_half = false;          // -D OPT_IS_HALF: OPT rounded through fp16 (soc_set_opt_half)
     bool   opt_from_abu = false;       // dOPT and dAF hold the current frequency's soc_set_optical_abu values
@@ -1464,6 +1465,20 @@ int soc_set_cr_heating(soc_ctx *c, float rate)
     return SOC_OK;
 }
 
+int soc_set_map_roi(soc_ctx *c, const int32_t *ROI)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!ROI) { c->map_roi_on = 0;  return SOC_OK; }
+    if (!c->have_grid) return fail(c, SOC_ERR_STATE, "soc_set_map_roi: call soc_set_grid first");
+    const int N[3] = { c->G.NX, c->G.NY, c->G.NZ };
+    for (int k = 0; k < 3; k++)
+        if (ROI[2 * k] < 0 || ROI[2 * k + 1] < ROI[2 * k] || ROI[2 * k + 1] >= N[k])
+            return fail(c, SOC_ERR_ARG, "soc_set_map_roi: limits %d..%d on axis %d of a grid of %d root cells", ROI[2 * k], ROI[2 * k + 1], k, N[k]);
+    for (int k = 0; k < 6; k++) c->map_roi[k] = ROI[k];
+    c->map_roi_on = 1;
+    return SOC_OK;
+}
+
 int soc_set_map_threshold(soc_ctx *c, int level)
 {
     if (!c) return SOC_ERR_ARG;
@@ -1549,6 +1564,8 @@ int soc_map(soc_ctx *c, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const
     A.mode = healpix ? 1 : 0;
     A.NPIX_X = NPIX_X;  A.NPIX_Y = healpix ? 1 : NPIX_Y;  A.SAVE_COLDEN = save_colden;
     A.LEVEL_THRESHOLD = c->map_level_threshold;
+    A.ROI_MAP = c->map_roi_on;
+    for (int k = 0; k < 6; k++) A.ROI[k] = c->map_roi[k];
     A.MAP_DX = MAP_DX;  A.ABS = ABS;  A.SCA = SCA;  A.LENGTH = LENGTH;
     for (int k = 0; k < 3; k++) {
         A.DIR[k] = DIR ? DIR[k] : 0.0f;  A.RA[k] = RA ? RA[k] : 0.0f;  A.DE[k] = DE ? DE[k] : 0.0f;

@@ -119,6 +119,7 @@ hipError_t soc_launch_opt_half(int cells, float2 *OPT, hipStream_t st);
 struct SocMapArgs {
     int   mode;                    // 0 Mapping, 1 HealpixMapping (NSIDE = NPIX_X)
     int   NPIX_X, NPIX_Y, SAVE_COLDEN;
+    int   ROI_MAP, ROI[6];         // -D ROI_MAP: only the emission of cells inside ROI = [x0,x1,y0,y1,z0,z1] (root cells, inclusive)
     int   LEVEL_THRESHOLD;         // Mapping: no emission from levels below it (-D LEVEL_THRESHOLD, kernel_ASOC_map.c:825-834)
     float MAP_DX, ABS, SCA, LENGTH;
     float DIR[3], RA[3], DE[3], CENTRE[3], INTOBS[3];

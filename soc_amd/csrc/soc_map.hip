@@ -92,6 +92,15 @@ __device__ __forceinline__ bool soc_map_outside(const SocGrid &G, float x, float
     return (x < 0.0f) || (x > G.NX) || (y < 0.0f) || (y > G.NY) || (z < 0.0f) || (z > G.NZ);
 }
 
+// InRoi (kernel_ASOC_map.c:37-56): is the root cell above cell (level, ind) inside ROI?
+template <bool OCT>
+__device__ __forceinline__ bool soc_map_inroi(const SocGrid &G, const int *sOFF, const int *ROI, int level, int ind)
+{
+    if (OCT) { while (level > 0) { ind = G.PAR[sOFF[level] + ind - G.NXYZ];  level--; } }
+    const int k = ind / (G.NX * G.NY), j = (ind / G.NX) % G.NY, i = ind % G.NX;
+    return (i >= ROI[0]) && (i <= ROI[1]) && (j >= ROI[2]) && (j <= ROI[3]) && (k >= ROI[4]) && (k <= ROI[5]);
+}
+
 template <bool OCT, bool DBL, bool ABU>
 __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const SocMapArgs A)
 {
@@ -185,7 +194,8 @@ __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const Soc
         float DTAU;
         if (ABU) { const float2 o = A.OPT[oind];  DTAU = sx * d0 * (o.x + o.y); }
         else     DTAU = sx * d0 * (A.SCA + A.ABS);
-        if (!A.mode && (olevel < A.LEVEL_THRESHOLD)) { }                  // `threshold`: coarse levels do not emit (they still absorb); Mapping only
+        if (A.ROI_MAP && !soc_map_inroi<OCT>(G, sOFF, A.ROI, olevel, oind - sOFF[olevel])) { }   // `roimap`: cells outside ROI do not emit
+        else if (!A.mode && (olevel < A.LEVEL_THRESHOLD)) { }             // `threshold`: coarse levels do not emit (they still absorb); Mapping only
         else if (DTAU < 1.0e-3f) PHOTONS += soc_expf(-TAU) * (1.0f - 0.5f * DTAU) * sx * emit * d0;
         else                     PHOTONS += soc_expf(-TAU) * ((1.0f - soc_expf(-DTAU)) / DTAU) * sx * emit * d0;
         TAU += DTAU;

@@ -85,6 +85,7 @@ API = {
     "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
     "soc_set_cr_heating": (C.c_int, [C.c_void_p, C.c_float]),
     "soc_set_map_threshold": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_set_map_roi": (C.c_int, [C.c_void_p, _I]),
     "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
     "soc_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int,
@@ -267,6 +268,11 @@ class Engine:
     def set_map_threshold(self, level):
         """-D LEVEL_THRESHOLD: flat maps leave out the emission of coarser levels; 0 = off"""
         self._chk(self.lib.soc_set_map_threshold(self.h, int(level)))
+
+    def set_map_roi(self, ROI):
+        """-D ROI_MAP: maps of the emission inside ROI = [x0,x1,y0,y1,z0,z1] only; None = all cells"""
+        r = None if ROI is None else np.ascontiguousarray(ROI, np.int32)
+        self._chk(self.lib.soc_set_map_roi(self.h, _i(r)))
 
     def set_opt_half(self, on=True):
         """-D OPT_IS_HALF: OPT of later set_opt / set_optical_abu calls is rounded to fp16 as the reference stores it"""

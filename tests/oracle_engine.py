@@ -190,6 +190,9 @@ class OracleEngine:
     def set_cr_heating(self, rate):
         self.cr_rate = float(rate)
 
+    def set_map_roi(self, ROI):
+        self.map_roi = None if ROI is None else [int(v) for v in ROI]
+
     def set_map_threshold(self, level):
         self.map_threshold = int(level)
 
@@ -209,6 +212,7 @@ class OracleEngine:
     def map(self, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, ABS, SCA, INTOBS=None, save_colden=0, LENGTH=1.0, healpix=0):
         job = Job(self.cloud, np.linspace(1, -1, 8), ABS=ABS, SCA=SCA, OPT=self.OPT)
         job.LEVEL_THRESHOLD = getattr(self, "map_threshold", 0)
+        job.ROI_MAP = getattr(self, "map_roi", None)
         io = NO_INTOBS if (INTOBS is None or INTOBS[0] < -1e10) else INTOBS
         m, t = oracle_mapping(self.orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, io, save_colden, LENGTH, healpix)
         shape = (m.size,) if healpix else (int(NPIX[1]), int(NPIX[0]))

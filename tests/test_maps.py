@@ -31,6 +31,9 @@ MAP_CASES = {
     "map_oct8_inside": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(intobs=(4.2, 4.1, 3.9), npix=(16, 9))),
     "map_oct8_colden": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(colden=1)),
     "map_oct8_healpix": ("oct8", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(intobs=(4.2, 4.1, 3.9), healpix=8)),
+    "map_oct8_roimap": ("oct8roi", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(roi=[2, 5, 1, 6, 3, 4])),    # -D ROI_MAP=1
+    "map_oct8_roimap_healpix": ("oct8roi", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7),
+                                dict(roi=[2, 5, 1, 6, 3, 4], intobs=(4.2, 4.1, 3.9), healpix=8)),
     "map_oct8_threshold": ("oct8thr", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(threshold=1)),   # -D LEVEL_THRESHOLD=1
     "map_oct104_double": ("oct104", lambda: synth.octree_cloud(104, levels=3, frac=0.002, seed=11), dict(npix=(24, 24), dx=4.0)),
     "map_c208_entry": ("c208", lambda: synth.cartesian_cloud(208, uniform=1.0), dict(npix=(10, 10), dx=20.0)),
@@ -42,6 +45,7 @@ def run_case(name, mapper):
     ref, mk, kw = MAP_CASES[name]
     cloud = mk()
     job = Job(cloud, CSC, ABS=1e-3, SCA=3e-3, OPT=_opt(cloud.CELLS) if kw.get("abu") else None)
+    job.ROI_MAP = kw.get("roi")                             # `roimap`: only the emission of cells inside ROI
     job.LEVEL_THRESHOLD = kw.get("threshold", 0)            # `threshold` key: emission of coarser levels left out of the maps
     emit = np.where(cloud.DENS > 0, np.abs(cloud.DENS) * 1e-3 * np.random.default_rng(1).uniform(0.5, 2, cloud.CELLS), 0).astype(np.float32)
     c = (cloud.NX / 2, cloud.NY / 2, cloud.NZ / 2)
@@ -257,9 +261,11 @@ def test_map_hip_bit_identical_to_oracle(name, engine, oracle_soc):
         engine.set_cloud(job.cloud)
         engine.set_opt(job.OPT)
         engine.set_map_threshold(job.LEVEL_THRESHOLD)
+        engine.set_map_roi(job.ROI_MAP)
         return engine.map(emit, d, r, e, npix, dx, c, job.ABS, job.SCA, INTOBS=io, save_colden=cd, LENGTH=LENGTH, healpix=hp)
     job, m, t = run_case(name, gpu)
     engine.set_map_threshold(0)
+    engine.set_map_roi(None)
     _, mo, to = run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
                          oracle_mapping(oracle_soc, job, emit, d, r, e, npix, dx, c, io, cd, LENGTH, hp))
     assert np.array_equal(m.view(np.uint32), mo.view(np.uint32))
