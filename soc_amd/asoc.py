@@ -51,7 +51,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
     if USER.POLMAP or USER.POLSIM or len(USER.BFILES) > 0 or len(getattr(USER, "file_polred", "")) > 0:
         bad.append("polmap / polred / magnetic-field files (polarisation maps)")
     if USER.FAST_MAP >= 2:
-        bad.append("mapping with a fourth argument >= 2 (FAST_MAP: all frequencies at once / one map per hierarchy level)")
+        bad.append("mapping with a fourth argument >= 2 (FAST_MAP 2..998: kernel_ASOC_map_X.c, all frequencies per launch -- the reference's "
+                   "own branch stops at ASOC.py:3553, a list compared with a float; >= 999: one map per hierarchy level, kernel_ASOC_map_H.c)")
     if USER.MAP_INTERPOLATION > 0:
         bad.append("mapint (interpolated map integration, kernel_ASOC_map.c:656-761)")
     if len(USER.kernel_defs.strip()) > 0:
