@@ -407,8 +407,8 @@ class AbsorptionRun:
         ALI): per iteration the dust emission of the previous one is simulated with SimRAM_CL
         (`cellpackets`), the integrated absorptions TABS + CTABS give the equilibrium temperature of
         every cell and that the emission at every frequency -- EqTemperature and Emission on the device
-        (the reference's `CLT`/`CLE` paths; its default host loop uses a different interpolation weight,
-        ASOC.py:2059, and is not reproduced).  Writes the temperature and emitted files.
+        with the keys `CLT` / `CLE` in the ini, else the reference's host formulas (its host temperature loop uses
+        a different interpolation weight, ASOC.py:2060).  Writes the temperature and emitted files.
         Returns (TNEW or None, EMITTED[CELLS, REMIT_NFREQ])."""
         U, e, c = self.U, self.eng, self.cloud
         CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
@@ -570,12 +570,28 @@ class AbsorptionRun:
                 EABS = np.array(CTABS, np.float32)
             if solve:
                 t0 = time.time()
-                if ali:                                            # only the host solve knows beta (ASOC.py:2024, 2056-2057)
-                    TNEW = launch.solve_temperature_host(EABS, c, Emin, kE, TTT, U.GL, beta)
-                    e.set_temperature(np.where(TNEW > 0, TNEW, np.float32(10.0)))
-                else:
+                # the ini keys pick the solver as in the reference: `CLT` (without ALI) = the EqTemperature kernel,
+                # otherwise its host loop, the only one that knows beta (ASOC.py:2027, :2042; `MPT` = the same
+                # formula on several processes); `CLE` = the Emission kernel, otherwise the host formula (:2159, :2199)
+                if ('CLT' in U.KEYS) and not ali:
                     TNEW = e.solve_temperature(launch.ADHOC, kE, Emin, TTT, FACTOR_f, LENGTH_f, EABS)
-                EMITTED[:, :] = e.emission(FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], FACTOR_f, LENGTH_f)
+                else:
+                    TNEW = launch.solve_temperature_host(EABS, c, Emin, kE, TTT, U.GL, beta if ali else None,
+                                                         empty_below=0.0 if 'MPT' in U.KEYS else 1.0e-10)
+                if CELLS < 1e8:                                    # ASOC.py:2122-2136
+                    TNEW[~np.isfinite(TNEW)] = 10.0
+                    mok = c.DENS > 1.0e-8
+                    TNEW[mok] = np.clip(TNEW[mok], 3.0, 1600.0)
+                if 'CLE' in U.KEYS:
+                    e.set_temperature(TNEW)                        # ASOC.py:2160: the host's TNEW goes to the device
+                    EMITTED[:, :] = e.emission(FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], FACTOR_f, LENGTH_f)
+                else:
+                    if I1 > 0:
+                        raise ValueError("the host emission loop indexes EMITTED with the frequency index (ASOC.py:2215, :2226): "
+                                         "with `remit` cutting the low frequencies it fails in the reference; add `CLE`")
+                    if 'MPE' in U.KEYS:
+                        TNEW[TNEW < 3.0] = 10.0                    # ASOC.py:2211
+                    EMITTED[:, :] = launch.emission_host(FFREQ[I1:I2 + 1], self.AFABS[0][I1:I2 + 1], TNEW, U.GL)
                 self.timers["Tsolve"] = self.timers.get("Tsolve", 0.0) + time.time() - t0
         if self.rank == 0 and solve and U.ITERATIONS > 0:
             if len(U.file_temperature) > 0:

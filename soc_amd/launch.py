@@ -169,11 +169,12 @@ def temperature_table(FFREQ, FABS, GL, NE=NE_TEMPERATURE):
     return Emin, kE, TTT
 
 
-def solve_temperature_host(EABS, cloud, Emin, kE, TTT, GL, beta=None):
-    """The reference's host temperature solve (ASOC.py:2042-2073), vectorised: the only path that takes
-    the escape probability beta of an ALI run.  Its interpolation weight
+def solve_temperature_host(EABS, cloud, Emin, kE, TTT, GL, beta=None, empty_below=1.0e-10):
+    """The reference's host temperature solve (ASOC.py:2042-2073), vectorised: the default without the key `CLT`
+    and the only path that takes the escape probability beta of an ALI run.  Its interpolation weight
     wi = (Emin kE^(iE+1) - E) / (Emin kE^(iE+1) - kE^iE) is kept as written (the device kernel divides by
-    Emin kE^iE (kE-1) instead); cells with density < 1e-10 (parents, empty cells) get 0."""
+    Emin kE^iE (kE-1) instead); cells with density < 1e-10 (parents, empty cells) get 0.  The `MPT` variant
+    (ASOC.py:2076-2119) is the same formula with density <= 0 as the test for an empty cell: empty_below=0."""
     NE = len(TTT)
     oplgkE = 1.0 / math.log10(kE)
     scale = (6.62607e-27 * FACTOR) / (GL * PARSEC)
@@ -182,7 +183,7 @@ def solve_temperature_host(EABS, cloud, Emin, kE, TTT, GL, beta=None):
     for level in range(cloud.LEVELS):
         a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
         dens = np.asarray(cloud.DENS[a:b], np.float64)
-        ok = dens >= 1.0e-10
+        ok = (dens >= empty_below) if empty_below > 0.0 else (dens > 0.0)
         Ein = (scale / ADHOC) * np.asarray(EABS[a:b], np.float64)[ok] * (8.0 ** level) / dens[ok]
         if beta is not None:
             Ein = Ein / np.asarray(beta[a:b], np.float64)[ok]
@@ -194,6 +195,20 @@ def solve_temperature_host(EABS, cloud, Emin, kE, TTT, GL, beta=None):
         t[ok] = wi * TT[iE] + (1.0 - wi) * TT[iE + 1]
         T[a:b] = t
     return T
+
+
+def emission_host(FREQ, FABS, TNEW, GL):
+    """The reference's host emission (ASOC.py:2199-2232, without the key `CLE`): EMITTED[CELLS, nfreq] =
+    FACTOR 4 pi / (h f) FABS B_f(TNEW) / (GL pc), float32; cells with TNEW = 0 (parents) get the value of the
+    clipped exponent exp(80), as there."""
+    T = np.asarray(TNEW, np.float64)
+    out = np.zeros((T.size, len(FREQ)), np.float32)
+    with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
+        for k in range(len(FREQ)):
+            f = float(FREQ[k])
+            B = 2.0e-20 * ((H_CC20 * f) * f) * f / (np.exp(np.clip(H_K_D * f / T, -80, +80)) - 1.0)
+            out[:, k] = ((FACTOR * 4.0 * np.pi / (PLANCK * f)) * float(FABS[k]) * B) / (GL * PARSEC)
+    return out
 
 
 def mirror_mask(MIRROR):

@@ -76,7 +76,7 @@ def test_iteration_loop_on_oracle_engine(tmp_path):
     from test_host import _write_model
     d = str(tmp_path)
     cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
-    extra = ("noabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
+    extra = ("CLT\nCLE\nnoabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
     ini = _write_model(d, cloud, extra=extra).replace("nosolve\n", "")
     txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
     open(ini, "w").write(txt)
@@ -136,7 +136,7 @@ def test_iteration_loop_end_to_end(engine, tmp_path):
     from test_host import _write_model
     d = str(tmp_path)
     cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
-    extra = ("noabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
+    extra = ("CLT\nCLE\nnoabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (2 * cloud.CELLS, d, d))
     ini = _write_model(d, cloud, extra=extra)
     txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
     open(ini, "w").write(txt)
@@ -153,7 +153,7 @@ def test_iteration_loop_end_to_end(engine, tmp_path):
 
 def _iter_ini(d, cloud, extra):
     from test_host import _write_model
-    ini = _write_model(d, cloud, extra="noabsorbed\niterations 2\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (d, d) + extra)
+    ini = _write_model(d, cloud, extra="CLT\nCLE\nnoabsorbed\niterations 2\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (d, d) + extra)
     txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
     open(ini, "w").write(txt)
     return ini
@@ -228,6 +228,45 @@ def test_reference_field_iterations_on_oracle_engine(tmp_path):
     assert not np.array_equal(np.fromfile(os.path.join(d, "OTABS.save"), np.float32), OT) and em.shape == last.EMITTED.shape
 
 
+def test_default_solver_is_the_host_loop_of_the_reference(tmp_path):
+    """without the keys `CLT` / `CLE` the reference solves temperatures and emission on the host (ASOC.py:2042-2073,
+    :2214-2227): parents get T = 0, the weight is the host loop's, the emission the double-precision Planck formula;
+    `MPE` replaces T < 3 by 10 first (:2211); `remit` that cuts low frequencies fails there and is refused"""
+    from oracle_engine import OracleEngine
+    from test_host import _write_model
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    os.chdir(d)
+
+    def go(keys):
+        extra = keys + "noabsorbed\niterations 1\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal 128\n" % (d, d)
+        ini = _write_model(d, cloud, extra=extra)
+        txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
+        open(ini, "w").write(txt)
+        if os.path.exists(os.path.join(d, "em.bin")):
+            os.remove(os.path.join(d, "em.bin"))
+        run = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+        return run, run.run()[0]
+    host, CTABS = go("")
+    dev, _ = go("CLT\nCLE\n")
+    leaf = cloud.DENS > 0
+    assert (host.TNEW[~leaf] == 0.0).all() and (dev.TNEW[~leaf] == 10.0).all()
+    FFREQ, _, AFABS, _ = files.read_dust([os.path.join(d, "m.dust")], 0.5)
+    Emin, kE, TTT = launch.temperature_table(FFREQ, AFABS[0], 0.5)
+    want = launch.solve_temperature_host(CTABS, cloud, Emin, kE, TTT, 0.5)
+    assert np.array_equal(host.TNEW[leaf], np.clip(want[leaf], 3.0, 1600.0))
+    assert np.array_equal(host.EMITTED, launch.emission_host(FFREQ, AFABS[0], host.TNEW, 0.5))
+    # host and device emission formulas agree where the temperatures do, to the constants they are written with
+    # (h/k = 4.7995074e-11 in the kernel, 4.79924335e-11 on the host)
+    mixed, _ = go("CLT\n")
+    assert np.array_equal(mixed.TNEW, dev.TNEW)
+    assert np.allclose(mixed.EMITTED[leaf], dev.EMITTED[leaf], rtol=1e-2)
+    mpe, _ = go("MPE\n")
+    assert (mpe.TNEW[~leaf] == 10.0).all() and np.array_equal(mpe.TNEW[leaf], host.TNEW[leaf])
+    with pytest.raises(ValueError, match="CLE"):
+        go("remit 0.5 0.7\n")
+
+
 def test_host_temperature_solve_matches_device_formula_away_from_its_quirk():
     """launch.solve_temperature_host (the reference's host loop) lands within one table step of the device kernel"""
     o8 = synth.octree_cloud(8, levels=3, frac=0.15, seed=7)
@@ -249,7 +288,7 @@ def test_iteration_loop_end_to_end_with_cell_emission_in_the_brick_sweep(engine,
     from test_host import _write_model
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(64, seed=9)
-    extra = ("gridlength 2e-6\nnoabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal %d\n"
+    extra = ("CLT\nCLE\ngridlength 2e-6\nnoabsorbed\niterations 2\ncellpackets %d\ntemperature %s/T.bin\nemitted %s/em.bin\nglobal %d\n"
              "bgpackets 400000\n" % (cloud.CELLS, d, d, cloud.CELLS))
     ini = _write_model(d, cloud, extra=extra)
     txt = open(ini).read().replace("nosolve\n", "").replace("absorbed %s/abs.data\n" % d, "")
