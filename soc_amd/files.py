@@ -22,8 +22,10 @@ def read_cloud(filename, kdensity=1.0, max_levels=999):
             raise FileError("%s: truncated cloud header" % filename)
         NX, NY, NZ, LEVELS, CELLS = [int(v) for v in hdr]
         if LEVELS > max_levels:
-            raise FileError("%s has %d levels; cutting hierarchies (keyword levels) is preprocessing that this "
-                            "engine does not do" % (filename, LEVELS))
+            # keyword `levels`: the hierarchy is cut, the new cloud written beside the old one and used (ASOC_aux.py:748-761)
+            newname = '%s.MAX%d' % (filename, max_levels)
+            cut_levels(filename, newname, max_levels - 1)
+            return read_cloud(newname, kdensity, max_levels)
         H = []
         for level in range(LEVELS):
             n = np.fromfile(fp, np.int32, 1)
@@ -40,6 +42,37 @@ def read_cloud(filename, kdensity=1.0, max_levels=999):
     if c.CELLS != CELLS:
         raise FileError("%s: header says %d cells, levels hold %d" % (filename, CELLS, c.CELLS))
     return c
+
+
+def cut_levels(infile, outfile, maxlevel):
+    """OT_cut_levels (ASOC_aux.py:651-713) with the AverageParent kernel (kernel_OT_tools.c:5-24) in numpy: levels above
+    ``maxlevel`` (0, 1, ...) are dropped, from the bottom up every parent (value <= 1e-9: a link) becomes a leaf with the
+    mean of its eight children -- the float32 sum in child order, divided by 8, as the kernel adds them."""
+    with open(infile, 'rb') as fp:
+        NX, NY, NZ, LEVELS, CELLS = [int(v) for v in np.fromfile(fp, np.int32, 5)]
+        H = []
+        for _ in range(LEVELS):
+            n = int(np.fromfile(fp, np.int32, 1)[0])
+            d = np.fromfile(fp, np.float32, n)
+            if d.size != n:
+                raise FileError("%s: truncated" % infile)
+            H.append(d)
+    maxlevel = min(LEVELS - 1, int(maxlevel))
+    for i in range(LEVELS - 2, maxlevel - 1, -1):
+        P, C = H[i], H[i + 1]
+        par = np.nonzero(~(P > np.float32(1.0e-9)))[0]
+        first = (-P[par]).view(np.int32).astype(np.int64)
+        if par.size and (first.min() < 0 or first.max() + 8 > C.size):
+            raise FileError("%s: level %d holds a link outside level %d" % (infile, i, i + 1))
+        f = np.zeros(par.size, np.float32)
+        for k in range(8):
+            f = f + C[first + k]
+        P[par] = f / np.float32(8.0)
+    with open(outfile, 'wb') as fp:
+        np.asarray([NX, NY, NZ, maxlevel + 1, sum(len(h) for h in H[:maxlevel + 1])], np.int32).tofile(fp)
+        for i in range(maxlevel + 1):
+            np.asarray([len(H[i])], np.int32).tofile(fp)
+            np.asarray(H[i], np.float32).tofile(fp)
 
 
 def read_dust(filenames, GL):

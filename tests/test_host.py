@@ -100,6 +100,39 @@ def test_launch_arithmetic_pins():
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(W - 1))
 
 
+def test_levels_keyword_cuts_the_hierarchy(tmp_path):
+    """`levels N` (ASOC_aux.py:748-761, OT_cut_levels :651-713, AverageParent kernel_OT_tools.c:5-24): a cloud with more
+    levels is cut from the bottom up, parents become leaves with the float32 mean of their eight children; the cut
+    cloud is written as <cloud>.MAX<N> and used"""
+    cloud = synth.octree_cloud(6, levels=4, frac=0.3, seed=5)
+    fn = str(tmp_path / "c.cloud")
+    cloud.write(fn)
+    cut = files.read_cloud(fn, max_levels=2)
+    assert os.path.exists(fn + ".MAX2") and cut.LEVELS == 2
+    assert np.array_equal(cut.LCELLS, cloud.LCELLS[:2]) and cut.CELLS == int(cloud.LCELLS[:2].sum())
+    # scalar restatement, bottom up
+    H = [np.array(cloud.DENS[cloud.OFF[l]:cloud.OFF[l] + cloud.LCELLS[l]]) for l in range(cloud.LEVELS)]
+    for i in (2, 1):
+        for j in range(len(H[i])):
+            if not (H[i][j] > np.float32(1e-9)):
+                k = int(np.float32(-H[i][j]).view(np.int32))
+                f = np.float32(0.0)
+                for c in H[i + 1][k:k + 8]:
+                    f = np.float32(f + c)
+                H[i][j] = np.float32(f / np.float32(8.0))
+    assert np.array_equal(cut.DENS.view(np.uint32), np.concatenate(H[:2]).view(np.uint32))
+    assert (cut.DENS[cut.OFF[1]:] > 0).all()                      # the last level holds leaves only
+    links = cut.DENS[:cut.OFF[1]] <= 0
+    assert np.array_equal(links, cloud.DENS[:cloud.OFF[1]] <= 0)  # root links stay
+    # mass is conserved to rounding: volume-weighted density
+    def mass(c):
+        return sum(float(np.sum(np.where(c.DENS[c.OFF[l]:c.OFF[l] + c.LCELLS[l]] > 0, c.DENS[c.OFF[l]:c.OFF[l] + c.LCELLS[l]], 0).astype(np.float64))) / 8.0 ** l
+                   for l in range(c.LEVELS))
+    assert abs(mass(cut) / mass(cloud) - 1) < 1e-6
+    same = files.read_cloud(fn, max_levels=4)
+    assert same.LEVELS == 4 and not os.path.exists(fn + ".MAX4")
+
+
 def test_cloud_file_round_trip(tmp_path):
     for cloud in (synth.cartesian_cloud(5, seed=1, NY=4, NZ=3), synth.octree_cloud(6, levels=3, frac=0.2, seed=2)):
         fn = str(tmp_path / "c.cloud")
