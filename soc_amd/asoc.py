@@ -43,7 +43,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
     if USER.WITH_REFERENCE and USER.SAVE_INTENSITY > 0:
         bad.append("saveint with the reference field (ASOC.py:994 asserts against it: the tallies hold differences)")
     if 'SUBITERATIONS' in USER.KEYS:
-        bad.append("SUBITERATIONS (sub-iterations of the reference field, ASOC.py:2261-2720)")
+        bad.append("SUBITERATIONS (sub-iterations of the reference field, ASOC.py:2261-2720; there the branch starts from "
+                   "`TOLD = 0.0*TNEW` with TNEW = None unless `loadtemp` is given, ASOC.py:700, :2282)")
     # keys the parser knows (soc_amd/ini.py keeps the reference's keyword set) whose effect is not built: refused, so that
     # an ini file using them stops here instead of finishing with products missing or different
     if 'nnmake' in USER.KEYS:
