@@ -300,6 +300,11 @@ int soc_set_cr_heating(soc_ctx *ctx, float rate);
  * test) leaves out the emission of cells on levels below `level`; they still absorb.  0 switches it off. */
 int soc_set_map_threshold(soc_ctx *ctx, int level);
 
+/* -D MAP_INTERPOLATION=<mode> (ini key mapint; ASOC.py:352,362; kernel_ASOC_map.c:656-810): soc_map (flat maps and the
+ * longitude x latitude image; HealpixMapping has no such block) blends the density and the emission of every cell on the
+ * ray with those of two neighbours across the ray; mode 2 also limits a step to 0.22 cells.  0 switches it off. */
+int soc_set_map_interpolation(soc_ctx *ctx, int mode);
+
 /* -D ROI_MAP=1 and the ROI argument of Mapping / HealpixMapping (ini key roimap with roi; ASOC.py:2941-2956,3126-3133;
  * kernel_ASOC_map.c:37-56,821-823,947-949): soc_map counts the emission of cells whose root cell lies inside
  * ROI = [x0,x1,y0,y1,z0,z1] (inclusive) only; extinction as usual.  NULL switches it off. */
@@ -329,8 +334,8 @@ int soc_emission(soc_ctx *ctx, int nfreq, const float *FREQ, const float *FABS, 
  * for one map.  healpix = 0: orthographic map of NPIX_X x NPIX_Y pixels of MAP_DX root cells towards DIR with image axes
  * RA (right), DE (up) through CENTRE -- or, with INTOBS given (INTOBS[0] > -1e10), the longitude x latitude image seen
  * from that position; healpix = 1: Healpix map of NSIDE = NPIX_X seen from INTOBS.  MAP gets the surface brightness
- * integral, SAVETAU the optical depth or (save_colden) column density x LENGTH.  MAP_INTERPOLATION, ROI_MAP,
- * LEVEL_THRESHOLD and polarisation maps are not covered. */
+ * integral, SAVETAU the optical depth or (save_colden) column density x LENGTH.  -D MAP_INTERPOLATION, ROI_MAP and
+ * LEVEL_THRESHOLD: soc_set_map_interpolation, soc_set_map_roi, soc_set_map_threshold.  Polarisation maps are not covered. */
 int soc_map(soc_ctx *ctx, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const float *EMIT, const float *DIR,
             const float *RA, const float *DE, const float *CENTRE, const float *INTOBS, float ABS, float SCA,
             int save_colden, float LENGTH, float *MAP, float *SAVETAU);

@@ -68,7 +68,8 @@ def build_oracle(force=False):
 def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0,
              USE_EMWEIGHT=0, SAVE_INTENSITY=0, NOABSORBED=1, WITH_MSF=0, NDUST=1, MIRROR=0,
              GL=0.01, HPBG_WEIGHTED=0, WITH_ALI=0, ROI_STEP=0, ROI_NSIDE=16, WITH_ROI_LOAD=0, WITH_ROI_SAVE=0,
-             STEP_WEIGHT=-1, SW_A=0.0, SW_B=0.0, DIR_WEIGHT=-1, DW_A=0.0, LEVEL_THRESHOLD=0, CR_HEATING=0.0, ROI_MAP=0):
+             STEP_WEIGHT=-1, SW_A=0.0, SW_B=0.0, DIR_WEIGHT=-1, DW_A=0.0, LEVEL_THRESHOLD=0, CR_HEATING=0.0, ROI_MAP=0,
+             MAP_INTERPOLATION=0):
     """The -D list of ASOC.py:344-362 (+ -D NSIDE=128, ASOC.py:396) for one model."""
     AREA = 2 * (NX * NY + NY * NZ + NZ * NX)
     d = dict(NX=NX, NY=NY, NZ=NZ, BINS=BINS, WITH_ALI=WITH_ALI, PS_METHOD=PS_METHOD, FACTOR="1.0000e+20f",
@@ -80,7 +81,7 @@ def ref_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_AB
              LEVEL_THRESHOLD=LEVEL_THRESHOLD, POLRED=0, p00="0.2000f", MINLOS="-1.000e+00f", MAXLOS="1.000e+10f",
              FFS=1, NODIR=1, USE_EMWEIGHT=USE_EMWEIGHT, SAVE_INTENSITY=SAVE_INTENSITY,
              NOABSORBED=NOABSORBED, INTERPOLATE=0, ADHOC="1.00000e+00f", HPBG_WEIGHTED=HPBG_WEIGHTED,
-             WITH_MSF=WITH_MSF, NDUST=NDUST, OPT_IS_HALF=0, POL_RHO_WEIGHT=0, MAP_INTERPOLATION=0,
+             WITH_MSF=WITH_MSF, NDUST=NDUST, OPT_IS_HALF=0, POL_RHO_WEIGHT=0, MAP_INTERPOLATION=MAP_INTERPOLATION,
              MIRROR=MIRROR, CR_HEATING=int(CR_HEATING > 0), CR_HEATING_RATE="%.3ef" % CR_HEATING, NVIDIA=0, NSIDE=128)
     return ["-D%s=%s" % (k, v) for k, v in d.items()]
 
@@ -229,6 +230,10 @@ def map_ref_models():
         "c208": dict(NX=208, NY=208, NZ=208, LEVELS=1, CELLS=208 ** 3),
         "oct8roi": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, ROI_MAP=1),
         "oct8thr": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, LEVEL_THRESHOLD=1),
+        "c8mi1": dict(NX=8, NY=8, NZ=8, LEVELS=1, CELLS=512, MAP_INTERPOLATION=1),
+        "oct8mi1": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, MAP_INTERPOLATION=1),
+        "oct8mi2": dict(NX=8, NY=8, NZ=8, LEVELS=oct8.LEVELS, CELLS=oct8.CELLS, MAP_INTERPOLATION=2),
+        "oct104mi2": dict(NX=104, NY=104, NZ=104, LEVELS=oct104.LEVELS, CELLS=oct104.CELLS, MAP_INTERPOLATION=2),
     }
 
 

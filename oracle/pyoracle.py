@@ -45,6 +45,7 @@ class OrcModel(C.Structure):
         ("MSF_NDUST", C.c_int), ("MSF_SCA", _F), ("ABU", _F),
         ("INTV", _F),
         ("LEVEL_THRESHOLD", C.c_int), ("ROI_MAP", C.c_int), ("CR_HEATING_RATE", C.c_float),
+        ("MAP_INTERPOLATION", C.c_int),
     ]
 
 
@@ -187,6 +188,7 @@ class Oracle:
         m.INTV = _fp(job.INTV) if job.INTV is not None else None
         m.LEVEL_THRESHOLD = int(getattr(job, "LEVEL_THRESHOLD", 0))
         m.CR_HEATING_RATE = float(getattr(job, "CR_HEATING_RATE", 0.0))
+        m.MAP_INTERPOLATION = int(getattr(job, "MAP_INTERPOLATION", 0))
         m.ROI_MAP = 0
         if getattr(job, "ROI_MAP", None) is not None:        # maps of the emission inside ROI = [x0,x1,y0,y1,z0,z1] only
             m.ROI_MAP = 1

@@ -133,6 +133,7 @@ typedef struct {
     int   LEVEL_THRESHOLD;            /* -D LEVEL_THRESHOLD: Mapping ignores the emission of coarser levels (kernel_ASOC_map.c:825-834) */
     int   ROI_MAP;                    /* -D ROI_MAP: the map kernels count the emission of cells inside ROI only (kernel_ASOC_map.c:821-823,947-949) */
     float CR_HEATING_RATE;            /* -D CR_HEATING=1 -D CR_HEATING_RATE: EqTemperature adds 1e-27*FACTOR*rate (kernel_ASOC_aux.c:769-773); 0 = off */
+    int   MAP_INTERPOLATION;          /* -D MAP_INTERPOLATION=1|2 (ini key mapint): Mapping blends density and emission with two neighbours (kernel_ASOC_map.c:656-810) */
 } orc_model;
 
 /* kernel_ASOC_sca.c:495-497,1486-1488 declare XPS_NSIDE and XPS_SIDE "__global float *" while
@@ -1508,7 +1509,28 @@ static int map_outside(const orc_model *M, f3 T)
     return (T.x < 0.0f) || (T.x > M->NX) || (T.y < 0.0f) || (T.y > M->NY) || (T.z < 0.0f) || (T.z > M->NZ);
 }
 
-/* Mapping (kernel_ASOC_map.c:496-888; MAP_INTERPOLATION 0, no ROI_MAP, no LEVEL_THRESHOLD): line-of-sight
+/* One neighbour of the MAP_INTERPOLATION block (kernel_ASOC_map.c:716-731, :771-788): from the middle of the step, the
+ * distance (in cell units) to the next cell along +V, else along -V (V is flipped for good), else "no neighbour". */
+static void map_neighbour(const orc_model *M, const float *EMIT, f3 POS0, f3 TMP, float w, int level0, int ind0, float K,
+                          f3 *V, float lim, int second_try_unscaled, float *dist, float *ndens, float *nemit)
+{
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int   slevel = level0, sind = ind0;
+        f3    MPOS;
+        float a;
+        if (attempt) { V->x *= -1.0f;  V->y *= -1.0f;  V->z *= -1.0f; }
+        MPOS.x = POS0.x + w * TMP.x;  MPOS.y = POS0.y + w * TMP.y;  MPOS.z = POS0.z + w * TMP.z;
+        a = GetStepMap(M, &MPOS, V, &slevel, &sind);
+        if (!(attempt && second_try_unscaled)) a /= K;        /* (:736 has no "b /= K" in the MAP_INTERPOLATION==2 block) */
+        if ((a <= lim) && (sind >= 0)) {
+            *dist = a;  *ndens = M->DENS[M->OFF[slevel] + sind];  *nemit = EMIT[M->OFF[slevel] + sind];
+            return;
+        }
+    }
+    *dist = 0.5f;  *ndens = 0.0f;  *nemit = 0.0f;
+}
+
+/* Mapping (kernel_ASOC_map.c:496-888, with -D MAP_INTERPOLATION, ROI_MAP and LEVEL_THRESHOLD as model fields): line-of-sight
  * integral of the emission with extinction for the pixels of an orthographic map, or of an all-sky
  * (longitude x latitude) image seen from INTOBS when INTOBS[0] > -1e10.  One call = all pixels.
  * mode 1: HealpixMapping (:890-970), NSIDE = NPIX_X, seen from INTOBS. */
@@ -1595,12 +1617,57 @@ __attribute__((visibility("default"))) void orc_mapping(const orc_model *M, int 
             if (fabsf(TMP.z) < 1.0e-5f) TMP.z = 1.0e-5f;
         }
         IndexG(M, &POS, &level, &ind);
+        const int MI = mode ? 0 : M->MAP_INTERPOLATION;      /* (Mapping only: HealpixMapping has no such block) */
+        f3 ADIR = { 0.0f, 0.0f, 0.0f }, BDIR = ADIR;
+        if (MI > 0) {                                        /* two directions perpendicular to the ray (:664-682) */
+            if (fabsf(TMP.x) > fabsf(TMP.y)) {
+                if (fabsf(TMP.z) > fabsf(TMP.x)) { ADIR.x = 0.0005f;  ADIR.y = 1.0f;  ADIR.z = -TMP.y / TMP.z; }
+                else                             { ADIR.x = -TMP.z / TMP.x;  ADIR.y = 0.0005f;  ADIR.z = 1.0f; }
+            } else {
+                if (fabsf(TMP.z) > fabsf(TMP.y)) { ADIR.x = 0.0005f;  ADIR.y = 1.0f;  ADIR.z = -TMP.y / TMP.z; }
+                else                             { ADIR.x = 1.0f;  ADIR.y = -TMP.x / TMP.y;  ADIR.z = 0.0005f; }
+            }
+            normalize3(&ADIR);
+            BDIR.x = TMP.y * ADIR.z - TMP.z * ADIR.y;
+            BDIR.y = TMP.z * ADIR.x - TMP.x * ADIR.z;
+            BDIR.z = TMP.x * ADIR.y - TMP.y * ADIR.x;
+            normalize3(&BDIR);
+        }
         while (ind >= 0) {
             const int olevel = level;
+            const f3  POS0 = POS;
+            const int ind0 = ind, level0 = level;
             oind = M->OFF[level] + ind;
             sx   = GetStepMap(M, &POS, &TMP, &level, &ind);
             dens = M->DENS[oind];
             emit = EMIT[oind];
+            if (MI > 0) {
+                const float K = ldexpf(1.0f, -level0);       /* local -> root-grid length */
+                float a, b, Adens, Bdens, Aemit, Bemit;
+                if (MI == 2) {                               /* steps of at most 0.22 cells (:709-715) */
+                    a = 0.22f * K;
+                    if (sx > a) {
+                        sx = a;
+                        POS.x = POS0.x + 0.22f * TMP.x;  POS.y = POS0.y + 0.22f * TMP.y;  POS.z = POS0.z + 0.22f * TMP.z;
+                        ind = ind0;  level = level0;
+                        if (M->NX > 100) IndexMap_d(M, &POS, &level, &ind);
+                        else             IndexMap_f(M, &POS, &level, &ind);
+                    }
+                }
+                const float w = 0.5f * sx / K;               /* to the middle of the step, local units */
+                map_neighbour(M, EMIT, POS0, TMP, w, level0, ind0, K, &ADIR, (MI == 2) ? 0.52f : 0.502f, 0, &a, &Adens, &Aemit);
+                map_neighbour(M, EMIT, POS0, TMP, w, level0, ind0, K, &BDIR, (MI == 2) ? 0.52f : 0.502f, MI == 2, &b, &Bdens, &Bemit);
+                if (MI == 2) {                               /* :746-751 */
+                    a = clampf(a, 0.0f, 0.51f);
+                    b = clampf(b, 0.0f, 0.51f);
+                    dens = (0.5f - a) * Adens + (0.5f - b) * Bdens + (a + b) * dens;
+                    emit = (0.5f - a) * Aemit + (0.5f - b) * Bemit + (a + b) * emit;
+                } else {                                     /* :806-808 */
+                    a = 0.5f - a;  b = 0.5f - b;
+                    dens = (1.0f - a - b) * dens + a * Adens + b * Bdens;
+                    emit = (1.0f - a - b) * emit + a * Aemit + b * Bemit;
+                }
+            }
             if (M->WITH_ABU) DTAU = sx * dens * (M->OPT[2 * (long)oind] + M->OPT[2 * (long)oind + 1]);
             else             DTAU = sx * dens * (M->SCA + M->ABS);
             if (M->ROI_MAP && (InRoi(M, olevel, oind - M->OFF[olevel]) < 0)) {

@@ -54,8 +54,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
     if USER.FAST_MAP >= 2:
         bad.append("mapping with a fourth argument >= 2 (FAST_MAP 2..998: kernel_ASOC_map_X.c, all frequencies per launch -- the reference's "
                    "own branch stops at ASOC.py:3553, a list compared with a float; >= 999: one map per hierarchy level, kernel_ASOC_map_H.c)")
-    if USER.MAP_INTERPOLATION > 0:
-        bad.append("mapint (interpolated map integration, kernel_ASOC_map.c:656-761)")
+    if USER.MAP_INTERPOLATION > 2 or USER.MAP_INTERPOLATION < 0:
+        bad.append("mapint other than 0, 1, 2 (kernel_ASOC_map.c:656-810 knows those: a larger value leaves Adens, Aemit ... unset there)")
     if len(USER.kernel_defs.strip()) > 0:
         bad.append("DEFS (extra -D options for the OpenCL compiler)")
     # accepted without effect, because they have none in the reference either: `interpolate` and `yshear` reach only the
@@ -171,6 +171,8 @@ class AbsorptionRun:
             e.set_map_roi(U.ROI if U.ROI_MAP else None)              # -D ROI_MAP (ASOC.py:345,354; :3126-3133)
         if U.LEVEL_THRESHOLD > 0 or hasattr(e, "set_map_threshold"):
             e.set_map_threshold(max(0, int(U.LEVEL_THRESHOLD)))      # -D LEVEL_THRESHOLD (ASOC.py:349,359)
+        if U.MAP_INTERPOLATION > 0 or hasattr(e, "set_map_interpolation"):
+            e.set_map_interpolation(int(U.MAP_INTERPOLATION))        # -D MAP_INTERPOLATION (ini key mapint; ASOC.py:352,362)
         if self.WITH_ABU:
             if U.OPT_IS_HALF or hasattr(e, "set_opt_half"):
                 e.set_opt_half(bool(U.OPT_IS_HALF))            # OPT as fp16 (ASOC.py:1158-1159)

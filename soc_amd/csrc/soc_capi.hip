@@ -45,6 +45,7 @@ struct soc_ctx {
     float *dABU = nullptr, *dAF = nullptr;        // abundances [CELLS, NDUST] (or [CELLS]), cross sections of the frequency
     int    abu_ndust = 0, abu_single = 0;
     int    map_level_threshold = 0;    // -D LEVEL_THRESHOLD (soc_set_map_threshold)
+    int    map_interpolation = 0;      // -D MAP_INTERPOLATION (soc_set_map_interpolation)
     int    map_roi_on = 0, map_roi[6] = { 0, 0, 0, 0, 0, 0 };   // -D ROI_MAP (soc_set_map_roi)
     float  cr_rate = 0.0f;             // -D CR_HEATING_RATE with -D CR_HEATING=1 (soc_set_cr_heating); 0 = off
     bool   opt_half = false;          // -D OPT_IS_HALF: OPT rounded through fp16 (soc_set_opt_half)
@@ -1487,6 +1488,14 @@ int soc_set_map_threshold(soc_ctx *c, int level)
     return SOC_OK;
 }
 
+int soc_set_map_interpolation(soc_ctx *c, int mode)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (mode < 0 || mode > 2) return fail(c, SOC_ERR_ARG, "soc_set_map_interpolation: mode %d (0, 1 or 2)", mode);
+    c->map_interpolation = mode;
+    return SOC_OK;
+}
+
 int soc_set_temperature(soc_ctx *c, const float *T)
 {
     if (!c) return SOC_ERR_ARG;
@@ -1564,6 +1573,7 @@ int soc_map(soc_ctx *c, int healpix, int NPIX_X, int NPIX_Y, float MAP_DX, const
     A.mode = healpix ? 1 : 0;
     A.NPIX_X = NPIX_X;  A.NPIX_Y = healpix ? 1 : NPIX_Y;  A.SAVE_COLDEN = save_colden;
     A.LEVEL_THRESHOLD = c->map_level_threshold;
+    A.MAPINT = healpix ? 0 : c->map_interpolation;
     A.ROI_MAP = c->map_roi_on;
     for (int k = 0; k < 6; k++) A.ROI[k] = c->map_roi[k];
     A.MAP_DX = MAP_DX;  A.ABS = ABS;  A.SCA = SCA;  A.LENGTH = LENGTH;

@@ -121,6 +121,7 @@ struct SocMapArgs {
     int   NPIX_X, NPIX_Y, SAVE_COLDEN;
     int   ROI_MAP, ROI[6];         // -D ROI_MAP: only the emission of cells inside ROI = [x0,x1,y0,y1,z0,z1] (root cells, inclusive)
     int   LEVEL_THRESHOLD;         // Mapping: no emission from levels below it (-D LEVEL_THRESHOLD, kernel_ASOC_map.c:825-834)
+    int   MAPINT;                  // Mapping: -D MAP_INTERPOLATION 0 | 1 | 2 (kernel_ASOC_map.c:656-810)
     float MAP_DX, ABS, SCA, LENGTH;
     float DIR[3], RA[3], DE[3], CENTRE[3], INTOBS[3];
     const float  *EMIT;

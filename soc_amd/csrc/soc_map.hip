@@ -8,7 +8,7 @@
 // "POS.z<=0.0") -- so after every step out of an octet the position is rebuilt from the root.  That
 // changes the last bits of positions and step lengths, hence of the maps; it is restated here as written
 // (soc_map_index) and pinned bit-exactly by the x86 build of the reference (oracle/_ref/refmap_*.so).
-// MAP_INTERPOLATION, ROI_MAP, LEVEL_THRESHOLD and the polarisation kernels are not covered.
+// -D MAP_INTERPOLATION, ROI_MAP and LEVEL_THRESHOLD are launch arguments here; the polarisation kernels are not covered.
 #include "soc_walk.h"
 
 #define SOC_MAP_PEPS 5.0e-4f
@@ -101,6 +101,26 @@ __device__ __forceinline__ bool soc_map_inroi(const SocGrid &G, const int *sOFF,
     return (i >= ROI[0]) && (i <= ROI[1]) && (j >= ROI[2]) && (j <= ROI[3]) && (k >= ROI[4]) && (k <= ROI[5]);
 }
 
+// One neighbour of the MAP_INTERPOLATION block (kernel_ASOC_map.c:716-731, :771-788): from the middle of the step the
+// distance (cell units) to the next cell along +V, else along -V (V stays flipped), else "none" (0.5, nothing to blend)
+template <bool OCT, bool DBL>
+__device__ __forceinline__ void soc_map_neighbour(const SocGrid &G, const int *sOFF, const float *EMIT, float p0x, float p0y, float p0z,
+                                                  float tx, float ty, float tz, float w, int level0, int ind0, float K,
+                                                  float &vx, float &vy, float &vz, float lim, bool second_try_unscaled,
+                                                  float &dist, float &ndens, float &nemit)
+{
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int   slevel = level0, sind = ind0;
+        float nd = 0.0f;
+        if (attempt) { vx = -vx;  vy = -vy;  vz = -vz; }
+        float mx = p0x + w * tx, my = p0y + w * ty, mz = p0z + w * tz;
+        float a = soc_map_getstep<OCT, DBL>(G, sOFF, mx, my, mz, vx, vy, vz, slevel, sind, nd);
+        if (!(attempt && second_try_unscaled)) a = a / K;                 // (:736 has no "b /= K" in the MAP_INTERPOLATION==2 block)
+        if ((a <= lim) && (sind >= 0)) { dist = a;  ndens = nd;  nemit = EMIT[sOFF[slevel] + sind];  return; }
+    }
+    dist = 0.5f;  ndens = 0.0f;  nemit = 0.0f;
+}
+
 template <bool OCT, bool DBL, bool ABU>
 __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const SocMapArgs A)
 {
@@ -185,12 +205,60 @@ __global__ __launch_bounds__(256) void soc_map_kernel(const SocGrid G, const Soc
     int   level = 0, ind = -1;
     float dens = 0.0f;
     soc_indexg<OCT>(G, sOFF, px, py, pz, level, ind, dens);
+    const int MI = A.MAPINT;
+    float adx = 0.0f, ady = 0.0f, adz = 0.0f, bdx = 0.0f, bdy = 0.0f, bdz = 0.0f;
+    if (MI > 0) {                                                         // two directions across the ray (:664-682)
+        if (soc_fabsf(tx) > soc_fabsf(ty)) {
+            if (soc_fabsf(tz) > soc_fabsf(tx)) { adx = 0.0005f;  ady = 1.0f;  adz = -ty / tz; }
+            else                               { adx = -tz / tx;  ady = 0.0005f;  adz = 1.0f; }
+        } else {
+            if (soc_fabsf(tz) > soc_fabsf(ty)) { adx = 0.0005f;  ady = 1.0f;  adz = -ty / tz; }
+            else                               { adx = 1.0f;  ady = -tx / ty;  adz = 0.0005f; }
+        }
+        soc_normalize(adx, ady, adz);
+        bdx = ty * adz - tz * ady;
+        bdy = tz * adx - tx * adz;
+        bdz = tx * ady - ty * adx;
+        soc_normalize(bdx, bdy, bdz);
+    }
     while (ind >= 0) {
         const int   oind = sOFF[level] + ind;
         const int   olevel = level;
-        const float d0 = dens;
-        const float sx = soc_map_getstep<OCT, DBL>(G, sOFF, px, py, pz, tx, ty, tz, level, ind, dens);
-        const float emit = A.EMIT[oind];
+        const float p0x = px, p0y = py, p0z = pz;
+        const int   ind0 = ind;
+        float d0 = dens;
+        float sx = soc_map_getstep<OCT, DBL>(G, sOFF, px, py, pz, tx, ty, tz, level, ind, dens);
+        float emit = A.EMIT[oind];
+        if (MI > 0) {
+            const float K = soc_scale_down(1.0f, olevel);                 // local -> root-grid length
+            float a, b, Ad, Bd, Ae, Be;
+            if (MI == 2) {                                                // steps of at most 0.22 cells (:709-715)
+                a = 0.22f * K;
+                if (sx > a) {
+                    sx = a;
+                    px = p0x + 0.22f * tx;  py = p0y + 0.22f * ty;  pz = p0z + 0.22f * tz;
+                    ind = ind0;  level = olevel;
+                    if (DBL) soc_map_index<OCT, double>(G, sOFF, px, py, pz, level, ind, dens);
+                    else     soc_map_index<OCT, float>(G, sOFF, px, py, pz, level, ind, dens);
+                }
+            }
+            const float w = 0.5f * sx / K;
+            const float lim = (MI == 2) ? 0.52f : 0.502f;
+            soc_map_neighbour<OCT, DBL>(G, sOFF, A.EMIT, p0x, p0y, p0z, tx, ty, tz, w, olevel, ind0, K, adx, ady, adz, lim, false, a, Ad, Ae);
+            soc_map_neighbour<OCT, DBL>(G, sOFF, A.EMIT, p0x, p0y, p0z, tx, ty, tz, w, olevel, ind0, K, bdx, bdy, bdz, lim, MI == 2, b, Bd, Be);
+            if (MI == 2) {                                                // :746-751
+                a = soc_clampf(a, 0.0f, 0.51f);
+                b = soc_clampf(b, 0.0f, 0.51f);
+                const float c0 = 0.5f - a, c1 = 0.5f - b, c2 = a + b;
+                emit = c0 * Ae + c1 * Be + c2 * emit;
+                d0   = c0 * Ad + c1 * Bd + c2 * d0;
+            } else {                                                      // :806-808
+                a = 0.5f - a;  b = 0.5f - b;
+                const float c2 = 1.0f - a - b;
+                emit = c2 * emit + a * Ae + b * Be;
+                d0   = c2 * d0 + a * Ad + b * Bd;
+            }
+        }
         float DTAU;
         if (ABU) { const float2 o = A.OPT[oind];  DTAU = sx * d0 * (o.x + o.y); }
         else     DTAU = sx * d0 * (A.SCA + A.ABS);

@@ -85,6 +85,7 @@ API = {
     "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
     "soc_set_cr_heating": (C.c_int, [C.c_void_p, C.c_float]),
     "soc_set_map_threshold": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_set_map_interpolation": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_map_roi": (C.c_int, [C.c_void_p, _I]),
     "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
@@ -264,6 +265,10 @@ class Engine:
     def set_cr_heating(self, rate):
         """-D CR_HEATING_RATE (with -D CR_HEATING=1): added to the absorbed energy in solve_temperature; 0 = off"""
         self._chk(self.lib.soc_set_cr_heating(self.h, float(rate)))
+
+    def set_map_interpolation(self, mode):
+        """-D MAP_INTERPOLATION (ini key mapint): 1 | 2 = flat maps blend every cell on the ray with two neighbours; 0 = off"""
+        self._chk(self.lib.soc_set_map_interpolation(self.h, int(mode)))
 
     def set_map_threshold(self, level):
         """-D LEVEL_THRESHOLD: flat maps leave out the emission of coarser levels; 0 = off"""

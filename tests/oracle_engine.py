@@ -196,6 +196,9 @@ class OracleEngine:
     def set_map_threshold(self, level):
         self.map_threshold = int(level)
 
+    def set_map_interpolation(self, mode):
+        self.map_interpolation = int(mode)
+
     def solve_temperature(self, adhoc, kE, Emin, TTT, FACTOR, LENGTH, EABS):
         job = Job(self.cloud, np.linspace(1, -1, 8))
         job.CR_HEATING_RATE = getattr(self, "cr_rate", 0.0)
@@ -212,6 +215,7 @@ class OracleEngine:
     def map(self, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, ABS, SCA, INTOBS=None, save_colden=0, LENGTH=1.0, healpix=0):
         job = Job(self.cloud, np.linspace(1, -1, 8), ABS=ABS, SCA=SCA, OPT=self.OPT)
         job.LEVEL_THRESHOLD = getattr(self, "map_threshold", 0)
+        job.MAP_INTERPOLATION = 0 if healpix else getattr(self, "map_interpolation", 0)
         job.ROI_MAP = getattr(self, "map_roi", None)
         io = NO_INTOBS if (INTOBS is None or INTOBS[0] < -1e10) else INTOBS
         m, t = oracle_mapping(self.orc, job, EMIT, DIR, RA, DE, NPIX, MAP_DX, CENTRE, io, save_colden, LENGTH, healpix)

@@ -221,7 +221,7 @@ def test_unsupported_options_fail_loudly(tmp_path):
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
     for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\nnnmake 1\n", "polmap bx by bz\n",
-                  "mapping 12 10 0.8 2\n", "mapint 1\n", "DEFS -D X=1\n",
+                  "mapping 12 10 0.8 2\n", "mapint 3\n", "DEFS -D X=1\n",
                   "reference 1\nsaveint 1\n"):
         with pytest.raises(UnsupportedOption):
             AbsorptionRun(User(_write_model(d, cloud, extra=extra)), OracleEngine("soc"))

@@ -35,6 +35,12 @@ MAP_CASES = {
     "map_oct8_roimap_healpix": ("oct8roi", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7),
                                 dict(roi=[2, 5, 1, 6, 3, 4], intobs=(4.2, 4.1, 3.9), healpix=8)),
     "map_oct8_threshold": ("oct8thr", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(threshold=1)),   # -D LEVEL_THRESHOLD=1
+    # -D MAP_INTERPOLATION=1|2 (ini key mapint): density and emission blended with two neighbours across the ray
+    "map_c8_mapint1": ("c8mi1", lambda: synth.cartesian_cloud(8, seed=3), dict(mapint=1)),
+    "map_oct8_mapint1": ("oct8mi1", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(mapint=1)),
+    "map_oct8_mapint2": ("oct8mi2", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(mapint=2)),
+    "map_oct8_mapint1_inside": ("oct8mi1", lambda: synth.octree_cloud(8, levels=3, frac=0.15, seed=7), dict(mapint=1, intobs=(4.2, 4.1, 3.9), npix=(16, 9))),
+    "map_oct104_mapint2_double": ("oct104mi2", lambda: synth.octree_cloud(104, levels=3, frac=0.002, seed=11), dict(mapint=2, npix=(12, 12), dx=8.0)),
     "map_oct104_double": ("oct104", lambda: synth.octree_cloud(104, levels=3, frac=0.002, seed=11), dict(npix=(24, 24), dx=4.0)),
     "map_c208_entry": ("c208", lambda: synth.cartesian_cloud(208, uniform=1.0), dict(npix=(10, 10), dx=20.0)),
 }
@@ -46,6 +52,7 @@ def run_case(name, mapper):
     cloud = mk()
     job = Job(cloud, CSC, ABS=1e-3, SCA=3e-3, OPT=_opt(cloud.CELLS) if kw.get("abu") else None)
     job.ROI_MAP = kw.get("roi")                             # `roimap`: only the emission of cells inside ROI
+    job.MAP_INTERPOLATION = kw.get("mapint", 0)             # `mapint` key
     job.LEVEL_THRESHOLD = kw.get("threshold", 0)            # `threshold` key: emission of coarser levels left out of the maps
     emit = np.where(cloud.DENS > 0, np.abs(cloud.DENS) * 1e-3 * np.random.default_rng(1).uniform(0.5, 2, cloud.CELLS), 0).astype(np.float32)
     c = (cloud.NX / 2, cloud.NY / 2, cloud.NZ / 2)
@@ -104,6 +111,17 @@ def test_map_files_of_the_driver(tmp_path):
     want, _ = oracle_mapping(Oracle("soc"), job, emit, OD2[0], RA2[0], DE2[0], (12, 10), 0.8, (3.0, 3.0, 3.0))
     maps = np.fromfile("map_dir_00.bin", np.float32, offset=8).reshape(3, 10, 12)
     assert np.array_equal(maps[i].ravel(), want)
+    # `mapint 1`: the same run with -D MAP_INTERPOLATION=1 (ASOC_aux.py:330, ASOC.py:352,362)
+    open(ini, "w").write(txt + "mapint 1\n")
+    os.remove(os.path.join(d, "em.bin"))
+    run2 = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0)
+    run2.run()
+    assert np.array_equal(run2.EMITTED, run.EMITTED)
+    job.MAP_INTERPOLATION = 1
+    want1, _ = oracle_mapping(Oracle("soc"), job, emit, OD2[0], RA2[0], DE2[0], (12, 10), 0.8, (3.0, 3.0, 3.0))
+    maps1 = np.fromfile("map_dir_00.bin", np.float32, offset=8).reshape(3, 10, 12)
+    assert np.array_equal(maps1[i].ravel(), want1) and not np.array_equal(want1, want)
+    assert abs(want1.sum() / want.sum() - 1) < 0.2           # a blend of neighbouring cells, not another quantity
 
 
 def test_fits_maps_and_column_density(tmp_path):
@@ -261,10 +279,12 @@ def test_map_hip_bit_identical_to_oracle(name, engine, oracle_soc):
         engine.set_cloud(job.cloud)
         engine.set_opt(job.OPT)
         engine.set_map_threshold(job.LEVEL_THRESHOLD)
+        engine.set_map_interpolation(job.MAP_INTERPOLATION)
         engine.set_map_roi(job.ROI_MAP)
         return engine.map(emit, d, r, e, npix, dx, c, job.ABS, job.SCA, INTOBS=io, save_colden=cd, LENGTH=LENGTH, healpix=hp)
     job, m, t = run_case(name, gpu)
     engine.set_map_threshold(0)
+    engine.set_map_interpolation(0)
     engine.set_map_roi(None)
     _, mo, to = run_case(name, lambda job, emit, d, r, e, npix, dx, c, io, cd, hp:
                          oracle_mapping(oracle_soc, job, emit, d, r, e, npix, dx, c, io, cd, LENGTH, hp))
