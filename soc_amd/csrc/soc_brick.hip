@@ -47,21 +47,24 @@
 
 // wave-level counters of the walk loop for experiments (-DSOC_BRICK_PROF): iterations, lanes stepping, arm executions
 #if defined(SOC_BRICK_PROF)
-__device__ unsigned long long g_soc_prof[16];
-#define SOC_PROF_DECL unsigned int prof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  unsigned long long tprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast_ = __builtin_readcyclecounter()
+__device__ unsigned long long g_soc_prof[24];
+#define SOC_PROF_DECL unsigned int prof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  unsigned long long tprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast_ = __builtin_readcyclecounter()
 #define SOC_PROF_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter();  tprof_[i] += t_ - tlast_;  tlast_ = t_; } while (0)
 #define SOC_PROF(i, n) do { prof_[i] += (unsigned int)(n); } while (0)           /* n is wave-uniform */
-#define SOC_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_soc_prof[i_], (unsigned long long)prof_[i_]); \
+#define SOC_DPROF(i, n) do { dprof_[i] += (unsigned int)(n); } while (0)         /* diagnostics of the lane-bound walk: [16..23] */
+#define SOC_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_soc_prof[16 + i_], (unsigned long long)dprof_[i_]); \
+                            if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_soc_prof[i_], (unsigned long long)prof_[i_]); \
                             if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_soc_prof[8 + i_], tprof_[i_]); } while (0)   /* [6] is counted per lane */
 extern "C" __attribute__((visibility("default"))) void soc_prof_read(unsigned long long *out, int reset)
 {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_soc_prof), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = { 0 };  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_soc_prof), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_soc_prof), sizeof(unsigned long long) * 24);
+    if (reset) { unsigned long long z[24] = { 0 };  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_soc_prof), z, sizeof(z)); }
 }
 #else
 #define SOC_PROF_DECL
 #define SOC_PROF_T(i) do { } while (0)
 #define SOC_PROF(i, n) do { } while (0)
+#define SOC_DPROF(i, n) do { } while (0)
 #define SOC_PROF_FLUSH do { } while (0)
 #endif
 #define SOC_BRICK_PMAX 4096      // upper bound of packets per workgroup chunk (walks that keep the chunk's ranks in LDS)
@@ -678,6 +681,10 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     while (true) {
         {
             SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
+            // where the idle lanes are: chunks with fewer than 4 / 16 packets per lane, and the end of a chunk (no lane of the wave has a packet waiting)
+            if (D.count < 4 * nthr)  { SOC_DPROF(0, 1);  SOC_DPROF(1, __popcll(__ballot(mode == SOC_BM_IDLE))); }
+            if (D.count < 16 * nthr) { SOC_DPROF(2, 1);  SOC_DPROF(3, __popcll(__ballot(mode == SOC_BM_IDLE))); }
+            if (__ballot(nhave | nnhave) == 0ull) { SOC_DPROF(4, 1);  SOC_DPROF(5, __popcll(__ballot(mode == SOC_BM_IDLE))); }
             // the end of the chunk: when no lane of the wave has a packet waiting and few still walk, those go back to
             // the brick's queue (between steps their state is complete) and continue in the next pass among a full wave
             if ((A.TAIL > 0) && (__ballot(nhave | nnhave) == 0ull)) {
@@ -697,11 +704,10 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed: no later use waits behind the stores below
                     if (have) {
                         SocPk2 *q = pk + wid;
-                        // the brick of the root cell a leaving packet goes to: one load + wait per entry of this arm.  (Loaded in
-                        // the block below, when the packet leaves, it made EVERY iteration wait for all loads in flight: the
-                        // branches that do not load must not overwrite a register with a load pending -- 19 % of the wave's
-                        // cycles, rocprof wave counters, profiles/)
-                        if (key < 0) key = qbase + A.rbrick[-1 - key];
+                        // (the brick of the root cell a leaving packet goes to -- key < 0: -1 - root cell -- is looked up after
+                        // the walk, for all packets of the chunk at once.  Loaded when the packet leaves, in the block below, it
+                        // made EVERY iteration wait for all loads in flight: 19 % of the wave's cycles, rocprof wave counters,
+                        // profiles/; loaded here, it made every entry of this arm wait one L2 latency)
                         soc_st4(&q->A, make_float4(px, py, pz, photons));
                         soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
                         q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
@@ -909,8 +915,11 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     }
     // every packet of the chunk: its queue -> its rank among the workgroup's packets for that queue (kept in posq
     // meanwhile; the barrier above made the workgroup's keyq stores visible to all its threads)
-    for (int j = threadIdx.x; j < D.count; j += nthr)
-        A.posq[D.start + j] = soc_qh_rank(sH, A.HS, (int)A.keyq[D.start + j], A.hist);
+    for (int j = threadIdx.x; j < D.count; j += nthr) {
+        int k = (int)A.keyq[D.start + j];
+        if (k < 0) { k = qbase + A.rbrick[-1 - k];  A.keyq[D.start + j] = (uint32_t)k; }      // a packet that left: root cell -> brick queue
+        A.posq[D.start + j] = soc_qh_rank(sH, A.HS, k, A.hist);
+    }
     __syncthreads();
     soc_qh_bases(sH, A.HS, NQ, A.hist);
     __syncthreads();

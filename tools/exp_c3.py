@@ -46,7 +46,7 @@ def main():
         L = soclib.load_library(os.environ["SOC_HIP_LIB"])
         if hasattr(L, "soc_prof_read"):
             prof = L.soc_prof_read
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 24)()
     eng = Engine(0)
     eng.set_cloud(cloud)
     eng.set_features(a.with_int, 0, 0)
@@ -98,6 +98,11 @@ def main():
                       "deferred Index every %.1f with %.1f lanes | wave cycles: swap %.1f %%, step %.1f %%, climb %.1f %%" % (
                           p[0], p[1] / max(p[0], 1), p[7] / max(p[0], 1), p[0] / max(p[4], 1), p[5] / max(p[4], 1),
                           p[0] / max(p[2], 1), p[3] / max(p[2], 1), 100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
+                if p[16] or p[18] or p[20]:
+                    print("   idle lanes by where: chunks < 4 packets per lane %.1f %% of the iterations with %.1f idle lanes; < 16 per lane %.1f %% with %.1f; "
+                          "end of a chunk (nothing prefetched in the wave) %.1f %% with %.1f" % (
+                              100 * p[16] / max(p[0], 1), p[17] / max(p[16], 1), 100 * p[18] / max(p[0], 1), p[19] / max(p[18], 1),
+                              100 * p[20] / max(p[0], 1), p[21] / max(p[20], 1)), flush=True)
                 print("   switch / exchange arm every %.1f iterations; wave cycles: switch / exchange %.1f %%, loop head %.1f %%, outcome %.1f %%" % (p[0] / max(p[6], 1), 100 * p[11] / tt, 100 * p[14] / tt, 100 * p[13] / tt), flush=True)
         eng.set_tuning(**reset)
     eng.close()
