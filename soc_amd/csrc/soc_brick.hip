@@ -827,40 +827,39 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
                         root = true;
                     }
+                    // one LDS read serves the move to a root cell and the move to a sibling (a wave has lanes of both kinds)
+                    int s2 = -1, qx = Rx, qy = Ry, qz = Rz;
                     if (root) {
                         const bool out = (level0 == 0) ? !((px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ))
                                                        : (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ));
                         const int rx = Rx - KB.x0, ry = Ry - KB.y0, rz = Rz - KB.z0;
-                        if (out) {
-                            r = SOC_LT_EXIT;
-                        } else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) {
-                            r = SOC_LT_LEAVE;
-                        } else {
-                            const int   s2 = (rz * KB.by + ry) * KB.bx + rx;
-                            const float rec = sD[s2];
-                            if (rec > 0.0f) {
-                                if (level0 == 1) {                            // up to the root grid: pos' = RN(pos/2 + octet origin/2)
-                                    px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
-                                    level = 0;  lsc = 1.0f;
-                                }
-                                slot = s2;  dens = rec;  cx = Rx;  cy = Ry;  cz = Rz;  r = SOC_LT_INSIDE;
-                            } else if (!A.lean_step && (level0 == 0)) {
-                                // one level down: octant and position from 2*fmod(pos,1), exact
-                                const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
-                                const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
-                                const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
-                                const float rec3 = sD[s3];
-                                if (rec3 > 0.0f) {
-                                    px = hx;  py = hy;  pz = hz;
-                                    level = 1;  lsc = 0.5f;
-                                    slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
-                                }
+                        if (out) r = SOC_LT_EXIT;
+                        else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) r = SOC_LT_LEAVE;
+                        else s2 = (rz * KB.by + ry) * KB.bx + rx;
+                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
+                        s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
+                        qx = (cx & ~1) + ix;  qy = (cy & ~1) + iy;  qz = (cz & ~1) + iz;
+                    }
+                    if (s2 >= 0) {
+                        const float rec = sD[s2];
+                        if (rec > 0.0f) {
+                            if (root && (level0 == 1)) {                      // up to the root grid: pos' = RN(pos/2 + octet origin/2)
+                                px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
+                                level = 0;  lsc = 1.0f;
+                            }
+                            slot = s2;  dens = rec;  cx = qx;  cy = qy;  cz = qz;  r = SOC_LT_INSIDE;
+                        } else if (root && !A.lean_step && (level0 == 0)) {
+                            // one level down: octant and position from 2*fmod(pos,1), exact
+                            const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
+                            const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
+                            const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
+                            const float rec3 = sD[s3];
+                            if (rec3 > 0.0f) {
+                                px = hx;  py = hy;  pz = hz;
+                                level = 1;  lsc = 0.5f;
+                                slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
                             }
                         }
-                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
-                        const int   s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
-                        const float rec = sD[s2];
-                        if (rec > 0.0f) { slot = s2;  dens = rec;  cx = (cx & ~1) + ix;  cy = (cy & ~1) + iy;  cz = (cz & ~1) + iz;  r = SOC_LT_INSIDE; }
                     }
                 }
                 if (r > SOC_LT_SLOW) mode = SOC_BM_CLIMB;
