@@ -310,6 +310,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st = eng.stats()
     passes = eng.last_passes()
+    form = eng.last_form()                       # of the timed sweeps (the launch-shape measurement below is a direct kernel)
 
     packets_rank = st["packets"]
     events_rank = st["tally_events"]
@@ -346,7 +347,6 @@ def main():
         kavg_s = kernel_ms * 1e-3 / max(args.steps, 1)
         alg_bytes = events_rank / max(args.steps, 1) * BYTES_PER_TALLY_EVENT
         achieved = alg_bytes / kavg_s / 1e9
-        form = eng.last_form()
         kname = {3: "soc_lbrick_pass<TABS-only> (brick-local hierarchies: soc_lbrick_walk + soc_brick_events)",
                  4: "soc_lbrick_pass<TABS-only> (brick-local hierarchies, packet pools: soc_lbrick_walk_pool + soc_brick_events)",
                  2: "soc_brick_pass<octree,scalar-opacity,TABS-only>", 1: "soc_brick_pass<Cartesian,scalar-opacity,TABS-only>"}.get(form, "soc_brick_pass")

@@ -98,6 +98,7 @@ struct SocBrickArgs {
     int T, P, KCAP, FTH;         // step-kernel threads, packets per chunk, max steps per packet per pass, fetch threshold
     int CTH;                     // lanes waiting for the deferred Index() before that arm is entered (hierarchies)
     int TAIL;                    // a wave with this many lanes out of work sends its last packets back to the queue (0: never)
+    int PARK;                    // brick queues shorter than this and than the mean brick queue are not walked this pass: their packets wait for company (0: never)
     SocPk2 *pk;
     const uint32_t *idq;         // current queue (ids sorted by brick)
     uint32_t *idq_next;
@@ -620,6 +621,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     SocDesc D = A.desc[bid];
     D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
     if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
+    const bool parked = __builtin_amdgcn_readfirstlane(D.pad) != 0;      // too few packets for a workgroup: they stay in the queue this pass (soc_brick_scan)
     const int BV = A.CAP;                                  // slots in LDS
     const int nthr = (int)blockDim.x;
     SocPk2 *pk = A.pk;
@@ -649,12 +651,13 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     KB.x0 = __builtin_amdgcn_readfirstlane(KB.x0);  KB.y0 = __builtin_amdgcn_readfirstlane(KB.y0);  KB.z0 = __builtin_amdgcn_readfirstlane(KB.z0);
     KB.bx = __builtin_amdgcn_readfirstlane(KB.bx);  KB.by = __builtin_amdgcn_readfirstlane(KB.by);  KB.bz = __builtin_amdgcn_readfirstlane(KB.bz);
     KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
-    {
+    if (!parked) {
         const float *src = A.btree + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
     }
     soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
+    if (parked) for (int j = threadIdx.x; j < D.count; j += nthr) A.keyq[D.start + j] = (uint32_t)D.brick;
     __syncthreads();
 
     const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
@@ -678,7 +681,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     unsigned int n_tally = 0;
     SOC_PROF_DECL;
 
-    while (true) {
+    while (!parked) {
         {
             SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
             // where the idle lanes are: chunks with fewer than 4 / 16 packets per lane, and the end of a chunk (no lane of the wave has a packet waiting)
@@ -900,7 +903,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     SOC_PROF_FLUSH;
     atomicAdd(&sCtl[1], (int)n_tally);
     __syncthreads();
-    {
+    if (!parked) {
         const int *cells = A.bcell + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
             const float v = sT[i];
@@ -2128,6 +2131,23 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         sSumD[tid] += vd;
         __syncthreads();
     }
+    // parking: a brick queue shorter than min(PARK, mean length of the non-empty brick queues) is not walked in the next
+    // pass -- its workgroup hands the packets back to the same queue, where they wait for company (a workgroup with a
+    // packet or less per lane runs until its longest visit ends with most lanes idle).  Queues of at least the mean
+    // length always exist, so every pass walks; the event queues never wait.
+    int park = 0;
+    if (A.PARK > 0) {
+        __shared__ int sCnt[1024], sTot[1024];
+        int n1 = 0, t1 = 0;
+        for (int b = b0; b < b1; b++) if (b < A.ev_brick) { const int c = A.hist[b];  if (c > 0) { n1++;  t1 += c; } }
+        sCnt[tid] = n1;  sTot[tid] = t1;
+        __syncthreads();
+        for (int d = 512; d > 0; d >>= 1) {
+            if (tid < d) { sCnt[tid] += sCnt[tid + d];  sTot[tid] += sTot[tid + d]; }
+            __syncthreads();
+        }
+        park = (sCnt[0] > 0) ? min(A.PARK, sTot[0] / sCnt[0]) : 0;
+    }
     int off = sSum[tid] - s, offd = sSumD[tid] - sd;
     for (int b = b0; b < b1; b++) {
         const int c = A.hist[b];
@@ -2143,7 +2163,7 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
             d.brick = b;
             d.start = o;
             d.count = c / nk + (k < c % nk ? 1 : 0);
-            d.pad = 0;
+            d.pad = ((b < A.ev_brick) && (c < park)) ? 1 : 0;
             o += d.count;
             A.desc_next[offd++] = d;
         }
@@ -2460,6 +2480,9 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.CTH = (tune.CTH > 0) ? tune.CTH : 8;
             if (tune.pool > 0) { A.FTH = (tune.FTH > 0) ? tune.FTH : 4;  A.CTH = (tune.CTH > 0) ? tune.CTH : 16; }   // exchange threshold, low-water mark
             A.TAIL = (tune.TAIL > 0) ? tune.TAIL : 0;
+            // short brick queues wait (soc_brick_scan): 4096 = 8 packets per lane, measured on config 3 (1024 ... 16384; +5 % point source,
+            // +9 % diffuse emission against no parking); soc_set_tuning("park_below", 1) = never
+            A.PARK = (A.pool || A.spool) ? 0 : ((tune.park > 0) ? tune.park : 4096);
         } else if (e != hipErrorNotSupported) {
             return e;
         }

@@ -391,7 +391,7 @@ int soc_set_tuning(soc_ctx *c, const char *name, int value)
     if (value < 0) return fail(c, SOC_ERR_ARG, "soc_set_tuning: %s = %d (0 = built-in choice)", name, value);
     struct { const char *n; int *p; } tab[] = {
         { "threads", &c->tune.T }, { "chunk", &c->tune.P }, { "steps_per_visit", &c->tune.KCAP }, { "swap_lanes", &c->tune.FTH },
-        { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "population", &c->tune.POP },
+        { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "park_below", &c->tune.park }, { "population", &c->tune.POP },
         { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every }, { "lean_step", &c->tune.lean_step }, { "pool_slots", &c->tune.pool }, { "shared_pool", &c->tune.spool },
         { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
     for (auto &t : tab)

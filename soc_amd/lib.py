@@ -224,7 +224,7 @@ class Engine:
 
     def set_tuning(self, **params):
         """shape of the brick sweep (soc_set_tuning): threads, chunk, steps_per_visit, swap_lanes, climb_lanes,
-        brick_cells, tail_lanes, population, hash_slots, general_kernel, oversubscribe, verbose; 0 = built-in"""
+        brick_cells, tail_lanes, park_below, population, hash_slots, general_kernel, oversubscribe, verbose; 0 = built-in"""
         for k, v in params.items():
             self._chk(self.lib.soc_set_tuning(self.h, k.encode(), int(v)))
 
