@@ -37,6 +37,7 @@
 
 #include <cstdio>
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -2625,6 +2626,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     soc_brick2_init<<<(max(count, (uint32_t)NQ) + 255) / 256, 256, 0, st>>>(bb.pack, A, count, bb.idq[0], bb.desc[0], bb.ndesc, bb.hist);
     BCHK(hipGetLastError());
     int passes = 0, total = 1;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
     while (total > 0) {
         for (int k = 0; k < 64; k++, passes++) {
             const int c = k & 1;
@@ -2644,6 +2647,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         BCHK(hipGetLastError());
         BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
+        if (tune.verbose > 1) {                                       // the course of a sweep: packets in the queues every 64 passes
+            const auto t_now = std::chrono::steady_clock::now();
+            fprintf(stderr, "soc_brick: pass %6d  packets in queues %10d  %8.2f ms per pass\n", passes, total,
+                    std::chrono::duration<double, std::milli>(t_now - t_last).count() / 64.0);
+            t_last = t_now;
+        }
         if (passes > 4000000) return hipErrorUnknown;                 // cannot happen: every pass retires work
     }
     if (passes_out) *passes_out = passes;

@@ -54,7 +54,7 @@ def main():
     for ts in (a.tunes or ["{}"]):
         tune = json.loads(ts)
         reset = {k: 0 for k in tune}
-        eng.set_tuning(verbose=1, **tune)
+        eng.set_tuning(**dict(dict(verbose=1), **tune))
         for rep in range(2):
             eng.zero(0)
             eng.stats(reset=True)
