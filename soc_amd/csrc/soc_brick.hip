@@ -661,8 +661,19 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     if (parked) for (int j = threadIdx.x; j < D.count; j += nthr) A.keyq[D.start + j] = (uint32_t)D.brick;
     __syncthreads();
 
-    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
-    const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
+    // Uniform values the loop needs now and then.  Left as plain kernel arguments the compiler, out of scalar registers,
+    // re-reads them from the argument segment where they are used -- an s_load and a wait for it (and for every LDS
+    // operation in flight) in the step arm and, for first[], one per launch in the swap arm.  Made opaque here they are
+    // values it has to keep: in scalar registers or in lanes of a spill VGPR (v_readlane, no memory).
+    int   NX = G.NX, NY = G.NY, NZ = G.NZ;
+    float thr1 = A.lt_thr[1];
+    asm volatile("" : "+s"(NX), "+s"(NY), "+s"(NZ), "+s"(thr1));
+    uint32_t *keyq_c = A.keyq + D.start;                  // this chunk's part of the queue arrays
+    const uint32_t *idq_c = A.idq + D.start;
+    asm volatile("" : "+s"(pk), "+s"(keyq_c), "+s"(idq_c));
+    const float fNX = (float)NX, fNY = (float)NY, fNZ = (float)NZ;
+    // lane j of firstv holds the first work item of launch j: the launch of a packet is found with v_readlane + compare
+    const uint32_t firstv = sFirst[min((int)(threadIdx.x & 63), SOC_MAXLAUNCH)];
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
@@ -716,7 +727,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
                         q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
                         q->D.w = dw;
-                        SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + cslot]);    // its rank in that queue is settled after the walk, for all packets at once
+                        SOC_NT_STORE((uint32_t)key, &keyq_c[cslot]);              // its rank in that queue is settled after the walk, for all packets at once
                     }
                     // the prefetched packet becomes the current one
                     have = nhave;
@@ -731,7 +742,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         level = (int)(dz >> 29);
                         lsc = soc_lt_pow2(-level);
                         lq = 0;                                                   // the launch of the work item (first[] is a kernel argument: scalar compares)
-                        for (int j = 1; j < nl; j++) lq += (wid >= A.first[j]) ? 1 : 0;
+                        for (int j = 1; j < nl; j++) lq += (wid >= (uint32_t)__builtin_amdgcn_readlane((int)firstv, j)) ? 1 : 0;
                         kabs = sL[3 * lq];  ksca = sL[3 * lq + 1];  tw = sL[3 * lq + 2];
                         nvisit = 0;
                         mode = SOC_BM_STEP;
@@ -775,7 +786,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         nnslot = __builtin_amdgcn_readfirstlane(base) + rank;
                     }
                     nnhave = nnslot < D.count;
-                    if (nnhave) nnwid = SOC_NT_LOAD(&A.idq[D.start + nnslot]);
+                    if (nnhave) nnwid = SOC_NT_LOAD(&idq_c[nnslot]);
                     if (!have) mode = (nhave | nnhave) ? SOC_BM_SWAP : SOC_BM_IDLE;      // (the first two turns of a lane only reserve)
                 }
             }
@@ -827,7 +838,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     const bool  sib = (level0 > 0) && (((ix | iy | iz) & ~1) == 0);
                     bool root = (level0 == 0);
                     Rx = ix;  Ry = iy;  Rz = iz;
-                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, A.lt_thr[1])) {
+                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, thr1)) {
                         Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
                         root = true;
                     }
