@@ -369,6 +369,16 @@ int soc_a2e_eqtemp(soc_ctx *ctx, int batch, int icell, int CELLS, int NFREQ, int
                    float oplgkE, float Emin, const float *FREQ, const float *KABS, const float *TTT,
                    const float *ABS, float *T, float *EMIT);
 
+/* What A2E_pre.py computes per grain size for a <dust>.solver file (A2E_pre.py:233-256; kernel_A2E_pre.c:580-736
+ * PrepareIntegrationWeightsTrapezoid, :123-212 PrepareTdown; -D FACTOR of A2E_pre.py:134 is an argument).
+ * In:  FREQ[NFREQ], Ef[NFREQ] = PLANCK*FREQ, SKABS[NFREQ] = pi a^2 Q_abs of ONE grain of this size, the enthalpy grid E[NE+1]
+ *      with its temperatures T[NE+1].
+ * Out: L1, L2[NE*NE] (first and last frequency feeding the transition l -> u at [l*NE+u]; -1, -2 = none; entries with
+ *      u <= l are 0 -- the caller sets [0] = -2 as A2E_pre.py:246,249 does), Iw[NE*NE*NFREQ] (the weights of lower bin l
+ *      start at l*NE*NFREQ, noIw[l] of them: the file holds them back to back), noIw[NE-1], Tdown[NE]. */
+int soc_a2e_pre(soc_ctx *ctx, int NFREQ, int NE, float FACTOR, const float *FREQ, const float *Ef, const float *SKABS,
+                const float *E, const float *T, int32_t *L1, int32_t *L2, float *Iw, int32_t *noIw, float *Tdown);
+
 /* ---- equilibrium dust components of a multi-dust run: A2E_MABU.py / kernel_eqsolver.c ---- */
 
 /* replaces kernel_T(...) + the per-frequency kernel_emission(...) launches of SolveEquilibriumDust for one batch of cells

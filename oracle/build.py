@@ -145,6 +145,29 @@ def build_ref_a2e(tag, NE, NFREQ, LOCAL, CELLS, NIP=5000, force=False):
     return so
 
 
+def build_ref_a2e_pre(force=False):
+    """kernel_A2E_pre.c (PrepareIntegrationWeightsTrapezoid, PrepareTdown) -> oracle/_ref/refa2epre.so.
+    -D list: A2E_pre.py:134 (FACTOR only; NE and NFREQ are kernel arguments)."""
+    so = os.path.join(REF_DIR, "refa2epre.so")
+    ksrc = os.path.join(REFERENCE, "kernel_A2E_pre.c")
+    if not os.path.exists(ksrc):
+        return so if os.path.exists(so) else None
+    os.makedirs(REF_DIR, exist_ok=True)
+    drv = os.path.join(HERE, "ref_a2e_pre.cpp")
+    if not force and _newer(so, [drv, os.path.join(HERE, "ref_builtins.inc"), os.path.abspath(__file__), ksrc]):
+        return so
+    kobj = os.path.join(REF_DIR, "ka2epre.%d.o" % os.getpid())
+    sobj = os.path.join(REF_DIR, "da2epre.%d.o" % os.getpid())
+    common = ["-O2", "-fPIC", "-ffp-contract=off", "-target", "x86_64-unknown-linux-gnu"]
+    subprocess.check_call([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
+                           "-w", "-I", REFERENCE] + common + ["-DFACTOR=1.0000e+20f", "-c", ksrc, "-o", kobj])
+    subprocess.check_call([CLANG + "++", "-std=c++17", "-w"] + common + ["-c", drv, "-o", sobj])
+    _link_atomically([CLANG + "++", "-shared", "-Wl,-z,defs", kobj, sobj, "-lm", "-lpthread"], so)
+    os.remove(kobj)
+    os.remove(sobj)
+    return so
+
+
 def sca_defs(NX, NY, NZ, LEVELS, CELLS, BINS=2500, PS_METHOD=0, NO_PS=1, WITH_ABU=0, USE_EMWEIGHT=0, FFS=1, GL=0.01,
              MIRROR=0, HPBG_WEIGHTED=0, WITH_MSF=0, NDUST=1):
     """The -D list of ASOCS.py:133-147 for one model."""
@@ -326,6 +349,7 @@ def build_all_refs(force=False):
         out["a2e_" + tag] = build_ref_a2e(tag, force=force, **model)
     for tag, model in sca_ref_models().items():
         out["sca_" + tag] = build_ref_sca(tag, force=force, **model)
+    out["a2e_pre"] = build_ref_a2e_pre(force=force)
     return out
 
 

@@ -512,6 +512,54 @@ def oracle_eqsolver(orc, icell, CELLS, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS,
     return T, E
 
 
+def a2e_oracle_pre(orc, FREQ, Ef, SKABS, E, T, FACTOR):
+    """oracle restatement of the two kernels A2E_pre.py runs per grain size; same return value as Engine.a2e_pre"""
+    L = orc.lib
+    FREQ, Ef, SKABS = (np.ascontiguousarray(a, np.float32) for a in (FREQ, Ef, SKABS))
+    E, T = np.ascontiguousarray(E, np.float32), np.ascontiguousarray(T, np.float32)
+    NFREQ, NE = FREQ.size, E.size - 1
+    L.orc_a2e_pre_weights.argtypes = [C.c_int, C.c_int, C.c_float, _F, _F, _I, _I, _F, _F, _I]
+    L.orc_a2e_pre_tdown.argtypes = [C.c_int, _F, _F, _F, C.c_int, _F, _F, _F]
+    L.orc_a2e_pre_weights.restype = None
+    L.orc_a2e_pre_tdown.restype = None
+    L1, L2 = np.zeros(NE * NE, np.int32), np.zeros(NE * NE, np.int32)
+    Iw, noIw, Tdown = np.zeros(NE * NE * NFREQ, np.float32), np.zeros(NE - 1, np.int32), np.zeros(NE, np.float32)
+    wrk = np.zeros(NE * NFREQ, np.float32)
+    L.orc_a2e_pre_weights(NFREQ, NE, np.float32(FACTOR), _fp(Ef), _fp(E), _ip(L1), _ip(L2), _fp(Iw), _fp(wrk), _ip(noIw))
+    L.orc_a2e_pre_tdown(NFREQ, _fp(FREQ), _fp(Ef), _fp(SKABS), NE, _fp(E), _fp(T), _fp(Tdown))
+    packed = np.concatenate([Iw[l * NE * NFREQ:l * NE * NFREQ + noIw[l]] for l in range(NE - 1)])
+    L1[0] = -2
+    L2[0] = -2
+    return dict(Iw=packed, L1=L1, L2=L2, Tdown=Tdown, noIw=noIw)
+
+
+class RefA2EPre:
+    """x86 build of kernel_A2E_pre.c (FACTOR = 1e20): oracle/_ref/refa2epre.so"""
+
+    def __init__(self):
+        path = _build.build_ref_a2e_pre()
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("reference build of kernel_A2E_pre.c not available")
+        self.lib = C.CDLL(path)
+        self.lib.ref_pre_weights.argtypes = [C.c_int, C.c_int, C.c_int, _F, _F, _I, _I, _F, _F, _I]
+        self.lib.ref_pre_tdown.argtypes = [C.c_int, C.c_int, _F, _F, _F, C.c_int, _F, _F, _F]
+
+    def pre(self, FREQ, Ef, SKABS, E, T):
+        FREQ, Ef, SKABS = (np.ascontiguousarray(a, np.float32) for a in (FREQ, Ef, SKABS))
+        E, T = np.ascontiguousarray(E, np.float32), np.ascontiguousarray(T, np.float32)
+        NFREQ, NE = FREQ.size, E.size - 1
+        GLOBAL = int((NE / 64) + 1) * 64                                     # A2E_pre.py:47
+        L1, L2 = np.zeros(NE * NE, np.int32), np.zeros(NE * NE, np.int32)
+        Iw, noIw, Tdown = np.zeros(NE * NE * NFREQ, np.float32), np.zeros(NE - 1, np.int32), np.zeros(NE, np.float32)
+        wrk = np.zeros(NE * NFREQ + NE * (NFREQ + 4), np.float32)
+        self.lib.ref_pre_weights(GLOBAL, NFREQ, NE, _fp(Ef), _fp(E), _ip(L1), _ip(L2), _fp(Iw), _fp(wrk), _ip(noIw))
+        self.lib.ref_pre_tdown(GLOBAL, NFREQ, _fp(FREQ), _fp(Ef), _fp(SKABS), NE, _fp(E), _fp(T), _fp(Tdown))
+        packed = np.concatenate([Iw[l * NE * NFREQ:l * NE * NFREQ + noIw[l]] for l in range(NE - 1)])
+        L1[0] = -2
+        L2[0] = -2
+        return dict(Iw=packed, L1=L1, L2=L2, Tdown=Tdown, noIw=noIw)
+
+
 class RefA2E:
     """x86 build of kernel_A2E.c for one (NE, NFREQ, LOCAL, CELLS, NIP): oracle/_ref/refa2e_<tag>.so"""
 

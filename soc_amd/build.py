@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsoc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["soc_kernels.hip", "soc_brick.hip", "soc_a2e.hip", "soc_sca.hip", "soc_emit.hip", "soc_map.hip", "soc_capi.hip"]
+SOURCES = ["soc_kernels.hip", "soc_brick.hip", "soc_a2e.hip", "soc_a2e_pre.hip", "soc_sca.hip", "soc_emit.hip", "soc_map.hip", "soc_capi.hip"]
 HEADERS = ["soc_dev.h", "soc_math.h", "soc_rng.h", "soc_walk.h", "soc_ltree.h", "soc_lbricks.h", "soc_octbricks.h", os.path.join("..", "..", "include", "soc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

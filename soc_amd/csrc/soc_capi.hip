@@ -1769,6 +1769,52 @@ int soc_eqsolver(soc_ctx *c, int batch, int icell, int CELLS, int NFREQ, int NE,
     return eqtemp_common(c, "soc_eqsolver", true, batch, icell, CELLS, NFREQ, NE, FACTOR, kE, oplgkE, Emin, FREQ, KABS, TTT, ABS, T, EMIT);
 }
 
+int soc_a2e_pre(soc_ctx *c, int NFREQ, int NE, float FACTOR, const float *FREQ, const float *Ef, const float *SKABS, const float *E,
+                const float *T, int32_t *L1, int32_t *L2, float *Iw, int32_t *noIw, float *Tdown)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (NFREQ < 2 || NE < 2 || NE > 4096 || !FREQ || !Ef || !SKABS || !E || !T || !L1 || !L2 || !Iw || !noIw || !Tdown)
+        return fail(c, SOC_ERR_ARG, "soc_a2e_pre: NFREQ %d, NE %d or a NULL array", NFREQ, NE);
+    for (int i = 1; i < NFREQ; i++)
+        if (!(FREQ[i] > FREQ[i - 1]) || !(Ef[i] > Ef[i - 1])) return fail(c, SOC_ERR_ARG, "soc_a2e_pre: FREQ, Ef must increase (entry %d)", i);
+    for (int i = 1; i <= NE; i++)
+        if (!(E[i] > E[i - 1])) return fail(c, SOC_ERR_ARG, "soc_a2e_pre: the enthalpy grid E[NE+1] must increase (entry %d)", i);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nIw = (size_t)NE * NE * NFREQ, nW = (size_t)NE * NFREQ;
+    float *d = nullptr, *dIw = nullptr;
+    int   *dL = nullptr;
+    // one block of floats: FREQ | Ef | SKABS (NFREQ each) | E | T (NE+1 each) | Tdown (NE) | wrk (NE*NFREQ)
+    const size_t nf = 3 * (size_t)NFREQ + 2 * (size_t)(NE + 1) + NE + nW;
+    hipError_t e = hipMalloc((void **)&d, nf * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dIw, nIw * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dL, (2 * (size_t)NE * NE + NE) * 4);
+    if (e == hipSuccess) {
+        float *dF = d, *dEf = dF + NFREQ, *dSK = dEf + NFREQ, *dE = dSK + NFREQ, *dT = dE + NE + 1, *dTd = dT + NE + 1, *dW = dTd + NE;
+        int *dL1 = dL, *dL2 = dL1 + (size_t)NE * NE, *dN = dL2 + (size_t)NE * NE;
+        e = hipMemcpyAsync(dF, FREQ, (size_t)NFREQ * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dEf, Ef, (size_t)NFREQ * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dSK, SKABS, (size_t)NFREQ * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dE, E, (size_t)(NE + 1) * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dT, T, (size_t)(NE + 1) * 4, hipMemcpyHostToDevice, c->stream);
+        // entries the kernels do not write (pairs with u <= l, the unused tail of Iw) are 0 here; the reference leaves them to chance
+        if (e == hipSuccess) e = hipMemsetAsync(dL, 0, (2 * (size_t)NE * NE + NE) * 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dIw, 0, nIw * 4, c->stream);
+        if (e == hipSuccess) e = soc_launch_a2e_pre(NFREQ, NE, FACTOR, dF, dEf, dSK, dE, dT, dL1, dL2, dIw, dW, dN, dTd, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(L1, dL1, (size_t)NE * NE * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(L2, dL2, (size_t)NE * NE * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(noIw, dN, (size_t)(NE - 1) * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(Iw, dIw, nIw * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(Tdown, dTd, (size_t)NE * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d);
+    (void)hipFree(dIw);
+    (void)hipFree(dL);
+    if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "soc_a2e_pre: %s", hipGetErrorString(e));
+    return SOC_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // probes
 // ---------------------------------------------------------------------------------------

@@ -111,6 +111,10 @@ hipError_t soc_launch_eqtemp(const SocGrid &G, float adhoc, float kE, float Emin
 hipError_t soc_launch_emission(int c0, int c1, int nfreq, float FACTOR, float LENGTH, const float *FREQ, const float *FABS,
                                const float *T, float *EMIT, hipStream_t st);
 
+// solver-file preprocessing (soc_a2e_pre.hip): integration weights and cooling rates of one grain size
+hipError_t soc_launch_a2e_pre(int NFREQ, int NE, float FACTOR, const float *FREQ, const float *Ef, const float *SKABS, const float *E, const float *T,
+                              int *L1, int *L2, float *IW, float *wrk, int *noIw, float *Tdown, hipStream_t st);
+
 // OPT from abundances on the device (soc_emit.hip)
 hipError_t soc_launch_opt(int cells, int ndust, int single, const float *ABU, const float *AF, float2 *OPT, hipStream_t st);
 hipError_t soc_launch_opt_half(int cells, float2 *OPT, hipStream_t st);

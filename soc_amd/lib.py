@@ -86,6 +86,7 @@ API = {
     "soc_set_cr_heating": (C.c_int, [C.c_void_p, C.c_float]),
     "soc_set_map_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_map_interpolation": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_a2e_pre": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, _F, _F, _F, _F, _F, _I, _I, _F, _I, _F]),
     "soc_set_map_roi": (C.c_int, [C.c_void_p, _I]),
     "soc_set_temperature": (C.c_int, [C.c_void_p, _F]),
     "soc_emission": (C.c_int, [C.c_void_p, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
@@ -568,6 +569,23 @@ class Engine:
         return float(ms.value)
 
     # ---- A2E ----
+    def a2e_pre(self, FREQ, Ef, SKABS, E, T, FACTOR):
+        """One grain size of a solver file (A2E_pre.py:233-256): integration weights and cooling rates on the enthalpy grid
+        E[NE+1] (temperatures T[NE+1]); SKABS = pi a^2 Q_abs per grain.  Returns dict(Iw (packed as in the file), L1, L2, Tdown)."""
+        FREQ, Ef, SKABS = (np.ascontiguousarray(a, np.float32) for a in (FREQ, Ef, SKABS))
+        E, T = np.ascontiguousarray(E, np.float32), np.ascontiguousarray(T, np.float32)
+        NFREQ, NE = FREQ.size, E.size - 1
+        if Ef.size != NFREQ or SKABS.size != NFREQ or T.size != NE + 1:
+            raise SocError("a2e_pre: Ef, SKABS must hold NFREQ floats, E and T NE+1")
+        L1, L2 = np.zeros(NE * NE, np.int32), np.zeros(NE * NE, np.int32)
+        Iw, noIw, Tdown = np.zeros(NE * NE * NFREQ, np.float32), np.zeros(NE - 1, np.int32), np.zeros(NE, np.float32)
+        self._chk(self.lib.soc_a2e_pre(self.h, int(NFREQ), int(NE), np.float32(FACTOR), _f(FREQ), _f(Ef), _f(SKABS), _f(E), _f(T),
+                                       _i(L1), _i(L2), _f(Iw), _i(noIw), _f(Tdown)))
+        packed = np.concatenate([Iw[l * NE * NFREQ:l * NE * NFREQ + noIw[l]] for l in range(NE - 1)]) if NE > 1 else Iw[:0]
+        L1[0] = -2                                         # A2E_pre.py:246, :249
+        L2[0] = -2
+        return dict(Iw=packed, L1=L1, L2=L2, Tdown=Tdown, noIw=noIw)
+
     def a2e_set_size(self, NE, NFREQ, size, AF):
         """size: dict with Iw, L1, L2, Tdown, EA, Ibeg of one grain size (solver file)."""
         a = {k: np.ascontiguousarray(size[k], t) for k, t in (("Iw", np.float32), ("L1", np.int32), ("L2", np.int32),

@@ -130,6 +130,36 @@ def a2e_main():
     print("a2e golden: T range", T.min(), T.max())
 
 
+def a2e_pre_cases():
+    """Inputs of the solver-preprocessing golden cases (shared with tests/test_a2e_pre.py): (FREQ, Ef, SKABS per grain, E, T)
+    of one grain size of soc_amd.a2e_pre.AnalyticDust on the temperature grid of A2E_pre.py:206-207."""
+    from soc_amd import a2e_pre
+    out = {}
+    for name, (NFREQ, NE, NSIZE, isize) in dict(small=(24, 16, 3, 0), big=(40, 48, 3, 2), wide=(64, 32, 4, 1)).items():
+        dust = a2e_pre.AnalyticDust(NSIZE=NSIZE)
+        FREQ = np.logspace(np.log10(1.5e11), np.log10(2.0e15), NFREQ).astype(np.float32)
+        Ef = np.asarray(a2e_pre.PLANCK * FREQ, np.float32)
+        T = dust.TMIN[isize] + (dust.TMAX[isize] - dust.TMIN[isize]) * (np.arange(NE + 1) / float(NE)) ** 2.0
+        E = dust.T2E(isize, T)
+        SK1 = np.asarray(dust.SKabs(isize, FREQ), np.float32)
+        out[name] = (FREQ, Ef, SK1, np.asarray(E, np.float32), np.asarray(T, np.float32))
+    return out
+
+
+def a2e_pre_main():
+    """Golden arrays of the solver preprocessing from the x86 build of kernel_A2E_pre.c."""
+    from oracle.pyoracle import RefA2EPre
+    sys.path.insert(0, REPO)
+    R = RefA2EPre()
+    out = {}
+    for name, (FREQ, Ef, SK1, E, T) in a2e_pre_cases().items():
+        k = R.pre(FREQ, Ef, SK1, E, T)
+        for key in ("Iw", "L1", "L2", "Tdown", "noIw"):
+            out["%s_%s" % (name, key)] = k[key]
+        print("%-6s weights %d  pairs %d  Tdown %.3e .. %.3e" % (name, k["Iw"].size, (k["L1"] >= 0).sum(), k["Tdown"][1], k["Tdown"][-1]))
+    np.savez_compressed(os.path.join(HERE, "a2e_pre.npz"), **out)
+
+
 def sca_main():
     """Scattered-light images of tests/cases.py:SCA_CASES from the x86 builds of kernel_ASOC_sca.c."""
     from oracle.pyoracle import RefSca
@@ -163,6 +193,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--sca" in sys.argv:
         sca_main()
+        sys.exit(0)
+    if "--a2e-pre" in sys.argv:
+        a2e_pre_main()
         sys.exit(0)
     if "--a2e" in sys.argv:
         a2e_main()

@@ -1,0 +1,131 @@
+"""Solver-file preprocessing (A2E_pre.py; kernel_A2E_pre.c PrepareIntegrationWeightsTrapezoid, PrepareTdown):
+oracle vs the x86 build of the reference kernels (golden arrays, and live where the reference is present), HIP vs oracle,
+and a solver file built from a closed-form dust model driving the stochastic-heating solver."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_golden import a2e_pre_cases                        # noqa: E402
+from oracle.pyoracle import RefA2EPre, a2e_oracle_pre, a2e_oracle_dosolve    # noqa: E402
+from soc_amd import a2e_pre, files, launch, synth            # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "a2e_pre.npz"))
+CASES = a2e_pre_cases()
+FACTOR = launch.kernel_literals(1.0)[0]
+
+
+def _ref_available():
+    try:
+        RefA2EPre()
+        return True
+    except (FileNotFoundError, OSError):
+        return False
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_bit_exact_vs_reference_golden(name, oracle_libm, oracle_soc):
+    for orc in (oracle_libm, oracle_soc):                     # double arithmetic and libm exp in both modes
+        k = a2e_oracle_pre(orc, *CASES[name], FACTOR)
+        for key in ("L1", "L2", "noIw"):
+            assert np.array_equal(k[key], GOLD["%s_%s" % (name, key)]), key
+        assert np.array_equal(k["Iw"].view(np.uint32), GOLD[name + "_Iw"].view(np.uint32))
+        assert np.array_equal(k["Tdown"].view(np.uint32), GOLD[name + "_Tdown"].view(np.uint32))
+    assert (k["Iw"] > 0).all() and k["Tdown"][0] == 0.0 and (k["Tdown"][1:] > 0).all()
+
+
+@pytest.mark.skipif(not _ref_available(), reason="reference build not available (GPU box)")
+def test_oracle_live_vs_reference_other_grids(oracle_libm):
+    """grids the golden file does not hold: frequencies that do not reach the largest bin differences, one very narrow bin"""
+    R = RefA2EPre()
+    rng = np.random.default_rng(3)
+    for NFREQ, NE in ((12, 20), (33, 9), (50, 40)):
+        FREQ = np.sort(np.exp(rng.uniform(np.log(3e11), np.log(5e14), NFREQ))).astype(np.float32)
+        FREQ = np.unique(FREQ)
+        Ef = np.asarray(a2e_pre.PLANCK * FREQ, np.float32)
+        E = np.cumsum(np.exp(rng.uniform(np.log(1e-16), np.log(3e-12), NE + 1)))
+        E[3] = E[2] * (1 + 3e-6)
+        E = np.sort(E).astype(np.float32)
+        T = np.sort(rng.uniform(5.0, 900.0, NE + 1)).astype(np.float32)
+        SK = (1e-12 * (FREQ / 1e13) ** 1.3).astype(np.float32)
+        want = R.pre(FREQ, Ef, SK, E, T)
+        got = a2e_oracle_pre(oracle_libm, FREQ, Ef, SK, E, T, FACTOR)
+        for key in ("L1", "L2", "noIw"):
+            assert np.array_equal(got[key], want[key]), key
+        assert np.array_equal(got["Iw"].view(np.uint32), want["Iw"].view(np.uint32))
+        assert np.array_equal(got["Tdown"].view(np.uint32), want["Tdown"].view(np.uint32))
+        assert (want["L1"] == -1).sum() > 0                   # pairs no frequency feeds (L1 = -1, L2 = -2)
+
+
+class _OracleEngine:
+    def __init__(self, orc):
+        self.orc = orc
+
+    def a2e_pre(self, FREQ, Ef, SKABS, E, T, FACTOR):
+        return a2e_oracle_pre(self.orc, FREQ, Ef, SKABS, E, T, FACTOR)
+
+
+def _solver(engine, NE=24, NFREQ=30):
+    dust = a2e_pre.AnalyticDust(NSIZE=3)
+    FREQ = np.logspace(np.log10(1.5e11), np.log10(2.0e15), NFREQ).astype(np.float32)
+    return dust, a2e_pre.make_solver(dust, FREQ, NE, engine)
+
+
+def test_solver_file_from_a_dust_model(tmp_path, oracle_soc):
+    """make_solver follows A2E_pre.py's host arithmetic: file layout, S_FRAC normalised to 1, SK_ABS with the grain
+    density, Ibeg, EA; the file drives the solver: more absorbed energy -> more emission"""
+    dust, sol = _solver(_OracleEngine(oracle_soc))
+    fn = str(tmp_path / "an.solver")
+    synth.write_solver(fn, sol)
+    a2e_pre.write_tgrid(str(tmp_path / "an.tgrid"), sol)
+    back = files.read_solver(fn)
+    assert back["NE"] == 24 and back["NSIZE"] == 3 and abs(float(np.sum(back["S_FRAC"])) - 1.0) < 1e-6
+    assert np.allclose(back["SK_ABS"][1], dust.SKabs_Int(1, sol["FREQ"]), rtol=1e-6)
+    hdr = np.fromfile(str(tmp_path / "an.tgrid"), np.int32, 2)
+    assert list(hdr) == [3, 25]
+    for isize in range(3):
+        s = back["sizes"][isize]
+        assert s["L1"][0] == -2 and s["L2"][0] == -2
+        L1, L2 = s["L1"].reshape(24, 24), s["L2"].reshape(24, 24)
+        up = np.triu_indices(24, 1)
+        n = np.where(L1[up] >= 0, L2[up] - L1[up] + 1, 0)
+        assert n.sum() == len(s["Iw"]) and (n >= 0).all()
+        assert (np.diff(s["Ibeg"]) >= 0).all() and s["Ibeg"][0] >= 1
+        EA = s["EA"].reshape(30, 24)
+        assert (EA >= 0).all() and (np.diff(EA[-1]) >= 0).all()          # hotter bins emit more at the highest frequency
+    # the smallest size through DoSolve: the emission follows the absorbed energy
+    AF = synth.a2e_absorption_fraction(back, 0)
+    ABS = (1e-3 * (sol["FREQ"] / 1e13) ** -1.0).astype(np.float32)[None, :] * np.asarray([[1.0], [30.0]], np.float32)
+    em = a2e_oracle_dosolve(oracle_soc, 24, 30, back["sizes"][0], AF, ABS)
+    assert np.isfinite(em).all() and (em >= 0).all() and em[1].sum() > em[0].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_vs_oracle_and_golden(name, engine, oracle_soc):
+    got = engine.a2e_pre(*CASES[name], FACTOR)
+    want = a2e_oracle_pre(oracle_soc, *CASES[name], FACTOR)
+    for key in ("L1", "L2", "noIw"):
+        assert np.array_equal(got[key], want[key]) and np.array_equal(got[key], GOLD["%s_%s" % (name, key)]), key
+    # weights: +, -, *, / in double and float -- bit for bit; cooling rates: exp() in double from the device library
+    assert np.array_equal(got["Iw"].view(np.uint32), GOLD[name + "_Iw"].view(np.uint32))
+    assert np.allclose(got["Tdown"], GOLD[name + "_Tdown"], rtol=1e-6, atol=0.0)
+
+
+@pytest.mark.gpu
+def test_hip_solver_file_and_error_paths(engine, oracle_soc, tmp_path):
+    from soc_amd.lib import SocError
+    _, want = _solver(_OracleEngine(oracle_soc))
+    _, got = _solver(engine)
+    for isize in range(3):
+        a, b = got["sizes"][isize], want["sizes"][isize]
+        assert np.array_equal(a["Iw"].view(np.uint32), b["Iw"].view(np.uint32)) and np.array_equal(a["L1"], b["L1"]) and np.array_equal(a["L2"], b["L2"])
+        assert np.allclose(a["Tdown"], b["Tdown"], rtol=1e-6) and np.array_equal(a["EA"], b["EA"]) and np.array_equal(a["Ibeg"], b["Ibeg"])
+    FREQ, Ef, SK, E, T = CASES["small"]
+    with pytest.raises(SocError, match="increase"):
+        engine.a2e_pre(FREQ, Ef, SK, E[::-1].copy(), T, FACTOR)
+    with pytest.raises(SocError, match="NE\\+1"):
+        engine.a2e_pre(FREQ, Ef, SK, E, T[:-1], FACTOR)
