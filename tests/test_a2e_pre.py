@@ -129,3 +129,23 @@ def test_hip_solver_file_and_error_paths(engine, oracle_soc, tmp_path):
         engine.a2e_pre(FREQ, Ef, SK, E[::-1].copy(), T, FACTOR)
     with pytest.raises(SocError, match="NE\\+1"):
         engine.a2e_pre(FREQ, Ef, SK, E, T[:-1], FACTOR)
+
+
+@pytest.mark.gpu
+def test_hip_command_line_writes_the_files_of_a2e_pre(engine, tmp_path, monkeypatch):
+    """`python -m soc_amd.a2e_pre <gs-dust> <freq file> <solver> [NE]` (A2E_pre.py:21-30): the GSET file is read by the
+    caller's DustLib -- here a stand-in module with the same class name -- and the solver and .tgrid files come out"""
+    d = str(tmp_path)
+    with open(os.path.join(d, "DustLib.py"), "w") as fp:
+        fp.write("from soc_amd.a2e_pre import AnalyticDust\n\ndef GSETDust(filename):\n    return AnalyticDust(NSIZE=2)\n")
+    monkeypatch.syspath_prepend(d)
+    sys.modules.pop("DustLib", None)
+    FREQ = np.logspace(np.log10(1.5e11), np.log10(2.0e15), 20)
+    np.savetxt(os.path.join(d, "freq.txt"), FREQ)
+    rc = a2e_pre.main([os.path.join(d, "gs_x.dust"), os.path.join(d, "freq.txt"), os.path.join(d, "x.solver"), "12"])
+    sys.modules.pop("DustLib", None)
+    assert rc == 0
+    sol = files.read_solver(os.path.join(d, "x.solver"))
+    assert sol["NE"] == 12 and sol["NSIZE"] == 2 and sol["NFREQ"] == 20
+    assert list(np.fromfile(os.path.join(d, "x.tgrid"), np.int32, 2)) == [2, 13]
+    assert a2e_pre.main([]) == 1                              # usage
