@@ -2124,25 +2124,38 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         A.admit[0] = next + n;
     }
     __syncthreads();
+    // Descriptors of the next pass in three groups: brick queues with long chunks (>= P/2 packets) first, then the short
+    // ones, then the event queues -- workgroups start in descriptor order, so the long walks are under way when the
+    // short ones fill the end of the pass (the queues themselves keep their order in the id array).
+    __shared__ int sSumL[1024], sSumE[1024];
     const int per = (NB + 1023) / 1024;
     const int b0 = tid * per, b1 = min(NB, b0 + per);
-    int s = 0, sd = 0;
+    const int longc = (A.P + 1) / 2;
+    int s = 0, sd = 0, sl = 0, se = 0;                   // packets; descriptors of short chunks, of long chunks, of event queues
     for (int b = b0; b < b1; b++) {
         const int c = A.hist[b];
+        const int nk = (c + A.P - 1) / A.P;
         s += c;
-        sd += (c + A.P - 1) / A.P;
+        if (b >= A.ev_brick) se += nk;
+        else if (c >= longc) sl += nk;
+        else                 sd += nk;
     }
     sSum[tid] = s;
     sSumD[tid] = sd;
+    sSumL[tid] = sl;
+    sSumE[tid] = se;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
-        int v = 0, vd = 0;
-        if (tid >= d) { v = sSum[tid - d];  vd = sSumD[tid - d]; }
+        int v = 0, vd = 0, vl = 0, ve = 0;
+        if (tid >= d) { v = sSum[tid - d];  vd = sSumD[tid - d];  vl = sSumL[tid - d];  ve = sSumE[tid - d]; }
         __syncthreads();
         sSum[tid] += v;
         sSumD[tid] += vd;
+        sSumL[tid] += vl;
+        sSumE[tid] += ve;
         __syncthreads();
     }
+    const int nlong = sSumL[1023], nbrickdesc = nlong + sSumD[1023];
     // parking: a brick queue shorter than min(PARK, mean length of the non-empty brick queues) is not walked in the next
     // pass -- its workgroup hands the packets back to the same queue, where they wait for company (a workgroup with a
     // packet or less per lane runs until its longest visit ends with most lanes idle).  Queues of at least the mean
@@ -2160,11 +2173,13 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
         }
         park = (sCnt[0] > 0) ? min(A.PARK, sTot[0] / sCnt[0]) : 0;
     }
-    int off = sSum[tid] - s, offd = sSumD[tid] - sd;
+    int off = sSum[tid] - s;
+    int offl = sSumL[tid] - sl, offs = nlong + sSumD[tid] - sd, offe = nbrickdesc + sSumE[tid] - se;
     for (int b = b0; b < b1; b++) {
         const int c = A.hist[b];
         A.off[b] = off;
-        if (b == A.ev_brick) A.ndesc_next[2] = offd;
+        if (b == A.ev_brick) A.ndesc_next[2] = nbrickdesc;
+        int &offd = (b >= A.ev_brick) ? offe : ((c >= longc) ? offl : offs);
         if (b >= A.ev_brick && ((b - A.ev_brick) % A.EQ) == 0) {        // a creation queue: the admitted ids go to its end
             const int l = (b - A.ev_brick) / A.EQ;
             if (l < A.nl && sAdm[l]) A.admit[3 + 3 * l] = off + c - sAdm[l];
@@ -2185,7 +2200,7 @@ __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
     if (tid == 1023) {
         A.off[NB] = sSum[1023];
         *A.total = sSum[1023];
-        *A.ndesc_next = sSumD[1023];
+        *A.ndesc_next = nbrickdesc + sSumE[1023];
         A.hist[NB] = 0;
     }
 }
