@@ -103,7 +103,9 @@ __global__ __launch_bounds__(64) void soc_a2e_pre_weights_kernel(const int NFREQ
         i = 1;
         while ((i < (NFREQ - 1)) && (Ef[i] < W1)) i += 1;
         i = (i - 1 > 0) ? (i - 1) : 0;
-        // W1 - W2
+        // The integrand G(E) E C_abs(E) over [W1, W4] is piecewise: G rises on [W1, W2], is flat on [W2, W3], falls on
+        // [W3, W4].  Every section is cut at the frequency grid; a piece [a, b] adds to the weights of its two grid
+        // points.  The first piece starts inside the bin of W1, the others continue from where the last one ended.
         a     = soc_pre_clamp(W1, (double)Ef[i], (double)Ef[i + 1]);
         b     = soc_pre_clamp(W2, a, (double)Ef[i + 1]);
         alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
@@ -112,37 +114,18 @@ __global__ __launch_bounds__(64) void soc_a2e_pre_weights_kernel(const int NFREQ
         G2    = (b - W1) / dEl;
         SOC_PRE_ADD(G1, G2);
         if (b < W2) i += 1;
-        while ((i < (NFREQ - 1)) && (b < W2)) {
-            a     = b;
-            G1    = G2;
-            b     = soc_pre_min(W2, (double)Ef[i + 1]);
-            alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            G2    = (b - W1) / dEl;
-            SOC_PRE_ADD(G1, G2);
-            if (b < W2) i += 1;
-        }
-        // W2 - W3
-        while ((i < (NFREQ - 1)) && (b < W3)) {
-            a     = b;
-            G1    = G2;
-            b     = soc_pre_min(W3, (double)Ef[i + 1]);
-            G2    = soc_pre_min(dEl, dEu) / dEl;
-            alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            SOC_PRE_ADD(G1, G2);
-            if (b < W3) i += 1;
-        }
-        // W3 - W4
-        while ((i < (NFREQ - 1)) && (b < W4)) {
-            a     = b;
-            G1    = G2;
-            b     = soc_pre_min(W4, (double)Ef[i + 1]);
-            alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-            G2    = (W4 - 0.5 * (a + b)) / dEl;
-            SOC_PRE_ADD(G1, G2);
-            if (b < W4) i += 1;
+        for (int section = 0; section < 3; section++) {
+            const double Wend = (section == 0) ? W2 : ((section == 1) ? W3 : W4);
+            while ((i < (NFREQ - 1)) && (b < Wend)) {
+                a     = b;
+                G1    = G2;
+                b     = soc_pre_min(Wend, (double)Ef[i + 1]);
+                alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
+                beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
+                G2    = (section == 0) ? ((b - W1) / dEl) : ((section == 1) ? (soc_pre_min(dEl, dEu) / dEl) : ((W4 - 0.5 * (a + b)) / dEl));
+                SOC_PRE_ADD(G1, G2);
+                if (b < Wend) i += 1;
+            }
         }
         // inside the bin (u = l + 1)
         if (u == (l + 1)) {
