@@ -47,8 +47,10 @@ def _check_supported(USER, NDUST, WITH_MSF):
                    "`TOLD = 0.0*TNEW` with TNEW = None unless `loadtemp` is given, ASOC.py:700, :2282)")
     # keys the parser knows (soc_amd/ini.py keeps the reference's keyword set) whose effect is not built: refused, so that
     # an ini file using them stops here instead of finishing with products missing or different
-    if 'nnmake' in USER.KEYS:
-        bad.append("nnmake (training data for the driver's neural-network shortcut: thinned absorptions, ASOC.py:100-105,632-638; `absthin` alone is ignored, as in the reference)")
+    if 'nnmake' in USER.KEYS and USER.ABSTHIN > 1 and USER.MMAP_ABSORBED > 0:
+        bad.append("nnmake with absthin and mmapabs (the reference adds thinned rows to a full-size memory map there and stops, ASOC.py:623-630, :1496)")
+    if 'nnmake' in USER.KEYS and USER.ABSTHIN > 1 and USER.WITH_REFERENCE and not USER.NOABSORBED:
+        bad.append("nnmake with absthin and the reference field (not built)")
     if USER.POLMAP or USER.POLSIM or len(USER.BFILES) > 0 or len(getattr(USER, "file_polred", "")) > 0:
         bad.append("polmap / polred / magnetic-field files (polarisation maps)")
     if USER.FAST_MAP >= 2:
@@ -238,7 +240,10 @@ class AbsorptionRun:
         U, e, c = self.U, self.eng, self.cloud
         CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
         CTABS = np.zeros(CELLS, np.float32)
-        FABSORBED = None if U.NOABSORBED else np.zeros((CELLS, NFREQ), np.float32)
+        # `nnmake` with `absthin N`: the absorptions of every N-th cell only (ASOC.py:100-105, :632-638)
+        thin = U.ABSTHIN if (U.ABSTHIN > 1 and 'nnmake' in U.KEYS) else 1
+        self.absthin = thin
+        FABSORBED = None if U.NOABSORBED else np.zeros(((CELLS + thin - 1) // thin, NFREQ), np.float32)
         if len(U.file_constant_load) > 0:
             self.log("=== CLOAD => %s" % U.file_constant_load)
             return np.fromfile(U.file_constant_load, np.float32, CELLS), FABSORBED
@@ -298,7 +303,7 @@ class AbsorptionRun:
                     arr = e.batch_read_int(k)
                     if self.comm and self.world > 1:
                         arr = self.comm.all_reduce_host(arr)
-                    FABSORBED[:, f] += arr
+                    FABSORBED[:, f] += arr[0::self.absthin]
                 del group[:]
             if deferred:
                 e.batch_begin(0)
@@ -369,7 +374,7 @@ class AbsorptionRun:
                 if (FABSORBED is not None or U.SAVE_INTENSITY > 0) and not int_batched:
                     TMP = e.read_tally(1)
                     if FABSORBED is not None:
-                        FABSORBED[:, IFREQ] += TMP
+                        FABSORBED[:, IFREQ] += TMP[0::self.absthin]
                     if U.SAVE_INTENSITY > 0:
                         self._save_intensity(IFREQ, FREQ, ABS, TMP)
                 if self.ROI_SAVE is not None:
@@ -544,7 +549,7 @@ class AbsorptionRun:
                     if iteration == U.ITERATIONS - 1 and (FABSORBED is not None or U.SAVE_INTENSITY > 0):
                         TMP = e.read_tally(1)
                         if FABSORBED is not None:
-                            FABSORBED[:, IFREQ] += TMP
+                            FABSORBED[:, IFREQ] += TMP[0::self.absthin]
                         if U.SAVE_INTENSITY > 0:                   # ASOC.py:1885-1908
                             self._save_intensity(IFREQ, FREQ, ABS_f, TMP)
                 if deferred:
@@ -776,7 +781,7 @@ class AbsorptionRun:
             if len(U.file_constant_save) > 0:
                 CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549
             if FABSORBED is not None:
-                files.scale_absorbed(FABSORBED, self.cloud, U.GL, U.NNNLIMIT)
+                files.scale_absorbed(FABSORBED, self.cloud, U.GL, U.NNNLIMIT, self.absthin)
                 files.write_absorbed(U.file_absorbed, FABSORBED)   # ASOC.py:2866-2875
             else:
                 prefix = U.KEYS.get('prefix', ['soc'])[0] if U.KEYS.get('prefix') else 'soc'

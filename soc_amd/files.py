@@ -163,10 +163,25 @@ def write_diffuserad(filename, data):
         data.tofile(fp)
 
 
-def scale_absorbed(FABSORBED, cloud, GL, nnnlimit=0.0):
+def scale_absorbed(FABSORBED, cloud, GL, nnnlimit=0.0, absthin=1):
     """Final scaling of the per-frequency absorptions before they are written
     (ASOC.py:2793-2809): x FACTOR*8^level/(GL*PARSEC)/DENS; parents (and cells with density
-    <= nnnlimit) are marked -1e20.  In place; returns the array."""
+    <= nnnlimit) are marked -1e20.  In place; returns the array.  absthin > 1: FABSORBED holds every absthin-th cell
+    (`nnmake`, ASOC.py:2815-2836)."""
+    if absthin > 1:
+        ind_all = np.arange(0, cloud.CELLS, absthin)
+        i0 = 0
+        for level in range(cloud.LEVELS):
+            a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
+            coeff = (8.0 ** level) * (FACTOR / (GL * PARSEC))
+            ind = ind_all[(ind_all >= a) & (ind_all < b)]
+            n = len(ind)
+            with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+                FABSORBED[i0:i0 + n, :] *= (coeff / cloud.DENS[ind].reshape(n, 1)).astype(np.float32)
+            m = np.nonzero(cloud.DENS[ind] <= nnnlimit)[0]
+            FABSORBED[i0 + m, :] = -1.0e20
+            i0 += n
+        return FABSORBED
     for level in range(cloud.LEVELS):
         a, b = int(cloud.OFF[level]), int(cloud.OFF[level] + cloud.LCELLS[level])
         coeff = (8.0 ** level) * (FACTOR / (GL * PARSEC))

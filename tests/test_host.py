@@ -220,7 +220,7 @@ def test_unsupported_options_fail_loudly(tmp_path):
     from oracle_engine import OracleEngine
     d = str(tmp_path)
     cloud = synth.cartesian_cloud(4, seed=1)
-    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\nnnmake 1\n", "polmap bx by bz\n",
+    for extra in ("split 1\n", "stepweight 1 0.5 3\n", "direweight 1 0.5\n", "psmethod 3\n", "absthin 4\nnnmake 1\nmmapabs 1\n", "polmap bx by bz\n",
                   "mapping 12 10 0.8 2\n", "mapint 3\n", "DEFS -D X=1\n",
                   "reference 1\nsaveint 1\n"):
         with pytest.raises(UnsupportedOption):
@@ -229,6 +229,24 @@ def test_unsupported_options_fail_loudly(tmp_path):
     # branches refused above or nothing at all
     AbsorptionRun(User(_write_model(d, cloud, extra="absthin 4\ninterpolate 1\nexternalmask m.bin\nsourcemap s.bin\nbgmethod 1\nyshear 0.1\n")),
                   OracleEngine("soc"))
+
+
+def test_nnmake_writes_the_absorptions_of_every_nth_cell(tmp_path):
+    """`nnmake` + `absthin N` (ASOC.py:100-105, :632-638, :1496, :2815-2836, :2871-2873): the absorbed file holds the cells
+    0, N, 2N, ... with the scaling and the -1e20 marks of the full file; `absthin` alone changes nothing"""
+    from oracle_engine import OracleEngine
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(5, levels=2, frac=0.15, seed=4)
+    os.chdir(d)
+    out = {}
+    for key, extra in (("full", ""), ("alone", "absthin 3\n"), ("thin", "absthin 3\nnnmake 1\n")):
+        ini = _write_model(d, cloud, extra=extra)
+        AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0).run()
+        out[key] = files.read_absorbed(os.path.join(d, "abs.data"))
+    assert out["full"].shape[0] == cloud.CELLS and np.array_equal(out["alone"], out["full"])
+    assert out["thin"].shape == ((cloud.CELLS + 2) // 3, out["full"].shape[1])
+    assert np.array_equal(out["thin"], out["full"][0::3])
+    assert (out["thin"] == -1.0e20).any() and (out["thin"] > 0).any()
 
 
 def test_healpix_background_block(tmp_path):
