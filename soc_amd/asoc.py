@@ -63,8 +63,8 @@ def _check_supported(USER, NDUST, WITH_MSF):
     # accepted without effect, because they have none in the reference either: `interpolate` and `yshear` reach only the
     # per-level map kernel (kernel_ASOC_map_H.c, FAST_MAP >= 999: refused above), `externalmask` only the SUBITERATIONS
     # branch (refused above), `sourcemap` is parsed and never read (ASOC_aux.py:322), `bgmethod` is a -D that no kernel tests
-    if USER.LOAD_TEMPERATURE and USER.ITERATIONS > 0 and USER.WITH_ALI:
-        bad.append("loadtemp with ALI iterations (the old temperatures enter the escape-probability correction, ASOC.py:2064-2071)")
+    # (`loadtemp` with iterations > 0 has no effect in the reference: the temperatures read are replaced before any use --
+    # the block that would use them with ALI, ASOC.py:2062-2071, is switched off there -- so it has none here)
     if bad:
         raise UnsupportedOption("ini options not supported by this engine: " + ", ".join(bad))
 
