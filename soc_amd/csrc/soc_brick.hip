@@ -1424,7 +1424,6 @@ __device__ __forceinline__ void soc_lbrick_walk_spool(const SocGrid &G, const So
     soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = (int)(threadIdx.x & 63);
     (void)wave;
     float *pool = sPool;                                   // one pool for the workgroup: NF * NSW fields, three rings, their control words
     int   *rq = (int *)(pool + SOC_POOL_NF * NSW), *oq = rq + NSW, *fq = oq + NSW;
