@@ -348,7 +348,6 @@ def main():
         alg_bytes = events_rank / max(args.steps, 1) * BYTES_PER_TALLY_EVENT
         achieved = alg_bytes / kavg_s / 1e9
         kname = {3: "soc_lbrick_pass<TABS-only> (brick-local hierarchies: soc_lbrick_walk + soc_brick_events)",
-                 4: "soc_lbrick_pass<TABS-only> (brick-local hierarchies, packet pools: soc_lbrick_walk_pool + soc_brick_events)",
                  2: "soc_brick_pass<octree,scalar-opacity,TABS-only>", 1: "soc_brick_pass<Cartesian,scalar-opacity,TABS-only>"}.get(form, "soc_brick_pass")
         kernel_name = ("%s (+ soc_brick_scan, soc_brick_scatter), %d passes in the last sweep: "
                        "time is the HIP-event span of all kernels of the K steps / K" % (kname, passes)) if passes else "soc_sim_pb_kernel / soc_sim_cl_kernel (direct)"

@@ -88,8 +88,8 @@ int soc_set_exec(soc_ctx *ctx, int mode, int brick_log2);
  * "climb_lanes" (lanes of a wave that must wait before the packet swap / the deferred Index() runs), "brick_cells"
  * (cells per brick on hierarchies, <= 16384), "tail_lanes", "park_below" (hierarchies: brick queues shorter than this and than the mean wait a pass; 1 = never), "population" (packets in flight), "hash_slots" (per-workgroup
  * arrival table, power of two), "general_kernel" (1: no background-only kernel), "global_tree" (1: hierarchies are walked in
- * global memory also where the brick-local form applies), "slow_every" (test knob of that form), "pool_slots" (packet slots of LDS per wave on brick-local hierarchies; 0 = packets
- * bound to lanes), "oversubscribe", "verbose". */
+ * global memory also where the brick-local form applies), "slow_every" (test knob of that form),
+ * "oversubscribe", "verbose". */
 int soc_set_tuning(soc_ctx *ctx, const char *name, int value);
 
 /* replaces the per-frequency uploads of ABS, SCA (ASOC.py:1171-1175); ndust must be 1
@@ -233,8 +233,7 @@ int soc_stats(soc_ctx *ctx, uint64_t out[3], int reset);
 /* number of brick-sweep passes of the last launch (0 if it ran in direct mode) */
 int soc_last_passes(soc_ctx *ctx);
 /* how the last launch was executed: 0 direct kernel, 1 brick sweep on a Cartesian grid, 2 on a hierarchy read from global
- * memory, 3 on brick-local hierarchies (soc_ltree.h: hierarchies whose Index() the reference evaluates in double), 4 the same
- * with packet pools per wave (tuning "pool_slots") */
+ * memory, 3 on brick-local hierarchies (soc_ltree.h: hierarchies whose Index() the reference evaluates in double) */
 int soc_last_form(soc_ctx *ctx);
 
 /* HIP-event timing on the handle's stream: bracket launches, then read elapsed ms */

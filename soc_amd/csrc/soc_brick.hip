@@ -131,8 +131,6 @@ struct SocBrickArgs {
     int EQ;                      // event queues per launch: creation, scattering (+ slow steps with LT)
     int slow_every;              // test knob: every n-th step below the root grid takes the slow-step queue (0: only the degenerate ones)
     int lean_step;               // experiment: only root-leaf and sibling-leaf moves are settled in the step arm
-    int pool;                    // > 0: soc_lbrick_walk_pool with this many packet slots of LDS per wave
-    int spool;                   // > 0: soc_lbrick_walk_spool with this many slots per workgroup (a power of two)
     const SocLBrick *lbr;        // [NB] boxes
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
@@ -942,864 +940,6 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 }
 
 
-// ---------------------------------------------------------------------------------------
-// The same walk with a packet pool per wave (A.pool > 0 slots of LDS per wave).
-//
-// Measured on the form above (wave counters, -DSOC_BRICK_PROF, config 3): 29-31 of 64 lanes step in an average
-// iteration; the arm that stores / fetches packets runs with 22 lanes, the deferred Index() with 9 -- a lane that
-// needs one of them waits until enough others do, and the arm then costs a whole wave's issue slots anyway.
-// Here a lane never waits for an arm.  Every wave owns `pool` packet slots in LDS (22 dwords each, fields apart so that
-// neighbouring lanes touch neighbouring banks) on four lists: READY packets (can step), OUT packets (leave the brick:
-// to be written to their queue), CLIMB packets (Index() to be finished by soc_lt_step) and free slots.  A lane whose
-// packet needs service trades it for a READY one in place (the exchange arm: LDS only, ~90 instructions, entered when
-// four lanes ask); the service arms run when about a wave's worth of work has piled up, with all 64 lanes: each lane
-// borrows one OUT (CLIMB) slot -- parks its own packet there, serves the borrowed one in its registers with the code of
-// the form above, and trades back.  The lists are private to the wave (counters in scalar registers, ranks from
-// ballots): no atomics, no barriers, nothing to wait for between waves.  Fetching stays pipelined per lane as above
-// (record of the next packet, id of the one after), one step of the pipeline per service arm.
-// A packet's trajectory does not depend on which lane steps it or when: results equal those of the form above and of
-// the direct kernels (same event counts; tallies to the order of the fp32 additions).
-// ---------------------------------------------------------------------------------------
-enum { SOC_PM_STEP = 0, SOC_PM_CLIMB = 1, SOC_PM_OUT = 2, SOC_PM_EMPTY = 3 };
-#define SOC_POOL_NF 22
-
-template <bool WINT, int KIND>
-__device__ __forceinline__ void soc_lbrick_walk_pool(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
-{
-    constexpr bool CL = (KIND == 2);
-    if (bid >= *A.ndesc) return;
-    SocDesc D = A.desc[bid];
-    D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
-    if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
-    const int BV = A.CAP;
-    const int nthr = (int)blockDim.x;
-    const int NSW = A.pool;
-    SocPk2 *pk = A.pk;
-
-    extern __shared__ float lds[];
-    float *sT   = lds;
-    float *sI   = sT + BV;
-    float *sD   = sI + (WINT ? BV : 0);
-    const int NQ = A.NBQ + A.EQ * A.nl + 1;
-    int   *sH   = (int *)(sD + BV);
-    int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));
-    float *sL   = (float *)(sCtl + 4);
-    float *sThr = sL + 3 * SOC_MAXLAUNCH;
-    uint32_t *sFirst = (uint32_t *)(sThr + SOC_MAXL) + 3;
-    float *sPool = (float *)(sFirst + SOC_MAXLAUNCH + 1);   // per wave: NF * NSW packet fields, then 4 * NSW list entries
-    const SocSim &S = K.S[0];
-    if ((int)threadIdx.x < K.n) {
-        sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
-    }
-    if (threadIdx.x < SOC_MAXL) sThr[threadIdx.x] = A.lt_thr[threadIdx.x];
-    if (threadIdx.x <= SOC_MAXLAUNCH) sFirst[threadIdx.x] = ((int)threadIdx.x < A.nl) ? K.first[threadIdx.x] : 0xffffffffu;
-    const int mybrick = (A.NBQ > A.NB) ? (D.brick % A.NB) : D.brick;
-    const int qbase = D.brick - mybrick;
-    const int nl = A.nl;
-    SocLBrick KB = A.lbr[mybrick];
-    KB.x0 = __builtin_amdgcn_readfirstlane(KB.x0);  KB.y0 = __builtin_amdgcn_readfirstlane(KB.y0);  KB.z0 = __builtin_amdgcn_readfirstlane(KB.z0);
-    KB.bx = __builtin_amdgcn_readfirstlane(KB.bx);  KB.by = __builtin_amdgcn_readfirstlane(KB.by);  KB.bz = __builtin_amdgcn_readfirstlane(KB.bz);
-    KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
-    {
-        const float *src = A.btree + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
-    }
-    soc_qh_init(sH, A.HS, NQ);
-    if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = (int)(threadIdx.x & 63);
-    float *pool = sPool + (size_t)wave * (SOC_POOL_NF + 4) * NSW;
-    int   *rq = (int *)(pool + SOC_POOL_NF * NSW), *oq = rq + NSW, *cq = oq + NSW, *fq = cq + NSW;
-    for (int i = lane; i < NSW; i += 64) fq[i] = i;
-    __syncthreads();
-
-    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
-    const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
-    // the packet in the lane's registers
-    float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 1.0f, uy = 1.0f, uz = 1.0f, rux = 1.0f, ruy = 1.0f, ruz = 1.0f;
-    float photons = 0.0f, free_path = 0.0f, tau = 0.0f;
-    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;
-    uint32_t dz = 0, dw = 0, wid = 0;
-    int   mode = SOC_PM_EMPTY;
-    // derived from it
-    float dens = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f, lsc = 1.0f, kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
-    // the wave's lists (scalar)
-    int   n_ready = 0, n_out = 0, n_climb = 0, n_free = NSW;
-    // the lane's fetch pipeline
-    bool  nhave = false, nnhave = false;
-    soc_f4v na = { 0.0f, 0.0f, 0.0f, 0.0f }, nb = na, nc = na;
-    soc_u2v ndzw = { 0u, 0u };
-    uint32_t nwid = 0, nnwid = 0;
-    int   nslot = 0, nnslot = 0;
-    bool  src_done = false;                                                  // the last reservation ran past the end of the chunk
-    unsigned int n_tally = 0;
-    int   r = SOC_LT_SLOW + 2, Rx = 0, Ry = 0, Rz = 0, slot0 = 0;
-    SOC_PROF_DECL;
-
-    // registers <-> slot s: the 22 fields of a packet
-#define SOC_PF(i)  pool[(i) * NSW + ps_]
-#define SOC_POOL_PACK_LS   ((uint32_t)(slot & 0xffff) | ((uint32_t)level << 16) | ((uint32_t)nvisit << 20))
-#define SOC_POOL_PACK_CQ   ((uint32_t)cslot | ((uint32_t)lq << 16))
-#define SOC_POOL_WRITE(s_) do { const int ps_ = (s_); \
-        SOC_PF(0) = px;  SOC_PF(1) = py;  SOC_PF(2) = pz;  SOC_PF(3) = ux;  SOC_PF(4) = uy;  SOC_PF(5) = uz;  SOC_PF(6) = rux;  SOC_PF(7) = ruy;  SOC_PF(8) = ruz; \
-        SOC_PF(9) = photons;  SOC_PF(10) = free_path;  SOC_PF(11) = tau;  SOC_PF(12) = __int_as_float(cx);  SOC_PF(13) = __int_as_float(cy);  SOC_PF(14) = __int_as_float(cz); \
-        SOC_PF(15) = __uint_as_float(SOC_POOL_PACK_LS);  SOC_PF(16) = __uint_as_float(dz);  SOC_PF(17) = __uint_as_float(dw);  SOC_PF(18) = __uint_as_float(wid); \
-        SOC_PF(19) = __uint_as_float(SOC_POOL_PACK_CQ);  SOC_PF(20) = __int_as_float(key);  SOC_PF(21) = __int_as_float(mode); } while (0)
-#define SOC_POOL_READ(s_) do { const int ps_ = (s_); \
-        px = SOC_PF(0);  py = SOC_PF(1);  pz = SOC_PF(2);  ux = SOC_PF(3);  uy = SOC_PF(4);  uz = SOC_PF(5);  rux = SOC_PF(6);  ruy = SOC_PF(7);  ruz = SOC_PF(8); \
-        photons = SOC_PF(9);  free_path = SOC_PF(10);  tau = SOC_PF(11);  cx = __float_as_int(SOC_PF(12));  cy = __float_as_int(SOC_PF(13));  cz = __float_as_int(SOC_PF(14)); \
-        { const uint32_t ls_ = __float_as_uint(SOC_PF(15));  slot = (int)(ls_ & 0xffffu);  if (slot == 0xffff) slot = -1;  level = (int)((ls_ >> 16) & 15u);  nvisit = (int)(ls_ >> 20); } \
-        dz = __float_as_uint(SOC_PF(16));  dw = __float_as_uint(SOC_PF(17));  wid = __float_as_uint(SOC_PF(18)); \
-        { const uint32_t cq_ = __float_as_uint(SOC_PF(19));  cslot = (int)(cq_ & 0xffffu);  lq = (int)(cq_ >> 16); } \
-        key = __float_as_int(SOC_PF(20));  mode = __float_as_int(SOC_PF(21)); } while (0)
-    // what a packet's fields imply (after SOC_POOL_READ or after the record has been decoded)
-#define SOC_POOL_DERIVE() do { \
-        gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS; \
-        lsc = soc_lt_pow2(-level);  kabs = sL[3 * lq];  ksca = sL[3 * lq + 1];  tw = sL[3 * lq + 2]; \
-        dens = (slot >= 0) ? sD[slot] : 0.0f; } while (0)
-    // trade the registers' packet for the one in slot s (the slot's packet may be garbage when the caller says so)
-#define SOC_POOL_TRADE(s_) do { \
-        const float a0 = px, a1 = py, a2 = pz, a3 = ux, a4 = uy, a5 = uz, a6 = rux, a7 = ruy, a8 = ruz, a9 = photons, a10 = free_path, a11 = tau; \
-        const int   b0 = cx, b1 = cy, b2 = cz, b5 = key, b6 = mode; \
-        const uint32_t c0 = SOC_POOL_PACK_LS, c1 = dz, c2 = dw, c3 = wid, c4 = SOC_POOL_PACK_CQ; \
-        SOC_POOL_READ(s_); \
-        { const int ps_ = (s_); \
-          SOC_PF(0) = a0;  SOC_PF(1) = a1;  SOC_PF(2) = a2;  SOC_PF(3) = a3;  SOC_PF(4) = a4;  SOC_PF(5) = a5;  SOC_PF(6) = a6;  SOC_PF(7) = a7;  SOC_PF(8) = a8; \
-          SOC_PF(9) = a9;  SOC_PF(10) = a10;  SOC_PF(11) = a11;  SOC_PF(12) = __int_as_float(b0);  SOC_PF(13) = __int_as_float(b1);  SOC_PF(14) = __int_as_float(b2); \
-          SOC_PF(15) = __uint_as_float(c0);  SOC_PF(16) = __uint_as_float(c1);  SOC_PF(17) = __uint_as_float(c2);  SOC_PF(18) = __uint_as_float(c3); \
-          SOC_PF(19) = __uint_as_float(c4);  SOC_PF(20) = __int_as_float(b5);  SOC_PF(21) = __int_as_float(b6); } } while (0)
-#define SOC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
-#define SOC_RANK(m_) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u)))
-    // put slot s_ on the list the packet it holds belongs to (mode m_): lanes for which on_ holds
-#define SOC_POOL_PUSH(on_, s_, m_) do { \
-        const unsigned long long mr_ = __ballot((on_) && (m_) == SOC_PM_STEP), mo_ = __ballot((on_) && (m_) == SOC_PM_OUT); \
-        const unsigned long long mc_ = __ballot((on_) && (m_) == SOC_PM_CLIMB), mf_ = __ballot((on_) && (m_) == SOC_PM_EMPTY); \
-        if (on_) { \
-            if ((m_) == SOC_PM_STEP)       rq[n_ready + SOC_RANK(mr_)] = (s_); \
-            else if ((m_) == SOC_PM_OUT)   oq[n_out + SOC_RANK(mo_)] = (s_); \
-            else if ((m_) == SOC_PM_CLIMB) cq[n_climb + SOC_RANK(mc_)] = (s_); \
-            else                           fq[n_free + SOC_RANK(mf_)] = (s_); \
-        } \
-        n_ready += __popcll(mr_);  n_out += __popcll(mo_);  n_climb += __popcll(mc_);  n_free += __popcll(mf_); \
-        SOC_WAVE_FENCE(); } while (0)
-    // the outcome r of Index() for the packet in the registers (the block that follows the arms in the form above)
-#define SOC_POOL_OUTCOME() do { \
-        if (r == SOC_LT_INSIDE) { \
-            if (!CL && (slot == slot0)) { px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz; } \
-            nvisit++;  mode = SOC_PM_STEP; \
-            if (nvisit >= A.KCAP) { mode = SOC_PM_OUT;  key = D.brick; } \
-        } else if (r == SOC_LT_LEAVE) { \
-            mode = SOC_PM_OUT;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;     /* the brick of that root cell is looked up when the packet is stored */ \
-        } else if (r == SOC_LT_EXIT) { \
-            mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq; \
-        } else { \
-            mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE; \
-        } } while (0)
-
-    const int XTH = (A.FTH > 0 && A.FTH < 64) ? A.FTH : 4; // lanes asking before the exchange arm is entered
-    const int LOW = (A.CTH > 0 && A.CTH < NSW) ? A.CTH : 16;   // READY packets left when the service arms are entered: the pool is then full of
-                                                           // packets that wait for them, and the arms run with (nearly) all lanes
-    int guard = 0;
-    while (true) {
-        const unsigned long long m_step = __ballot(mode == SOC_PM_STEP);
-        const int held_climb = __popcll(__ballot(mode == SOC_PM_CLIMB));
-        const int stepping = __popcll(m_step);
-        SOC_PROF(0, 1);  SOC_PROF(1, stepping);  SOC_PROF(7, __popcll(__ballot(mode == SOC_PM_EMPTY)));
-        SOC_PROF_T(6);                                     // loop head
-        const bool pipe = (__ballot(nhave | nnhave) != 0ull) || !src_done;
-        // ---- exchange: lanes without a packet to step take READY ones, leaving theirs in the slot ----
-        if (n_ready > 0) {
-            const bool want = (mode != SOC_PM_STEP);
-            const unsigned long long mw = __ballot(want);
-            if ((__popcll(mw) >= XTH) || ((stepping == 0) && (mw != 0ull))) {
-                SOC_PROF(6, 1);
-                const int  rk = SOC_RANK(mw);
-                const bool take = want && (rk < n_ready);
-                const int  s = take ? rq[n_ready - 1 - rk] : 0;
-                const int  mold = mode;
-                SOC_WAVE_FENCE();
-                if (take) {
-                    if (mold == SOC_PM_EMPTY) { SOC_POOL_READ(s); } else { SOC_POOL_TRADE(s); }
-                    SOC_POOL_DERIVE();
-                }
-                n_ready -= __popcll(__ballot(take));
-                SOC_WAVE_FENCE();
-                SOC_POOL_PUSH(take, s, mold);
-            }
-        }
-        SOC_PROF_T(3);                                     // exchange
-        // ---- deferred Index(): all lanes, each with a CLIMB packet of its own or a borrowed one ----
-        if (((n_climb + held_climb) >= 64) || ((n_ready < LOW) && ((n_climb + held_climb) > 0))) {
-            SOC_PROF(2, 1);  SOC_PROF(3, min(64, n_climb + held_climb));
-            const bool holds = (mode == SOC_PM_CLIMB);
-            const unsigned long long mo = __ballot(!holds);
-            const int  rk = SOC_RANK(mo);
-            const bool borrow = !holds && (rk < n_climb);
-            const int  s = borrow ? cq[n_climb - 1 - rk] : 0;
-            SOC_WAVE_FENCE();
-            if (borrow) { SOC_POOL_TRADE(s);  SOC_POOL_DERIVE(); }             // own packet (whatever its state) parks in s
-            n_climb -= __popcll(__ballot(borrow));
-            if (holds | borrow) {
-                slot0 = slot;
-                r = soc_lt_step(sD, KB, NX, NY, NZ, sThr[level], A.sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
-                lsc = soc_lt_pow2(-level);
-                SOC_POOL_OUTCOME();
-            }
-            const int mnew = mode;
-            SOC_WAVE_FENCE();
-            if (borrow) { SOC_POOL_TRADE(s);  SOC_POOL_DERIVE(); }             // the served packet stays in s, the lane's own comes back
-            SOC_WAVE_FENCE();
-            SOC_POOL_PUSH(borrow, s, mnew);
-        }
-        SOC_PROF_T(2);                                     // climb
-        // ---- store / fetch: all lanes; each stores one OUT packet (its own or a borrowed one) and places the packet
-        //      it has fetched -- into its registers if they are free, else into the slot it borrowed, else into a free slot
-        {
-            const int  heldo = __popcll(__ballot(mode == SOC_PM_OUT));
-            const bool nostep = (__ballot(mode == SOC_PM_STEP) == 0ull) && (n_ready == 0);
-            const bool room = (__ballot(mode == SOC_PM_EMPTY) != 0ull) || (n_free > 0);
-            if (((n_out + heldo) >= 64) || ((n_ready < LOW) && ((n_out + heldo) > 0)) || (nostep && pipe && room && ((n_climb + __popcll(__ballot(mode == SOC_PM_CLIMB))) == 0))
-                || (pipe && (n_free >= 16) && (n_ready < LOW))) {
-                SOC_PROF(4, 1);  SOC_PROF(5, min(64, n_out + heldo));
-                asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed
-                const bool holds = (mode == SOC_PM_OUT);
-                // lanes without an OUT packet of their own: first the OUT slots, then (if they have fetched a packet and
-                // cannot keep it in their registers) the free slots
-                const unsigned long long mo = __ballot(!holds);
-                const int  rk = SOC_RANK(mo);
-                const bool borrow = !holds && (rk < n_out);
-                const unsigned long long mfw = __ballot(!holds && !borrow && nhave && (mode != SOC_PM_EMPTY));
-                const int  rkf = SOC_RANK(mfw);
-                const bool usefree = !holds && !borrow && nhave && (mode != SOC_PM_EMPTY) && (rkf < n_free);
-                const int  s = borrow ? oq[n_out - 1 - rk] : (usefree ? fq[n_free - 1 - rkf] : 0);
-                SOC_WAVE_FENCE();
-                if (borrow | usefree) { SOC_POOL_TRADE(s); }                    // (a free slot's content is garbage: mode is set below)
-                n_out -= __popcll(__ballot(borrow));
-                n_free -= __popcll(__ballot(usefree));
-                if (usefree) mode = SOC_PM_EMPTY;
-                const bool outgoing = holds | borrow;
-                if (outgoing) {
-                    if (key < 0) key = qbase + A.rbrick[-1 - key];
-                    SocPk2 *q = pk + wid;
-                    soc_st4(&q->A, make_float4(px, py, pz, photons));
-                    soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
-                    q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
-                    q->D.w = dw;
-                    SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + cslot]);
-                    mode = SOC_PM_EMPTY;
-                }
-                // the fetched packet goes where there is room: the registers are free for lanes that stored, borrowed a free
-                // slot or had no packet
-                const bool place = nhave && (mode == SOC_PM_EMPTY);
-                if (place) {
-                    wid = nwid;  cslot = nslot;
-                    dz = ndzw.x;  dw = ndzw.y;
-                    px = na.x;  py = na.y;  pz = na.z;  photons = na.w;
-                    ux = nb.x;  uy = nb.y;  uz = nb.z;  free_path = nb.w;
-                    rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
-                    tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = __float_as_int(nc.w);
-                    level = (int)(dz >> 29);
-                    lq = 0;
-                    for (int j = 1; j < nl; j++) lq += (wid >= A.first[j]) ? 1 : 0;
-                    nvisit = 0;  key = 0;
-                    mode = SOC_PM_STEP;
-                    if (dw & SOC_LT_ARRIVE) {
-                        dw &= ~SOC_LT_ARRIVE;
-                        slot = -1;
-                        mode = SOC_PM_CLIMB;
-                        if (level == 0) {
-                            const int ix = (int)soc_floorf(px), iy = (int)soc_floorf(py), iz = (int)soc_floorf(pz);
-                            const int s2 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
-                            const float rec = sD[s2];
-                            if (rec > 0.0f) { slot = s2;  cx = ix;  cy = iy;  cz = iz;  mode = SOC_PM_STEP; }
-                        }
-                    } else if (level == 0) {
-                        slot = ((cz - KB.z0) * KB.by + (cy - KB.y0)) * KB.bx + (cx - KB.x0);
-                    } else if (!soc_lt_place(sD, KB, level, cx, cy, cz, slot, dens)) {
-                        mode = SOC_PM_OUT;  key = NQ - 1;                     // cannot happen: retire rather than walk off the tree
-                    }
-                    SOC_POOL_DERIVE();
-                }
-                const int mnew = mode;
-                SOC_WAVE_FENCE();
-                if (borrow | usefree) { SOC_POOL_TRADE(s);  SOC_POOL_DERIVE(); }   // the slot keeps the new packet (or nothing), the lane's own comes back
-                SOC_WAVE_FENCE();
-                SOC_POOL_PUSH(borrow | usefree, s, mnew);
-                // the pipeline moves on for lanes whose fetched packet has been placed (or that had none)
-                const bool adv = place | !nhave;
-                if (adv) {
-                    nhave = nnhave;
-                    nwid = nnwid;  nslot = nnslot;
-                    if (nhave) {
-                        const SocPk2 *q = pk + nwid;
-                        na = SOC_NT_LOAD((const soc_f4v *)&q->A);  nb = SOC_NT_LOAD((const soc_f4v *)&q->B);  nc = SOC_NT_LOAD((const soc_f4v *)&q->C);
-                        ndzw = *(const soc_u2v *)&q->D.z;
-                    }
-                }
-                {
-                    const unsigned long long am = __ballot(adv);
-                    const int rank = SOC_RANK(am);
-                    int base = 0;
-                    if (adv && (rank == 0)) base = atomicAdd(&sCtl[0], __popcll(am));
-                    if (am != 0ull) {
-                        const int b0 = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
-                        if (adv) { nnslot = b0 + rank;  nnhave = nnslot < D.count; }
-                        src_done = (b0 + __popcll(am)) >= D.count;
-                    }
-                    if (adv && nnhave) nnwid = SOC_NT_LOAD(&A.idq[D.start + nnslot]);
-                }
-            }
-        }
-        SOC_PROF_T(0);                                     // store / fetch
-        if ((__ballot(mode != SOC_PM_EMPTY) == 0ull) && (n_ready == 0) && (n_out == 0) && (n_climb == 0) && src_done && (__ballot(nhave | nnhave) == 0ull)) break;
-        if (++guard > (1 << 26)) break;                     // (never reached: every turn of the loop steps, serves or fetches)
-        // ---- one cell step (kernel_ASOC.c:565-683): the code of the form above ----
-        if (mode == SOC_PM_STEP) {
-            const int   level0 = level;
-            const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-            slot0 = slot;
-            float fx, fy, fz;
-            if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
-                fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
-            } else {
-                fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
-            }
-            const float ax = soc_div_by_rcp(gx - fx, ux, rux);
-            const float ay = soc_div_by_rcp(gy - fy, uy, ruy);
-            const float az = soc_div_by_rcp(gz - fz, uz, ruz);
-            float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
-            px += ds * ux;
-            py += ds * uy;
-            pz += ds * uz;
-            ds = ds * lsc;
-            const float tauA = ds * d0 * kabs;
-            const float dtau = ds * d0 * ksca;
-            if (free_path < (tau + dtau)) {
-                px = p0x;  py = p0y;  pz = p0z;
-                mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq + 1;              // -> scattering queue of its launch
-            } else {
-                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
-                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[slot0], delta * tw);
-                if (WINT) atomicAdd(&sI[slot0], delta);
-                n_tally++;
-                photons *= e;
-                tau += dtau;
-                r = SOC_LT_SLOW + 1;
-                if ((A.slow_every > 0) && (level0 > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
-                    r = SOC_LT_SLOW;
-                } else {
-                    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
-                    const int   ix = (int)flx, iy = (int)fly, iz = (int)flz;
-                    const bool  sib = (level0 > 0) && (((ix | iy | iz) & ~1) == 0);
-                    bool root = (level0 == 0);
-                    Rx = ix;  Ry = iy;  Rz = iz;
-                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, A.lt_thr[1])) {
-                        Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
-                        root = true;
-                    }
-                    if (root) {
-                        const bool out = (level0 == 0) ? !((px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ))
-                                                       : (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ));
-                        const int rx = Rx - KB.x0, ry = Ry - KB.y0, rz = Rz - KB.z0;
-                        if (out) {
-                            r = SOC_LT_EXIT;
-                        } else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) {
-                            r = SOC_LT_LEAVE;
-                        } else {
-                            const int   s2 = (rz * KB.by + ry) * KB.bx + rx;
-                            const float rec = sD[s2];
-                            if (rec > 0.0f) {
-                                if (level0 == 1) {
-                                    px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
-                                    level = 0;  lsc = 1.0f;
-                                }
-                                slot = s2;  dens = rec;  cx = Rx;  cy = Ry;  cz = Rz;  r = SOC_LT_INSIDE;
-                            } else if (!A.lean_step && (level0 == 0)) {
-                                const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
-                                const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
-                                const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
-                                const float rec3 = sD[s3];
-                                if (rec3 > 0.0f) {
-                                    px = hx;  py = hy;  pz = hz;
-                                    level = 1;  lsc = 0.5f;
-                                    slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
-                                }
-                            }
-                        }
-                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
-                        const int   s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
-                        const float rec = sD[s2];
-                        if (rec > 0.0f) { slot = s2;  dens = rec;  cx = (cx & ~1) + ix;  cy = (cy & ~1) + iy;  cz = (cz & ~1) + iz;  r = SOC_LT_INSIDE; }
-                    }
-                }
-                if (r > SOC_LT_SLOW) mode = SOC_PM_CLIMB;                       // not settled here: soc_lt_step, later
-                else SOC_POOL_OUTCOME();
-            }
-        }
-        SOC_PROF_T(1);                                     // step
-    }
-    SOC_PROF_FLUSH;
-#undef SOC_PF
-#undef SOC_POOL_WRITE
-#undef SOC_POOL_READ
-#undef SOC_POOL_DERIVE
-#undef SOC_POOL_TRADE
-#undef SOC_POOL_PUSH
-#undef SOC_POOL_OUTCOME
-
-    atomicAdd(&sCtl[1], (int)n_tally);
-    __syncthreads();
-    {
-        const int *cells = A.bcell + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
-            const float v = sT[i];
-            const float vi = WINT ? sI[i] : 0.0f;
-            if (v != 0.0f || vi != 0.0f) {
-                const int cell = cells[i];
-                soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);
-            }
-        }
-    }
-    for (int j = threadIdx.x; j < D.count; j += nthr)
-        A.posq[D.start + j] = soc_qh_rank(sH, A.HS, (int)A.keyq[D.start + j], A.hist);
-    __syncthreads();
-    soc_qh_bases(sH, A.HS, NQ, A.hist);
-    __syncthreads();
-    for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, A.posq[D.start + j]);
-    if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
-}
-
-// ---------------------------------------------------------------------------------------
-// The pooled walk with ONE pool per workgroup (A.spool slots, a power of two; tuning "shared_pool"): READY, OUT and
-// free slots on three rings in LDS shared by the waves (one atomic per wave and ring operation; entries carry slot + 1
-// so that a reader can tell a reserved entry from a written one).  The store / fetch arm is run, 64 lanes at a time, by
-// whichever wave finds 64 OUT packets waiting -- so it runs with full lanes although a wave by itself produces a
-// handful of leaving packets per iteration -- and 128 slots for the workgroup cost 11 KB of LDS instead of the 80 KB of
-// per-wave pools.  The deferred Index() stays with the lane (as in soc_lbrick_walk).  Every wait on another wave is
-// bounded (the error word A.stats-side is checked by the tests through the event counts).
-// ---------------------------------------------------------------------------------------
-template <bool WINT, int KIND>
-__device__ __forceinline__ void soc_lbrick_walk_spool(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
-{
-    constexpr bool CL = (KIND == 2);
-    if (bid >= *A.ndesc) return;
-    SocDesc D = A.desc[bid];
-    D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
-    if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
-    const int BV = A.CAP;
-    const int nthr = (int)blockDim.x;
-    const int NSW = A.spool;
-    SocPk2 *pk = A.pk;
-
-    extern __shared__ float lds[];
-    float *sT   = lds;
-    float *sI   = sT + BV;
-    float *sD   = sI + (WINT ? BV : 0);
-    const int NQ = A.NBQ + A.EQ * A.nl + 1;
-    int   *sH   = (int *)(sD + BV);
-    int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));
-    float *sL   = (float *)(sCtl + 4);
-    float *sThr = sL + 3 * SOC_MAXLAUNCH;
-    uint32_t *sFirst = (uint32_t *)(sThr + SOC_MAXL) + 3;
-    float *sPool = (float *)(sFirst + SOC_MAXLAUNCH + 1);   // per wave: NF * NSW packet fields, then 4 * NSW list entries
-    const SocSim &S = K.S[0];
-    if ((int)threadIdx.x < K.n) {
-        sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
-    }
-    if (threadIdx.x < SOC_MAXL) sThr[threadIdx.x] = A.lt_thr[threadIdx.x];
-    if (threadIdx.x <= SOC_MAXLAUNCH) sFirst[threadIdx.x] = ((int)threadIdx.x < A.nl) ? K.first[threadIdx.x] : 0xffffffffu;
-    const int mybrick = (A.NBQ > A.NB) ? (D.brick % A.NB) : D.brick;
-    const int qbase = D.brick - mybrick;
-    const int nl = A.nl;
-    SocLBrick KB = A.lbr[mybrick];
-    KB.x0 = __builtin_amdgcn_readfirstlane(KB.x0);  KB.y0 = __builtin_amdgcn_readfirstlane(KB.y0);  KB.z0 = __builtin_amdgcn_readfirstlane(KB.z0);
-    KB.bx = __builtin_amdgcn_readfirstlane(KB.bx);  KB.by = __builtin_amdgcn_readfirstlane(KB.by);  KB.bz = __builtin_amdgcn_readfirstlane(KB.bz);
-    KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
-    {
-        const float *src = A.btree + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
-    }
-    soc_qh_init(sH, A.HS, NQ);
-    if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    (void)wave;
-    float *pool = sPool;                                   // one pool for the workgroup: NF * NSW fields, three rings, their control words
-    int   *rq = (int *)(pool + SOC_POOL_NF * NSW), *oq = rq + NSW, *fq = oq + NSW;
-    int   *rc = fq + NSW, *oc = rc + 4, *fc = oc + 4, *serr = fc + 4;      // per ring: [0] tail, [1] head, [2] entries that can be taken
-    const int RM = NSW - 1;                                // (NSW is a power of two)
-    for (int i = threadIdx.x; i < NSW; i += nthr) { rq[i] = 0;  oq[i] = 0;  fq[i] = i + 1; }   // an entry holds slot + 1; 0 = not written yet
-    if (threadIdx.x < 13) rc[threadIdx.x] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) { fc[0] = NSW;  fc[2] = NSW; }
-    __syncthreads();
-
-    const int   NX = G.NX, NY = G.NY, NZ = G.NZ;
-    const float fNX = (float)G.NX, fNY = (float)G.NY, fNZ = (float)G.NZ;
-    // the packet in the lane's registers
-    float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 1.0f, uy = 1.0f, uz = 1.0f, rux = 1.0f, ruy = 1.0f, ruz = 1.0f;
-    float photons = 0.0f, free_path = 0.0f, tau = 0.0f;
-    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;
-    uint32_t dz = 0, dw = 0, wid = 0;
-    int   mode = SOC_PM_EMPTY;
-    // derived from it
-    float dens = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f, lsc = 1.0f, kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
-    // the lane's fetch pipeline
-    bool  nhave = false, nnhave = false;
-    soc_f4v na = { 0.0f, 0.0f, 0.0f, 0.0f }, nb = na, nc = na;
-    soc_u2v ndzw = { 0u, 0u };
-    uint32_t nwid = 0, nnwid = 0;
-    int   nslot = 0, nnslot = 0;
-    bool  src_done = false;                                                  // the last reservation ran past the end of the chunk
-    unsigned int n_tally = 0;
-    int   r = SOC_LT_SLOW + 2, Rx = 0, Ry = 0, Rz = 0, slot0 = 0;
-
-    // registers <-> slot s: the 22 fields of a packet
-#define SOC_PF(i)  pool[(i) * NSW + ps_]
-#define SOC_POOL_PACK_LS   ((uint32_t)(slot & 0xffff) | ((uint32_t)level << 16) | ((uint32_t)nvisit << 20))
-#define SOC_POOL_PACK_CQ   ((uint32_t)cslot | ((uint32_t)lq << 16))
-#define SOC_POOL_WRITE(s_) do { const int ps_ = (s_); \
-        SOC_PF(0) = px;  SOC_PF(1) = py;  SOC_PF(2) = pz;  SOC_PF(3) = ux;  SOC_PF(4) = uy;  SOC_PF(5) = uz;  SOC_PF(6) = rux;  SOC_PF(7) = ruy;  SOC_PF(8) = ruz; \
-        SOC_PF(9) = photons;  SOC_PF(10) = free_path;  SOC_PF(11) = tau;  SOC_PF(12) = __int_as_float(cx);  SOC_PF(13) = __int_as_float(cy);  SOC_PF(14) = __int_as_float(cz); \
-        SOC_PF(15) = __uint_as_float(SOC_POOL_PACK_LS);  SOC_PF(16) = __uint_as_float(dz);  SOC_PF(17) = __uint_as_float(dw);  SOC_PF(18) = __uint_as_float(wid); \
-        SOC_PF(19) = __uint_as_float(SOC_POOL_PACK_CQ);  SOC_PF(20) = __int_as_float(key);  SOC_PF(21) = __int_as_float(mode); } while (0)
-#define SOC_POOL_READ(s_) do { const int ps_ = (s_); \
-        px = SOC_PF(0);  py = SOC_PF(1);  pz = SOC_PF(2);  ux = SOC_PF(3);  uy = SOC_PF(4);  uz = SOC_PF(5);  rux = SOC_PF(6);  ruy = SOC_PF(7);  ruz = SOC_PF(8); \
-        photons = SOC_PF(9);  free_path = SOC_PF(10);  tau = SOC_PF(11);  cx = __float_as_int(SOC_PF(12));  cy = __float_as_int(SOC_PF(13));  cz = __float_as_int(SOC_PF(14)); \
-        { const uint32_t ls_ = __float_as_uint(SOC_PF(15));  slot = (int)(ls_ & 0xffffu);  if (slot == 0xffff) slot = -1;  level = (int)((ls_ >> 16) & 15u);  nvisit = (int)(ls_ >> 20); } \
-        dz = __float_as_uint(SOC_PF(16));  dw = __float_as_uint(SOC_PF(17));  wid = __float_as_uint(SOC_PF(18)); \
-        { const uint32_t cq_ = __float_as_uint(SOC_PF(19));  cslot = (int)(cq_ & 0xffffu);  lq = (int)(cq_ >> 16); } \
-        key = __float_as_int(SOC_PF(20));  mode = __float_as_int(SOC_PF(21)); } while (0)
-    // what a packet's fields imply (after SOC_POOL_READ or after the record has been decoded)
-#define SOC_POOL_DERIVE() do { \
-        gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS; \
-        lsc = soc_lt_pow2(-level);  kabs = sL[3 * lq];  ksca = sL[3 * lq + 1];  tw = sL[3 * lq + 2]; \
-        dens = (slot >= 0) ? sD[slot] : 0.0f; } while (0)
-    // trade the registers' packet for the one in slot s (the slot's packet may be garbage when the caller says so)
-#define SOC_POOL_TRADE(s_) do { \
-        const float a0 = px, a1 = py, a2 = pz, a3 = ux, a4 = uy, a5 = uz, a6 = rux, a7 = ruy, a8 = ruz, a9 = photons, a10 = free_path, a11 = tau; \
-        const int   b0 = cx, b1 = cy, b2 = cz, b5 = key, b6 = mode; \
-        const uint32_t c0 = SOC_POOL_PACK_LS, c1 = dz, c2 = dw, c3 = wid, c4 = SOC_POOL_PACK_CQ; \
-        SOC_POOL_READ(s_); \
-        { const int ps_ = (s_); \
-          SOC_PF(0) = a0;  SOC_PF(1) = a1;  SOC_PF(2) = a2;  SOC_PF(3) = a3;  SOC_PF(4) = a4;  SOC_PF(5) = a5;  SOC_PF(6) = a6;  SOC_PF(7) = a7;  SOC_PF(8) = a8; \
-          SOC_PF(9) = a9;  SOC_PF(10) = a10;  SOC_PF(11) = a11;  SOC_PF(12) = __int_as_float(b0);  SOC_PF(13) = __int_as_float(b1);  SOC_PF(14) = __int_as_float(b2); \
-          SOC_PF(15) = __uint_as_float(c0);  SOC_PF(16) = __uint_as_float(c1);  SOC_PF(17) = __uint_as_float(c2);  SOC_PF(18) = __uint_as_float(c3); \
-          SOC_PF(19) = __uint_as_float(c4);  SOC_PF(20) = __int_as_float(b5);  SOC_PF(21) = __int_as_float(b6); } } while (0)
-    // ---- rings shared by the waves of the workgroup (slot ids; every slot is on exactly one ring or in a lane's hands) ----
-    // push: the lanes of `on_` append v_ (a slot id).  One atomic on the tail per wave, entries written, then published.
-#define SOC_RING_PUSH(buf_, ctl_, on_, v_) do { \
-        const unsigned long long mp_ = __ballot(on_); \
-        if (mp_ != 0ull) { \
-            const int np_ = __popcll(mp_), rp_ = SOC_RANK(mp_); \
-            int bp_ = 0; \
-            if ((on_) && (rp_ == 0)) bp_ = atomicAdd(&(ctl_)[0], np_); \
-            bp_ = __builtin_amdgcn_readlane(bp_, __builtin_ctzll(mp_)); \
-            if (on_) ((volatile int *)(buf_))[(bp_ + rp_) & RM] = (v_) + 1; \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-            if ((on_) && (rp_ == 0)) atomicAdd(&(ctl_)[2], np_); \
-        } } while (0)
-    // pop: the lanes of `on_` ask for one entry each; the first got_ of them (by lane) receive v_ (others keep -1).
-    // Entries are claimed from the count of published ones; the position claimed may belong to a push that is still
-    // being written (an earlier reservation that publishes later): the short wait for it is bounded.
-#define SOC_RING_POP(buf_, ctl_, on_, v_, got_) do { \
-        const unsigned long long mq_ = __ballot(on_); \
-        (got_) = 0;  (v_) = -1; \
-        if (mq_ != 0ull) { \
-            const int nq_ = __popcll(mq_), rq_ = SOC_RANK(mq_); \
-            int tk_ = 0, bq_ = 0; \
-            if ((on_) && (rq_ == 0)) { \
-                for (int try_ = 0; try_ < 64; try_++) { \
-                    const int av_ = ((volatile int *)(ctl_))[2]; \
-                    const int t_ = min(av_, nq_); \
-                    if (t_ <= 0) break; \
-                    if (atomicCAS(&(ctl_)[2], av_, av_ - t_) == av_) { tk_ = t_;  break; } \
-                } \
-                if (tk_ > 0) bq_ = atomicAdd(&(ctl_)[1], tk_); \
-            } \
-            tk_ = __builtin_amdgcn_readlane(tk_, __builtin_ctzll(mq_));  bq_ = __builtin_amdgcn_readlane(bq_, __builtin_ctzll(mq_)); \
-            (got_) = tk_; \
-            if ((on_) && (rq_ < tk_)) { \
-                volatile int *e_ = (volatile int *)(buf_) + ((bq_ + rq_) & RM); \
-                int x_ = 0; \
-                for (int spin_ = 0; spin_ < (1 << 20); spin_++) { x_ = *e_;  if (x_ != 0) break;  __builtin_amdgcn_s_sleep(1); } \
-                if (x_ == 0) { *serr = 1;  x_ = 1; } \
-                *e_ = 0; \
-                (v_) = x_ - 1; \
-            } \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
-        } } while (0)
-#define SOC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
-#define SOC_RANK(m_) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u)))
-    // the outcome r of Index() for the packet in the registers (the block that follows the arms in the form above)
-#define SOC_POOL_OUTCOME() do { \
-        if (r == SOC_LT_INSIDE) { \
-            if (!CL && (slot == slot0)) { px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz; } \
-            nvisit++;  mode = SOC_PM_STEP; \
-            if (nvisit >= A.KCAP) { mode = SOC_PM_OUT;  key = D.brick; } \
-        } else if (r == SOC_LT_LEAVE) { \
-            mode = SOC_PM_OUT;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;     /* the brick of that root cell is looked up when the packet is stored */ \
-        } else if (r == SOC_LT_EXIT) { \
-            mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq; \
-        } else { \
-            mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE; \
-        } } while (0)
-
-    const int XTH = (A.FTH > 0 && A.FTH < 64) ? A.FTH : 4; // lanes asking before the exchange arm is entered
-    int guard = 0;
-    while (true) {
-        const int a_ready = ((volatile int *)rc)[2], a_out = ((volatile int *)oc)[2], a_free = ((volatile int *)fc)[2];
-        const bool nobody = (__ballot((mode == SOC_PM_STEP) | (mode == SOC_PM_CLIMB)) == 0ull);
-        const bool pipe = (__ballot(nhave | nnhave) != 0ull) || !src_done;
-        // ---- exchange: lanes without a packet to step take READY ones; a packet that leaves stays behind in the slot ----
-        {
-            const bool want = (mode == SOC_PM_OUT) | (mode == SOC_PM_EMPTY);
-            const unsigned long long mw = __ballot(want);
-            const unsigned long long mo_ = __ballot(mode == SOC_PM_OUT);
-            if (((a_ready > 0) || ((a_free > 0) && (mo_ != 0ull))) && ((__popcll(mw) >= XTH) || (nobody && (mw != 0ull)))) {
-                int s = -1, got = 0;
-                SOC_RING_POP(rq, rc, want, s, got);
-                const bool take = want && (s >= 0);
-                const int  mold = mode;
-                if (take) {
-                    if (mold == SOC_PM_EMPTY) { SOC_POOL_READ(s); } else { SOC_POOL_TRADE(s); }
-                    SOC_POOL_DERIVE();
-                }
-                SOC_RING_PUSH(oq, oc, take && (mold == SOC_PM_OUT), s);
-                SOC_RING_PUSH(fq, fc, take && (mold == SOC_PM_EMPTY), s);
-                // a leaving packet that found no READY one to trade with moves into a free slot (the lane waits empty)
-                const bool dump = (mode == SOC_PM_OUT) && !take;
-                int s2 = -1, got2 = 0;
-                SOC_RING_POP(fq, fc, dump, s2, got2);
-                if (dump && (s2 >= 0)) { SOC_POOL_WRITE(s2);  mode = SOC_PM_EMPTY; }
-                SOC_RING_PUSH(oq, oc, dump && (s2 >= 0), s2);
-                (void)got;  (void)got2;
-            }
-        }
-        // ---- store / fetch, 64 lanes at a time, by whichever wave finds the work: each lane takes one OUT slot, parks its own
-        //      packet there while it serves the slot's packet in its registers, and trades back ----
-        {
-            const bool starving = (a_ready == 0) && (__popcll(__ballot(mode == SOC_PM_EMPTY)) >= 16) && (a_out >= 8);
-            const bool room = (__ballot(mode == SOC_PM_EMPTY) != 0ull) || (a_free > 0);
-            if ((a_out >= 64) || starving || (nobody && (a_out > 0)) || (nobody && pipe && room) || (pipe && (a_free >= 32) && (a_ready < 16))) {
-                asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed
-                int s = -1, got = 0;
-                SOC_RING_POP(oq, oc, true, s, got);
-                const bool outgoing = (s >= 0);
-                // lanes without an OUT slot that have fetched a packet but hold one already: a free slot for the fetched one
-                const bool wantfree = !outgoing && nhave && (mode != SOC_PM_EMPTY);
-                int s2 = -1, got2 = 0;
-                SOC_RING_POP(fq, fc, wantfree, s2, got2);
-                const bool usefree = wantfree && (s2 >= 0);
-                if (usefree) s = s2;
-                const bool borrow = outgoing | usefree;
-                if (borrow) { SOC_POOL_TRADE(s); }                              // own packet (whatever its state) parks in s
-                if (usefree) mode = SOC_PM_EMPTY;                               // (a free slot held nothing)
-                if (outgoing) {
-                    if (key < 0) key = qbase + A.rbrick[-1 - key];
-                    SocPk2 *q = pk + wid;
-                    soc_st4(&q->A, make_float4(px, py, pz, photons));
-                    soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
-                    q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
-                    q->D.w = dw;
-                    SOC_NT_STORE((uint32_t)key, &A.keyq[D.start + cslot]);
-                    mode = SOC_PM_EMPTY;
-                }
-                const bool place = nhave && (mode == SOC_PM_EMPTY);
-                if (place) {
-                    wid = nwid;  cslot = nslot;
-                    dz = ndzw.x;  dw = ndzw.y;
-                    px = na.x;  py = na.y;  pz = na.z;  photons = na.w;
-                    ux = nb.x;  uy = nb.y;  uz = nb.z;  free_path = nb.w;
-                    rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
-                    tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = __float_as_int(nc.w);
-                    level = (int)(dz >> 29);
-                    lq = 0;
-                    for (int j = 1; j < nl; j++) lq += (wid >= A.first[j]) ? 1 : 0;
-                    nvisit = 0;  key = 0;
-                    mode = SOC_PM_STEP;
-                    if (dw & SOC_LT_ARRIVE) {
-                        dw &= ~SOC_LT_ARRIVE;
-                        slot = -1;
-                        mode = SOC_PM_CLIMB;
-                        if (level == 0) {
-                            const int ix = (int)soc_floorf(px), iy = (int)soc_floorf(py), iz = (int)soc_floorf(pz);
-                            const int s3 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
-                            const float rec = sD[s3];
-                            if (rec > 0.0f) { slot = s3;  cx = ix;  cy = iy;  cz = iz;  mode = SOC_PM_STEP; }
-                        }
-                    } else if (level == 0) {
-                        slot = ((cz - KB.z0) * KB.by + (cy - KB.y0)) * KB.bx + (cx - KB.x0);
-                    } else if (!soc_lt_place(sD, KB, level, cx, cy, cz, slot, dens)) {
-                        mode = SOC_PM_OUT;  key = NQ - 1;                     // cannot happen: retire rather than walk off the tree
-                    }
-                    SOC_POOL_DERIVE();
-                }
-                const int mnew = mode;
-                if (borrow) { SOC_POOL_TRADE(s);  SOC_POOL_DERIVE(); }          // the slot keeps the new packet (or nothing), the lane's own comes back
-                SOC_RING_PUSH(rq, rc, borrow && ((mnew == SOC_PM_STEP) | (mnew == SOC_PM_CLIMB)), s);
-                SOC_RING_PUSH(fq, fc, borrow && (mnew == SOC_PM_EMPTY), s);
-                SOC_RING_PUSH(oq, oc, borrow && (mnew == SOC_PM_OUT), s);
-                const bool adv = place | !nhave;
-                if (adv) {
-                    nhave = nnhave;
-                    nwid = nnwid;  nslot = nnslot;
-                    if (nhave) {
-                        const SocPk2 *q = pk + nwid;
-                        na = SOC_NT_LOAD((const soc_f4v *)&q->A);  nb = SOC_NT_LOAD((const soc_f4v *)&q->B);  nc = SOC_NT_LOAD((const soc_f4v *)&q->C);
-                        ndzw = *(const soc_u2v *)&q->D.z;
-                    }
-                }
-                {
-                    const unsigned long long am = __ballot(adv);
-                    const int rank = SOC_RANK(am);
-                    int base = 0;
-                    if (adv && (rank == 0)) base = atomicAdd(&sCtl[0], __popcll(am));
-                    if (am != 0ull) {
-                        const int b0 = __builtin_amdgcn_readlane(base, __builtin_ctzll(am));
-                        if (adv) { nnslot = b0 + rank;  nnhave = nnslot < D.count; }
-                        src_done = (b0 + __popcll(am)) >= D.count;
-                    }
-                    if (adv && nnhave) nnwid = SOC_NT_LOAD(&A.idq[D.start + nnslot]);
-                }
-                (void)got;  (void)got2;
-            }
-        }
-        // a wave leaves when it holds nothing, fetches nothing and sees nothing waiting (what other waves still hold, they serve)
-        if ((__ballot(mode != SOC_PM_EMPTY) == 0ull) && src_done && (__ballot(nhave | nnhave) == 0ull)
-            && (((volatile int *)rc)[2] == 0) && (((volatile int *)oc)[2] == 0)) break;
-        if (++guard > (1 << 24)) { *serr = 2;  break; }
-        // ---- one cell step (kernel_ASOC.c:565-683): the code of the form above ----
-        if (mode == SOC_PM_STEP) {
-            const int   level0 = level;
-            const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-            slot0 = slot;
-            float fx, fy, fz;
-            if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
-                fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
-            } else {
-                fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
-            }
-            const float ax = soc_div_by_rcp(gx - fx, ux, rux);
-            const float ay = soc_div_by_rcp(gy - fy, uy, ruy);
-            const float az = soc_div_by_rcp(gz - fz, uz, ruz);
-            float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
-            px += ds * ux;
-            py += ds * uy;
-            pz += ds * uz;
-            ds = ds * lsc;
-            const float tauA = ds * d0 * kabs;
-            const float dtau = ds * d0 * ksca;
-            if (free_path < (tau + dtau)) {
-                px = p0x;  py = p0y;  pz = p0z;
-                mode = SOC_PM_OUT;  key = A.NBQ + A.EQ * lq + 1;              // -> scattering queue of its launch
-            } else {
-                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
-                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[slot0], delta * tw);
-                if (WINT) atomicAdd(&sI[slot0], delta);
-                n_tally++;
-                photons *= e;
-                tau += dtau;
-                r = SOC_LT_SLOW + 1;
-                if ((A.slow_every > 0) && (level0 > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
-                    r = SOC_LT_SLOW;
-                } else {
-                    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
-                    const int   ix = (int)flx, iy = (int)fly, iz = (int)flz;
-                    const bool  sib = (level0 > 0) && (((ix | iy | iz) & ~1) == 0);
-                    bool root = (level0 == 0);
-                    Rx = ix;  Ry = iy;  Rz = iz;
-                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, A.lt_thr[1])) {
-                        Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
-                        root = true;
-                    }
-                    if (root) {
-                        const bool out = (level0 == 0) ? !((px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ))
-                                                       : (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ));
-                        const int rx = Rx - KB.x0, ry = Ry - KB.y0, rz = Rz - KB.z0;
-                        if (out) {
-                            r = SOC_LT_EXIT;
-                        } else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) {
-                            r = SOC_LT_LEAVE;
-                        } else {
-                            const int   s2 = (rz * KB.by + ry) * KB.bx + rx;
-                            const float rec = sD[s2];
-                            if (rec > 0.0f) {
-                                if (level0 == 1) {
-                                    px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
-                                    level = 0;  lsc = 1.0f;
-                                }
-                                slot = s2;  dens = rec;  cx = Rx;  cy = Ry;  cz = Rz;  r = SOC_LT_INSIDE;
-                            } else if (!A.lean_step && (level0 == 0)) {
-                                const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
-                                const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
-                                const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
-                                const float rec3 = sD[s3];
-                                if (rec3 > 0.0f) {
-                                    px = hx;  py = hy;  pz = hz;
-                                    level = 1;  lsc = 0.5f;
-                                    slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
-                                }
-                            }
-                        }
-                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
-                        const int   s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
-                        const float rec = sD[s2];
-                        if (rec > 0.0f) { slot = s2;  dens = rec;  cx = (cx & ~1) + ix;  cy = (cy & ~1) + iy;  cz = (cz & ~1) + iz;  r = SOC_LT_INSIDE; }
-                    }
-                }
-                if (r > SOC_LT_SLOW) mode = SOC_PM_CLIMB;                       // not settled here: soc_lt_step, later
-                else SOC_POOL_OUTCOME();
-            }
-        }
-
-        {
-            const unsigned long long mc = __ballot(mode == SOC_PM_CLIMB);
-            if (mc != 0ull && ((__popcll(mc) >= A.CTH) || (__ballot(mode == SOC_PM_STEP) == 0ull))) {
-                if (mode == SOC_PM_CLIMB) {
-                    slot0 = slot;
-                    r = soc_lt_step(sD, KB, NX, NY, NZ, sThr[level], A.sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
-                    lsc = soc_lt_pow2(-level);
-                    SOC_POOL_OUTCOME();
-                }
-            }
-        }
-    }
-#undef SOC_PF
-#undef SOC_POOL_WRITE
-#undef SOC_POOL_READ
-#undef SOC_POOL_DERIVE
-#undef SOC_POOL_TRADE
-#undef SOC_RING_PUSH
-#undef SOC_RING_POP
-#undef SOC_POOL_OUTCOME
-
-    atomicAdd(&sCtl[1], (int)n_tally);
-    __syncthreads();
-    {
-        const int *cells = A.bcell + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
-            const float v = sT[i];
-            const float vi = WINT ? sI[i] : 0.0f;
-            if (v != 0.0f || vi != 0.0f) {
-                const int cell = cells[i];
-                soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);
-            }
-        }
-    }
-    for (int j = threadIdx.x; j < D.count; j += nthr)
-        A.posq[D.start + j] = soc_qh_rank(sH, A.HS, (int)A.keyq[D.start + j], A.hist);
-    __syncthreads();
-    soc_qh_bases(sH, A.HS, NQ, A.hist);
-    __syncthreads();
-    for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, A.posq[D.start + j]);
-    if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
-}
-
-
 // creation and scattering, one lane per queued packet
 template <bool OCT, bool ABU, bool WINT, int KIND, bool LT>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
@@ -2089,9 +1229,7 @@ __global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const S
     const SocSimPack &K = *Kp;
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
-        if (A.spool > 0)     soc_lbrick_walk_spool<WINT, KIND>(G, K, A, b);
-        else if (A.pool > 0) soc_lbrick_walk_pool<WINT, KIND>(G, K, A, b);
-        else            soc_lbrick_walk<WINT, KIND>(G, K, A, b);
+        soc_lbrick_walk<WINT, KIND>(G, K, A, b);
     } else {
         const int e = b - nwalk;
         soc_brick_events<true, false, WINT, KIND, true>(G, K, A, e / slices, e % slices);
@@ -2496,19 +1634,14 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             for (int l = 0; l < SOC_MAXL; l++) A.lt_thr[l] = ldexpf(1.0f, k + l - 30);
             A.slow_every = tune.slow_every;
             A.lean_step = tune.lean_step;
-            A.pool = tune.pool;
-            A.spool = 0;
-            if (tune.spool >= 64) { int n = 64;  while (2 * n <= tune.spool && n < 4096) n *= 2;  A.spool = n;  A.pool = 0; }
-            if (tune.spool > 0) { A.FTH = (tune.FTH > 0) ? tune.FTH : 4; }
             A.P = (tune.P > 0) ? tune.P : 16384;
             A.KCAP = (tune.KCAP > 0) ? tune.KCAP : 64;
             A.FTH = (tune.FTH > 0) ? tune.FTH : 16;
             A.CTH = (tune.CTH > 0) ? tune.CTH : 8;
-            if (tune.pool > 0) { A.FTH = (tune.FTH > 0) ? tune.FTH : 4;  A.CTH = (tune.CTH > 0) ? tune.CTH : 16; }   // exchange threshold, low-water mark
             A.TAIL = (tune.TAIL > 0) ? tune.TAIL : 0;
             // short brick queues wait (soc_brick_scan): 4096 = 8 packets per lane, measured on config 3 (1024 ... 16384; +5 % point source,
             // +9 % diffuse emission against no parking); soc_set_tuning("park_below", 1) = never
-            A.PARK = (A.pool || A.spool) ? 0 : ((tune.park > 0) ? tune.park : 4096);
+            A.PARK = (tune.park > 0) ? tune.park : 4096;
         } else if (e != hipErrorNotSupported) {
             return e;
         }
@@ -2621,15 +1754,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    if (A.LT && A.pool > 0) {                                          // the pools take what the brick's cells leave of the 160 KB
-        const size_t base = (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 3 * SOC_MAXLAUNCH + SOC_MAXL + 3 + SOC_MAXLAUNCH + 1) * 4;
-        const size_t per = (size_t)(A.T / 64) * (SOC_POOL_NF + 4) * 4;
-        const int fit = (base < 160 * 1024) ? (int)((160 * 1024 - base) / per) : 0;
-        if (A.pool > fit) A.pool = fit;
-        if (A.pool < 16) A.pool = 0;                                       // too few slots to be of use: the walk without pools
-    }
-    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 3 * SOC_MAXLAUNCH + SOC_MAXL + 3 + SOC_MAXLAUNCH + 1
-                                            + (A.T / 64) * (SOC_POOL_NF + 4) * A.pool + (A.spool ? (SOC_POOL_NF + 3) * A.spool + 16 : 0)) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 3 * SOC_MAXLAUNCH + SOC_MAXL + 3 + SOC_MAXLAUNCH + 1) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
@@ -2681,6 +1806,6 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (passes > 4000000) return hipErrorUnknown;                 // cannot happen: every pass retires work
     }
     if (passes_out) *passes_out = passes;
-    if (form_out) *form_out = A.LT ? (A.spool > 0 ? 5 : (A.pool > 0 ? 4 : 3)) : (V.octree ? 2 : 1);
+    if (form_out) *form_out = A.LT ? 3 : (V.octree ? 2 : 1);
     return hipSuccess;
 }

@@ -307,6 +307,9 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
             }
         }
     }
+    // refused before anything of the handle changes: a refused call leaves the old grid usable
+    if (c->have_grid && (int64_t)G.CELLS != c->G.CELLS && ((c->dTABS && !c->own_TABS) || (c->dINT && !c->own_INT)))
+        return fail(c, SOC_ERR_STATE, "soc_set_grid: a caller-owned tally of %d cells is bound; soc_bind_tally(ctx, which, NULL, 0) first, re-bind after", c->G.CELLS);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, dev_alloc(&c->dDENS, (size_t)cells));
@@ -316,8 +319,6 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
     HIPCHK(c, hipMemsetAsync(c->dPAR, 0, (size_t)(c->npar ? c->npar : 1) * 4, c->stream));
     G.DENS = c->dDENS;
     G.PAR = c->dPAR;
-    if (c->have_grid && (int64_t)G.CELLS != c->G.CELLS && ((c->dTABS && !c->own_TABS) || (c->dINT && !c->own_INT)))
-        return fail(c, SOC_ERR_STATE, "soc_set_grid: a caller-owned tally of %d cells is bound; soc_bind_tally(ctx, which, NULL, 0) first, re-bind after", c->G.CELLS);
     if ((int64_t)G.CELLS != c->G.CELLS || !c->have_grid) {
         // tallies follow the cell count
         if (c->own_TABS || !c->dTABS) { c->dTABS = nullptr; HIPCHK(c, dev_alloc(&c->dTABS, (size_t)cells)); c->own_TABS = true; HIPCHK(c, hipMemsetAsync(c->dTABS, 0, (size_t)cells * 4, c->stream)); }
@@ -327,7 +328,14 @@ int soc_set_grid(soc_ctx *c, int NX, int NY, int NZ, int LEVELS, const int32_t *
         // everything else that is sized by the cell count
         if (c->dT) { (void)hipFree(c->dT); c->dT = nullptr; }
         if (c->dXAB) { (void)hipFree(c->dXAB); c->dXAB = nullptr; }
-        if (c->dINTV) { (void)hipFree(c->dINTV); c->dINTV = nullptr;  c->intv_cells = 0;  if (c->with_int == 2) c->with_int = 1; }
+        if (c->dINTV) {                                       // INTX, INTY, INTZ follow the cell count like TABS and INT (with_int stays 2)
+            (void)hipFree(c->dINTV);  c->dINTV = nullptr;  c->intv_cells = 0;
+            if (c->with_int == 2) {
+                HIPCHK(c, dev_alloc(&c->dINTV, (size_t)3 * cells));
+                c->intv_cells = (size_t)cells;
+                HIPCHK(c, hipMemsetAsync(c->dINTV, 0, (size_t)3 * cells * 4, c->stream));
+            }
+        }
         if (c->dEMINDEX) { (void)hipFree(c->dEMINDEX); c->dEMINDEX = nullptr; }
         c->have_T = false;  c->with_ali = false;  c->have_emindex = false;
         c->abu_ndust = 0;  c->abu_cells = 0;
@@ -392,7 +400,7 @@ int soc_set_tuning(soc_ctx *c, const char *name, int value)
     struct { const char *n; int *p; } tab[] = {
         { "threads", &c->tune.T }, { "chunk", &c->tune.P }, { "steps_per_visit", &c->tune.KCAP }, { "swap_lanes", &c->tune.FTH },
         { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "park_below", &c->tune.park }, { "population", &c->tune.POP },
-        { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every }, { "lean_step", &c->tune.lean_step }, { "pool_slots", &c->tune.pool }, { "shared_pool", &c->tune.spool },
+        { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every }, { "lean_step", &c->tune.lean_step },
         { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
     for (auto &t : tab)
         if (!strcmp(name, t.n)) {

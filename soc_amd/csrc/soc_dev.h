@@ -169,8 +169,6 @@ struct SocBrickTune {
     int T, P, KCAP, FTH, CTH, CAP, TAIL, POP, HS;
     int global_tree;           // hierarchies: the walk that reads the hierarchy from global memory, also where brick-local ones apply
     int lean_step;             // brick-local hierarchies, experiment: fewer kinds of moves settled in the step arm
-    int spool;                 // brick-local hierarchies: packet slots of LDS per WORKGROUP, shared by its waves (soc_lbrick_walk_spool)
-    int pool;                  // brick-local hierarchies: packet slots of LDS per wave (soc_lbrick_walk_pool); 0 = the walk without pools
     int park;                  // brick-local hierarchies: brick queues shorter than this (and than the mean queue) wait for more packets (0 = built-in 4096, 1 = never)
     int slow_every;            // brick-local hierarchies, test knob: every n-th step below the root grid goes through the slow-step queue
     int nolean;                // keep the general SimRAM_PB kernel for background-only sweeps

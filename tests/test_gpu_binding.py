@@ -54,6 +54,14 @@ def test_bound_tallies_on_a_torch_stream(mode, engine):
             engine.bind_tally(0, tabs.data_ptr(), cl.CELLS - 1)          # wrong element count
         with pytest.raises(Exception):
             engine.set_cloud(synth.cartesian_cloud(16, seed=2))          # other cell count while a caller-owned tally is bound
+        # the refused call left the handle as it was: the old grid (densities, links, brick cache) still runs
+        engine.zero(0)
+        engine.zero(1)
+        engine.stats(reset=True)
+        engine.sim_pb(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.BG, job.TW, GLOBAL=job.GLOBAL)
+        engine.sync()
+        assert engine.stats() == s0
+        assert_tally_close(engine.read_tally(0), T0, rtol=1e-5)
     finally:
         _unbind(engine, torch)
     engine.set_exec(-1, 4)

@@ -24,16 +24,13 @@ def cloud104():
 kw_form = {}
 
 
-@pytest.fixture(autouse=True, params=[(0, 0, 0), (0, 0, 64), (0, 0, 1), (96, 0, 0), (24, 0, 0), (0, 128, 0), (0, 64, 0)],
-                ids=["lanes", "lanes_park64", "lanes_nopark", "pool96", "pool24", "shared128", "shared64"])
+@pytest.fixture(autouse=True, params=[0, 64, 1], ids=["park4096", "park64", "nopark"])
 def walk_form(request, engine):
-    """every test of this file runs on all forms of the walk: packets bound to lanes (short brick queues parked
-    until they hold 4096 = the default, 64 packets, or never), packet pools per wave, one pool per workgroup"""
-    pool, shared, park = request.param
-    engine.set_tuning(pool_slots=pool, shared_pool=shared, park_below=park)
-    kw_form["base"] = 5 if shared else (4 if pool else 3)
+    """every test of this file runs with short brick queues parked until they hold 4096 packets (the default), 64, or never"""
+    engine.set_tuning(park_below=request.param)
+    kw_form["base"] = 3
     yield
-    engine.set_tuning(pool_slots=0, shared_pool=0, park_below=0)
+    engine.set_tuning(park_below=0)
     kw_form.pop("base", None)
 
 
