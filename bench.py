@@ -13,17 +13,20 @@ reference's simulation loop (source block II x frequency IFREQ, ASOC.py:1028-146
   reference's example dust; per-frequency ABS, SCA and a Henyey-Greenstein scattering table of the row's g),
   `pspackets 1e9` from one point source at (128.3, 128.3, 128.3) (SimRAM_PB SOURCE 0, ASOC.py:1036-1044) and
   `diffpack 1e9` of diffuse emission 1e-30 * density photons/Hz/cm3 (SimRAM_CL, ASOC.py:1086-1090), noabsorbed.
-  Step i simulates frequency (i // 2) % 50; even steps are the point-source launch, odd steps the diffuse one.
-  Launch size: the reference hard-codes GLOBAL_0 = 32768 work items for both (ASOC.py:86) -- 512 wavefronts,
-  half a wavefront per SIMD of an MI355X.  The ini key `global` (parsed by the reference, ASOC_aux.py:400)
-  sets GLOBAL_0 here; the bench uses --global work items (same packets, same sources, other partition into
-  RNG streams; identical to a reference run with that GLOBAL_0).  The rate at the reference's own launch
-  shape is measured beside it on a shortened launch (config.reference_launch_shape).
+  Step i simulates frequency (21 * (i // 2) + 45) % 50 -- a stride through the whole table, so that the driver's 5 + 20
+  steps hit optically thin and thick frequencies alike (the scattering block, kernel_ASOC.c:695-815, runs in the timed
+  region); even steps are the point-source launch, odd steps the diffuse one.
+  Launch size: the reference's absorption script hard-codes GLOBAL_0 = 32768 work items for both (ASOC.py:86) -- 512
+  wavefronts, half a wavefront per SIMD of an MI355X.  ASOC.py parses the ini key `global` (ASOC_aux.py:400) but never
+  reads it; only ASOCS.py:82 does.  The bench runs --global work items (default 2^24: same packets, same sources, another
+  partition into RNG streams): a launch shape the reference's ASOC.py can only be given by editing ASOC.py:86.  The rate
+  at the reference's own launch shape is measured beside it on a shortened launch (config.reference_launch_shape).
 
   C2 (--workload C2; BASELINE.json configs[1]): 128^3 Cartesian cloud, one frequency, `bgpackets 1e8` ->
   786432 work items x BATCH 127 of isotropic background, noabsorbed.
 
-The K steps are handed to the engine together (soc_batch_begin/end): launches of one kind share brick sweeps.
+The K steps are handed to the engine together (soc_batch_begin/end): on the config-3 hierarchy point-source and diffuse
+launches share one brick sweep (up to 128 launches: the two source blocks of a 50-frequency run, ASOC.py:1028-1545).
 
 Multi-GPU: --scaling strong (default for N > 1) splits the work items of every launch across the ranks
 (identical result to one GPU) with one RCCL all-reduce of the per-cell absorption buffer per
@@ -91,16 +94,17 @@ def c3_workload(GLOBAL_0):
         EMIT[a:b] = np.where(d > 0.0, 1.0e-30 * d, 0.0) * (C3_GL * launch.PARSEC / (8.0 ** level))
 
     def step(i):
-        f = (i // 2) % NFREQ
+        f = (21 * (i // 2) + 45) % NFREQ
         kind = "ps" if (i % 2) == 0 else "cl"
         dsc, csc = tables[f]
         return dict(kind=kind, L=LPS if kind == "ps" else LCL, ABS=AFABS[0][f], SCA=AFSCA[0][f], CSC=csc, DSC=dsc,
                     TW=np.float32(launch.trapezoid_weight(FFREQ, f)), BG=np.float32(0.0), IFREQ=f,
                     PS=PS[f:f + 1], PSPOS=PSPOS, EMIT=EMIT)
     name = ("C3: 256^3-root octree, LEVELS 4 (%d cells), GL 0.02 pc, 50 frequencies 1.5e11-2e15 Hz (own ABS, SCA, HG(g) "
-            "table each), noabsorbed; step i = frequency (i//2)%%50, even: point source at (128.3,128.3,128.3) pspackets 1e9 "
+            "table each), noabsorbed; step i = frequency (21*(i//2)+45)%%50, even: point source at (128.3,128.3,128.3) pspackets 1e9 "
             "= %d work items x BATCH %d = %d packets; odd: diffuse emission diffpack 1e9 = BATCH %d per cell = %d packets, "
-            "%d work items; GLOBAL_0 = %d via the ini key `global` (reference default 32768)"
+            "%d work items; GLOBAL_0 = %d work items per launch -- NOT a shape the reference's ASOC.py can be given without "
+            "editing it (ASOC.py:86 hard-codes 32768; the `global` key is read by ASOCS.py:82 only)"
             % (cloud.CELLS, LPS["GLOBAL"], LPS["BATCH"], LPS["PACKETS"], LCL["BATCH"], LCL["BATCH"] * cloud.CELLS,
                min(LCL["GLOBAL"], cloud.CELLS), GLOBAL_0))
     return dict(name=name, cloud=cloud, step=step, SEED=0.7853981634, ref_tag="oct256", kinds=("ps", "cl"))

@@ -118,7 +118,7 @@ struct SocBrickArgs {
     // population control: work items [0, target) start at once, the others are admitted (in order) as work items
     // finish, so that the sweep runs with `target` packets in flight until the last launch drains
     int target, nl;
-    uint32_t first[SOC_MAXLAUNCH + 1];
+    const uint32_t *first;       // [nl + 1] first work item of every launch (the SocSimPack's, in device memory)
     int *admit;                  // [0] next work item to admit; per launch l: [1+3l] first id, [2+3l] how many, [3+3l] where (this pass)
     // hierarchical grids: bricks are sets of <= CAP leaf cells (soc_oct_build)
     int CAP;
@@ -130,11 +130,10 @@ struct SocBrickArgs {
     int LT;                      // 1: this form of the walk
     int EQ;                      // event queues per launch: creation, scattering (+ slow steps with LT)
     int slow_every;              // test knob: every n-th step below the root grid takes the slow-step queue (0: only the degenerate ones)
-    int lean_step;               // experiment: only root-leaf and sibling-leaf moves are settled in the step arm
     const SocLBrick *lbr;        // [NB] boxes
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
-    float lt_thr[SOC_MAXL];      // 2^(k + level - 30), see soc_lt_degenerate
+    int kexp;                    // k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_move
 };
 
 #include "soc_octbricks.h"     // SOC_SLOT_BITS, SocOctBuilder
@@ -249,8 +248,8 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     SocPk2 *pk = A.pk;
     if (t < count) {
-        int l = 0;
-        while (l + 1 < K.n && t >= K.first[l + 1]) l++;
+        int l = 0, hi = K.n;                                // the launch of work item t: first[l] <= t < first[l + 1]
+        while (hi - l > 1) { const int m = (l + hi) >> 1;  if (t >= K.first[m]) l = m; else hi = m; }
         const soc_rng_t r = soc_seed_stream(K.S[l].seed_mul, K.S[l].seed_tab, K.S[l].gid0 + (t - K.first[l]));
         SocPk2 p;
         p.A = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -585,6 +584,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
 // into the next brick is not finished (old cell + advanced position: soc_lt_arrive completes it there).
 // ---------------------------------------------------------------------------------------
 #define SOC_LT_ARRIVE 0x80000000u
+#define SOC_LQ_SHIFT 24           // packet word C.w of this form: cz | launch << 24 (coordinates stay below 2^24, see soc_brick_run_pb)
 
 // integer coordinates of cell (level, ind) on its level: octants on the way up through PAR, then the root cell
 __device__ __forceinline__ void soc_cell_coords(const SocGrid &G, const int *sOFF, int level, int ind, int &cx, int &cy, int &cz)
@@ -612,10 +612,9 @@ __device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int c
     return ind;
 }
 
-template <bool WINT, int KIND>
+template <bool WINT>
 __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
-    constexpr bool CL = (KIND == 2);
     if (bid >= *A.ndesc) return;
     SocDesc D = A.desc[bid];
     D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
@@ -632,18 +631,14 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     const int NQ = A.NBQ + A.EQ * A.nl + 1;
     int   *sH   = (int *)(sD + BV);                        // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));   // [0] next packet, [1] tally events
-    float *sL   = (float *)(sCtl + 4);                     // [3 * MAXLAUNCH] ABS, SCA, TW of every launch
-    float *sThr = sL + 3 * SOC_MAXLAUNCH;                  // [SOC_MAXL] soc_lt_degenerate's bound per level
-    uint32_t *sFirst = (uint32_t *)(sThr + SOC_MAXL) + 3;  // [MAXLAUNCH + 1] first work item of every launch; entry 1 on a 16-byte boundary
+    float *sL   = (float *)(sCtl + 4);                     // [4 * MAXLAUNCH] ABS, SCA, TW, flags (bit 0: SimRAM_CL) of every launch
     const SocSim &S = K.S[0];
-    if ((int)threadIdx.x < K.n) {
-        sL[3 * threadIdx.x] = K.S[threadIdx.x].ABS;  sL[3 * threadIdx.x + 1] = K.S[threadIdx.x].SCA;  sL[3 * threadIdx.x + 2] = K.S[threadIdx.x].TW;
+    for (int l = threadIdx.x; l < K.n; l += nthr) {
+        sL[4 * l] = K.S[l].ABS;  sL[4 * l + 1] = K.S[l].SCA;  sL[4 * l + 2] = K.S[l].TW;
+        sL[4 * l + 3] = __int_as_float((K.S[l].SOURCE == SOC_SOURCE_CL) ? 1 : 0);
     }
-    if (threadIdx.x < SOC_MAXL) sThr[threadIdx.x] = A.lt_thr[threadIdx.x];
-    if (threadIdx.x <= SOC_MAXLAUNCH) sFirst[threadIdx.x] = ((int)threadIdx.x < A.nl) ? K.first[threadIdx.x] : 0xffffffffu;
     const int mybrick = (A.NBQ > A.NB) ? (D.brick % A.NB) : D.brick;
     const int qbase = D.brick - mybrick;                   // first brick queue of this workgroup's launch (0 when the launches share queues)
-    const int nl = A.nl;                                   // launches in the sweep (a kernel argument: K lives in global memory)
     SocLBrick KB = A.lbr[mybrick];
     // workgroup-uniform values that came from global memory go to scalar registers now: a use inside the loop would
     // otherwise wait for every load in flight (s_waitcnt vmcnt(0)), the prefetched packets included
@@ -661,27 +656,23 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 
     // Uniform values the loop needs now and then.  Left as plain kernel arguments the compiler, out of scalar registers,
     // re-reads them from the argument segment where they are used -- an s_load and a wait for it (and for every LDS
-    // operation in flight) in the step arm and, for first[], one per launch in the swap arm.  Made opaque here they are
-    // values it has to keep: in scalar registers or in lanes of a spill VGPR (v_readlane, no memory).
-    int   NX = G.NX, NY = G.NY, NZ = G.NZ;
-    float thr1 = A.lt_thr[1];
-    asm volatile("" : "+s"(NX), "+s"(NY), "+s"(NZ), "+s"(thr1));
+    // operation in flight) inside the loop.  Made opaque here they are values it has to keep: in scalar registers or in
+    // lanes of a spill VGPR (v_readlane, no memory).
+    int NX = G.NX, NY = G.NY, NZ = G.NZ, Lmax = G.LEVELS - 1, kexp = A.kexp;
+    asm volatile("" : "+s"(NX), "+s"(NY), "+s"(NZ), "+s"(Lmax), "+s"(kexp));
     uint32_t *keyq_c = A.keyq + D.start;                  // this chunk's part of the queue arrays
     const uint32_t *idq_c = A.idq + D.start;
     asm volatile("" : "+s"(pk), "+s"(keyq_c), "+s"(idq_c));
-    const float fNX = (float)NX, fNY = (float)NY, fNZ = (float)NZ;
-    // lane j of firstv holds the first work item of launch j: the launch of a packet is found with v_readlane + compare
-    const uint32_t firstv = sFirst[min((int)(threadIdx.x & 63), SOC_MAXLAUNCH)];
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;                 // GetStep's target inside the cell per axis: 1 + PEPS or -PEPS
-    float lsc = 1.0f;                                      // 2^-level
     float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
     int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;
+    int   what = SOC_LTM_STEP;                              // what the Index() part has to do for the lane: finish a step, an arrival, or find the packet's cell
+    bool  nonudge = false;                                 // SimRAM_CL: no nudge after a failed step (kernel_ASOC.c:1530-1540 has none)
     uint32_t dz = 0, dw = 0, wid = 0;
     int   mode = SOC_BM_SWAP;
-    int   r = SOC_LT_SLOW + 2, Rx = 0, Ry = 0, Rz = 0, slot0 = 0;            // outcome of Index() for the step in hand (> SOC_LT_SLOW: none)
     bool  have = false, nhave = false;                                       // the packet in hand, the prefetched one
     soc_f4v na = { 0.0f, 0.0f, 0.0f, 0.0f }, nb = na, nc = na;
     soc_u2v ndzw = { 0u, 0u };
@@ -691,38 +682,34 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     unsigned int n_tally = 0;
     SOC_PROF_DECL;
 
+    // The loop has two arms.  SWAP (entered when A.FTH lanes of the wave wait for it, or nobody can step): the lane's packet
+    // goes back to memory with the queue it belongs to next, the prefetched one is taken up.  STEP (every iteration): GetStep's
+    // arithmetic and the tally -- skipped by a lane whose packet has just come in from another brick or still needs its
+    // cell looked up -- and then Index() in the one-path form of soc_ltree.h (soc_lt_move), which serves all of them.
     while (!parked) {
         {
             SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
-            // where the idle lanes are: chunks with fewer than 4 / 16 packets per lane, and the end of a chunk (no lane of the wave has a packet waiting)
             if (D.count < 4 * nthr)  { SOC_DPROF(0, 1);  SOC_DPROF(1, __popcll(__ballot(mode == SOC_BM_IDLE))); }
             if (D.count < 16 * nthr) { SOC_DPROF(2, 1);  SOC_DPROF(3, __popcll(__ballot(mode == SOC_BM_IDLE))); }
             if (__ballot(nhave | nnhave) == 0ull) { SOC_DPROF(4, 1);  SOC_DPROF(5, __popcll(__ballot(mode == SOC_BM_IDLE))); }
-            // the end of the chunk: when no lane of the wave has a packet waiting and few still walk, those go back to
-            // the brick's queue (between steps their state is complete) and continue in the next pass among a full wave
-            if ((A.TAIL > 0) && (__ballot(nhave | nnhave) == 0ull)) {
-                const unsigned long long ms = __ballot(mode == SOC_BM_STEP);
-                if ((ms != 0ull) && (__popcll(ms) <= A.TAIL) && (mode == SOC_BM_STEP) && (nvisit > 0)) { mode = SOC_BM_SWAP;  key = D.brick; }
-            }
             const unsigned long long m = __ballot(mode == SOC_BM_SWAP);
-            const bool nobody_steps = (__ballot((mode == SOC_BM_STEP) | (mode == SOC_BM_CLIMB)) == 0ull);
+            const bool nobody_steps = (__ballot(mode == SOC_BM_STEP) == 0ull);
             if (m != 0ull && (nobody_steps || __popcll(m) >= A.FTH)) {
                 SOC_PROF(4, 1);  SOC_PROF(5, __popcll(m));
                 if (mode == SOC_BM_SWAP) {
                     // A lane holds three packets: the one it walks, the next one, whose record was asked for when the
                     // current one was taken up, and the one after that, of which the id has been asked for -- each a
-                    // visit ahead of its use, so nothing in this arm waits for global memory (the brick a leaving packet
-                    // goes to is looked up here).  The chunk itself is never copied: ids, queues and
-                    // places stay in global memory (idq, keyq, posq), so a chunk may be the whole queue of the brick.
+                    // visit ahead of its use, so nothing in this arm waits for global memory.  The chunk itself is never
+                    // copied: ids, queues and places stay in global memory (idq, keyq, posq), so a chunk may be the whole
+                    // queue of the brick.
                     asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed: no later use waits behind the stores below
                     if (have) {
                         SocPk2 *q = pk + wid;
                         // (the brick of the root cell a leaving packet goes to -- key < 0: -1 - root cell -- is looked up after
-                        // the walk, for all packets of the chunk at once.  Loaded when the packet leaves, in the block below, it
-                        // made EVERY iteration wait for all loads in flight: 19 % of the wave's cycles, rocprof wave counters,
-                        // profiles/; loaded here, it made every entry of this arm wait one L2 latency)
+                        // the walk, for all packets of the chunk at once: loaded when the packet leaves it made EVERY iteration
+                        // wait for all loads in flight, 19 % of the wave's cycles; loaded here, every entry of this arm one L2 latency)
                         soc_st4(&q->A, make_float4(px, py, pz, photons));
-                        soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz)));
+                        soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz | (lq << SOC_LQ_SHIFT))));
                         q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
                         q->D.w = dw;
                         SOC_NT_STORE((uint32_t)key, &keyq_c[cslot]);              // its rank in that queue is settled after the walk, for all packets at once
@@ -737,31 +724,26 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
                         gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;
                         tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = __float_as_int(nc.w);
+                        lq = (int)((uint32_t)cz >> SOC_LQ_SHIFT);  cz &= (1 << SOC_LQ_SHIFT) - 1;      // the launch of the work item
                         level = (int)(dz >> 29);
-                        lsc = soc_lt_pow2(-level);
-                        lq = 0;                                                   // the launch of the work item (first[] is a kernel argument: scalar compares)
-                        for (int j = 1; j < nl; j++) lq += (wid >= (uint32_t)__builtin_amdgcn_readlane((int)firstv, j)) ? 1 : 0;
-                        kabs = sL[3 * lq];  ksca = sL[3 * lq + 1];  tw = sL[3 * lq + 2];
+                        {
+                            const soc_f4v l4 = *(const soc_f4v *)&sL[4 * lq];
+                            kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = (__float_as_int(l4.w) & 1) != 0;
+                        }
                         nvisit = 0;
                         mode = SOC_BM_STEP;
-                        if (dw & SOC_LT_ARRIVE) {
-                            // the step that brought the packet here is completed by the Index() arms below: the common case --
-                            // a root-level packet into a root cell that is a leaf -- here, the others in the deferred arm
-                            dw &= ~SOC_LT_ARRIVE;
-                            slot = -1;                                            // (no cell of this brick: not a failed step)
-                            r = SOC_LT_SLOW + 1;
-                            mode = SOC_BM_CLIMB;
-                            if (level == 0) {
-                                const int ix = (int)soc_floorf(px), iy = (int)soc_floorf(py), iz = (int)soc_floorf(pz);
-                                const int s2 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
-                                const float rec = sD[s2];
-                                if (rec > 0.0f) { slot = s2;  dens = rec;  cx = ix;  cy = iy;  cz = iz;  r = SOC_LT_SLOW + 2;  mode = SOC_BM_STEP; }
-                            }
-                        } else if (level == 0) {
-                            slot = ((cz - KB.z0) * KB.by + (cy - KB.y0)) * KB.bx + (cx - KB.x0);
-                            dens = sD[slot];
-                        } else if (!soc_lt_place(sD, KB, level, cx, cy, cz, slot, dens)) {
-                            mode = SOC_BM_SWAP;  key = NQ - 1;                    // cannot happen (the sender looked the brick up): retire rather than walk off the tree
+                        slot = -1;
+                        // The first pass of the packet through the Index() part finds its cell in this brick: the second half of
+                        // the step that brought it here (ARRIVE), or the cell its coordinates name.  A root-level packet in (or
+                        // into) a root cell that is not refined -- the common case -- is settled here.
+                        const bool arrive = (dw & SOC_LT_ARRIVE) != 0u;
+                        dw &= ~SOC_LT_ARRIVE;
+                        what = arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE;
+                        if (level == 0) {
+                            const int ix = arrive ? (int)soc_floorf(px) : cx, iy = arrive ? (int)soc_floorf(py) : cy, iz = arrive ? (int)soc_floorf(pz) : cz;
+                            const int s2 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
+                            const float rec = sD[s2];
+                            if (!arrive || (rec > 0.0f)) { slot = s2;  dens = rec;  cx = ix;  cy = iy;  cz = iz;  what = SOC_LTM_STEP; }
                         }
                     }
                     // the record of the packet after it (its id has arrived)
@@ -791,122 +773,71 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
         }
         SOC_PROF_T(0);                                     // swap
         if (__ballot(mode != SOC_BM_IDLE) == 0ull) break;
-        // ---- one cell step (kernel_ASOC.c:565-683) ----
         if (mode == SOC_BM_STEP) {
-            const int   level0 = level;
-            const float p0x = px, p0y = py, p0z = pz, d0 = dens;
-            slot0 = slot;
-            float fx, fy, fz;
-            if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
-                fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
-            } else {
-                fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
-            }
-            const float ax = soc_div_by_rcp(gx - fx, ux, rux);
-            const float ay = soc_div_by_rcp(gy - fy, uy, ruy);
-            const float az = soc_div_by_rcp(gz - fz, uz, ruz);
-            float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
-            px += ds * ux;
-            py += ds * uy;
-            pz += ds * uz;
-            ds = ds * lsc;                                                    // ldexp(ds, -level)
-            const float tauA = ds * d0 * kabs;
-            const float dtau = ds * d0 * ksca;
-            if (free_path < (tau + dtau)) {
-                px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 1;             // -> scattering queue of its launch
-            } else {
-                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
-                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[slot0], delta * tw);
-                if (WINT) atomicAdd(&sI[slot0], delta);
-                n_tally++;
-                photons *= e;
-                tau += dtau;
-                // Index (kernel_ASOC_aux.c:198-278).  The common moves are settled here, each with the results soc_lt_step
-                // would give (soc_ltree.h): root cell -> root cell that is a leaf, or one level down into a refined one;
-                // sibling leaf in the same octet; level-1 cell -> neighbouring root cell that is a leaf.  The rest (deeper
-                // changes of level or octet, degenerate positions) waits for the deferred arm below.
-                r = SOC_LT_SLOW + 1;                                          // "not settled yet"
-                if ((A.slow_every > 0) && (level0 > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
-                    r = SOC_LT_SLOW;
+            bool move = true;
+            const int slot0 = slot;
+            // ---- one cell step (kernel_ASOC.c:565-683) ----
+            if (what == SOC_LTM_STEP) {
+                const float p0x = px, p0y = py, p0z = pz;
+                float fx, fy, fz;
+                if (__ballot(__builtin_fminf(px, __builtin_fminf(py, pz)) < 0.0f) == 0ull) {
+                    fx = __builtin_amdgcn_fractf(px);  fy = __builtin_amdgcn_fractf(py);  fz = __builtin_amdgcn_fractf(pz);
                 } else {
-                    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
-                    const int   ix = (int)flx, iy = (int)fly, iz = (int)flz;
-                    const bool  sib = (level0 > 0) && (((ix | iy | iz) & ~1) == 0);
-                    bool root = (level0 == 0);
-                    Rx = ix;  Ry = iy;  Rz = iz;
-                    if (!A.lean_step && (level0 == 1) && !sib && !soc_lt_degenerate(px, py, pz, flx, fly, flz, thr1)) {
-                        Rx = ((cx & ~1) + ix) >> 1;  Ry = ((cy & ~1) + iy) >> 1;  Rz = ((cz & ~1) + iz) >> 1;
-                        root = true;
-                    }
-                    // one LDS read serves the move to a root cell and the move to a sibling (a wave has lanes of both kinds)
-                    int s2 = -1, qx = Rx, qy = Ry, qz = Rz;
-                    if (root) {
-                        const bool out = (level0 == 0) ? !((px > 0.0f) & (px < fNX) & (py > 0.0f) & (py < fNY) & (pz > 0.0f) & (pz < fNZ))
-                                                       : (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ));
-                        const int rx = Rx - KB.x0, ry = Ry - KB.y0, rz = Rz - KB.z0;
-                        if (out) r = SOC_LT_EXIT;
-                        else if (((unsigned)rx >= (unsigned)KB.bx) | ((unsigned)ry >= (unsigned)KB.by) | ((unsigned)rz >= (unsigned)KB.bz)) r = SOC_LT_LEAVE;
-                        else s2 = (rz * KB.by + ry) * KB.bx + rx;
-                    } else if (sib && (__builtin_fminf(px, __builtin_fminf(py, pz)) >= A.sib_thr)) {
-                        s2 = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2));
-                        qx = (cx & ~1) + ix;  qy = (cy & ~1) + iy;  qz = (cz & ~1) + iz;
-                    }
-                    if (s2 >= 0) {
-                        const float rec = sD[s2];
-                        if (rec > 0.0f) {
-                            if (root && (level0 == 1)) {                      // up to the root grid: pos' = RN(pos/2 + octet origin/2)
-                                px = SOC_FMA(px, 0.5f, 0.5f * (float)(cx & ~1));  py = SOC_FMA(py, 0.5f, 0.5f * (float)(cy & ~1));  pz = SOC_FMA(pz, 0.5f, 0.5f * (float)(cz & ~1));
-                                level = 0;  lsc = 1.0f;
-                            }
-                            slot = s2;  dens = rec;  cx = qx;  cy = qy;  cz = qz;  r = SOC_LT_INSIDE;
-                        } else if (root && !A.lean_step && (level0 == 0)) {
-                            // one level down: octant and position from 2*fmod(pos,1), exact
-                            const float hx = (px - flx) + (px - flx), hy = (py - fly) + (py - fly), hz = (pz - flz) + (pz - flz);
-                            const int   bx = (hx >= 1.0f) ? 1 : 0, by = (hy >= 1.0f) ? 1 : 0, bz = (hz >= 1.0f) ? 1 : 0;
-                            const int   s3 = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
-                            const float rec3 = sD[s3];
-                            if (rec3 > 0.0f) {
-                                px = hx;  py = hy;  pz = hz;
-                                level = 1;  lsc = 0.5f;
-                                slot = s3;  dens = rec3;  cx = 2 * ix + bx;  cy = 2 * iy + by;  cz = 2 * iz + bz;  r = SOC_LT_INSIDE;
-                            }
+                    fx = soc_fmod1f(px);  fy = soc_fmod1f(py);  fz = soc_fmod1f(pz);
+                }
+                const float ax = soc_div_by_rcp(gx - fx, ux, rux);
+                const float ay = soc_div_by_rcp(gy - fy, uy, ruy);
+                const float az = soc_div_by_rcp(gz - fz, uz, ruz);
+                float ds = __builtin_fminf(ax, __builtin_fminf(ay, az));
+                px += ds * ux;
+                py += ds * uy;
+                pz += ds * uz;
+                ds = ds * soc_lt_pow2(-level);                                    // ldexp(ds, -level)
+                const float tauA = ds * dens * kabs;
+                const float dtau = ds * dens * ksca;
+                if (free_path < (tau + dtau)) {
+                    px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
+                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 1;             // -> scattering queue of its launch
+                    move = false;
+                } else {
+                    const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
+                    const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+                    atomicAdd(&sT[slot0], delta * tw);
+                    if (WINT) atomicAdd(&sI[slot0], delta);
+                    n_tally++;
+                    photons *= e;
+                    tau += dtau;
+                }
+            }
+            SOC_PROF_T(1);                                 // step
+            // ---- Index (kernel_ASOC_aux.c:198-278) ----
+            if (move) {
+                int r, Rx, Ry, Rz;
+                if ((A.slow_every > 0) && (what == SOC_LTM_STEP) && (level > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
+                    r = SOC_LT_SLOW;                                              // test knob: this step goes through the slow-step queue
+                } else {
+                    r = soc_lt_move(sD, KB, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+                }
+                if (r == SOC_LT_INSIDE) {
+                    if (what != SOC_LTM_PLACE) {
+                        if (!nonudge && (slot == slot0)) {                        // failed step: nudge (SimRAM_PB / HP only)
+                            px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
                         }
+                        nvisit++;
+                        if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
                     }
+                } else if (r == SOC_LT_LEAVE) {
+                    mode = SOC_BM_SWAP;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;      // (the brick of that root cell: looked up after the walk)
+                } else if (r == SOC_LT_EXIT) {
+                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
+                } else if (r == SOC_LT_SLOW) {
+                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE;          // -> slow-step queue: old cell, advanced position
+                } else {
+                    mode = SOC_BM_SWAP;  key = NQ - 1;                            // cannot happen (the sender looked the brick up): retire rather than walk off the tree
                 }
-                if (r > SOC_LT_SLOW) mode = SOC_BM_CLIMB;
+                what = SOC_LTM_STEP;
             }
-        }
-        SOC_PROF_T(1);                                     // step
-        {
-            const unsigned long long mc = __ballot(mode == SOC_BM_CLIMB);
-            if (mc != 0ull && (__popcll(mc) >= A.CTH || __ballot(mode == SOC_BM_STEP) == 0ull)) {
-                SOC_PROF(2, 1);  SOC_PROF(3, __popcll(mc));
-                if (mode == SOC_BM_CLIMB) {
-                    slot0 = slot;
-                    r = soc_lt_step(sD, KB, NX, NY, NZ, sThr[level], A.sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
-                    lsc = soc_lt_pow2(-level);
-                    mode = SOC_BM_STEP;
-                }
-            }
-        }
-        SOC_PROF_T(2);                                     // deferred Index
-        if (r <= SOC_LT_SLOW) {
-            if (r == SOC_LT_INSIDE) {
-                if (!CL && (slot == slot0)) {                                 // failed step: nudge (SimRAM_PB / HP only)
-                    px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
-                }
-                nvisit++;
-                if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
-            } else if (r == SOC_LT_LEAVE) {
-                mode = SOC_BM_SWAP;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;      // (the brick of that root cell: looked up in the swap arm)
-            } else if (r == SOC_LT_EXIT) {
-                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
-            } else {
-                mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE;          // -> slow-step queue: old cell, advanced position
-            }
-            r = SOC_LT_SLOW + 2;                                              // handled
+            SOC_PROF_T(2);                                 // Index
         }
     }
 
@@ -944,7 +875,6 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 template <bool OCT, bool ABU, bool WINT, int KIND, bool LT>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
-    constexpr bool CL = (KIND == 2), HP = (KIND == 1);
     constexpr int  SRC = (KIND == 3) ? 1 : -1;             // KIND 3: SimRAM_PB with SOURCE == 1 (background) only
     // ebid counts from the first event descriptor (event queues sort last);
     // slice: blockDim.x packets of the chunk -- one packet per lane
@@ -962,6 +892,9 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
     const int NQ = A.NBQ + A.EQ * K.n + 1;
     const int lq = (D.brick - A.NBQ) / A.EQ;                  // the launch this queue belongs to (workgroup-uniform)
     const SocSim &S = K.S[lq];
+    // KIND 4: launches of several kinds share the sweep, the kind is the launch's (uniform in the workgroup: an event queue belongs to one launch)
+    const int  skind = (KIND == 4) ? ((S.SOURCE == SOC_SOURCE_CL) ? 2 : (S.SOURCE == SOC_SOURCE_HP) ? 1 : 0) : KIND;
+    const bool CL = (skind == 2), HP = (skind == 1);
     const int qbase = (A.NBQ > A.NB) ? lq * A.NB : 0;      // first brick queue of this launch
     extern __shared__ float lds[];
     int   *sH   = (int *)lds;                              // arrivals per queue
@@ -994,7 +927,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         int ccx = 0, ccy = 0, ccz = 0;                         // brick-local hierarchies: cell coordinates on the cell's level
         if (LT) {
             // record of soc_lbrick_walk: C = tau, cell coordinates; D.z = III | scatterings << 24 | level << 29
-            ccx = __float_as_int(p.C.y);  ccy = __float_as_int(p.C.z);  ccz = __float_as_int(p.C.w);
+            ccx = __float_as_int(p.C.y);  ccy = __float_as_int(p.C.z);  ccz = __float_as_int(p.C.w) & ((1 << SOC_LQ_SHIFT) - 1);      // (the launch above it: this queue's)
             w.level = (int)(p.D.z >> 29);
             w.scat  = (int)((p.D.z >> 24) & 31u);
             if (evk == 2) cl_cell = p.D.w & ~SOC_LT_ARRIVE;                      // (a work item that has not started holds a negative cell)
@@ -1043,7 +976,8 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             w.pz = w.pz + dx * w.uz;
             w.photons *= e;
             w.free_path = soc_draw_free_path(S, &w.rng, w.photons);
-            soc_new_direction<CL>(S, S.CSC, oind, w.ux, w.uy, w.uz, w.free_path, &w.rng);   // one table read per event: no staging
+            if (CL) soc_new_direction<true>(S, S.CSC, oind, w.ux, w.uy, w.uz, w.free_path, &w.rng);   // one table read per event: no staging
+            else    soc_new_direction<false>(S, S.CSC, oind, w.ux, w.uy, w.uz, w.free_path, &w.rng);
             w.tau = 0.0f;
             if (!CL && (w.scat > 20)) { w.ind = -1;  create = true; }         // dropped after 20 scatterings
             if (LT) {                                                        // back to the brick of its cell
@@ -1181,7 +1115,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
         p.A = make_float4(w.px, w.py, w.pz, w.photons);
         p.B = make_float4(w.ux, w.uy, w.uz, w.free_path);
         if (LT) {
-            p.C = make_float4(w.tau, __int_as_float(ccx), __int_as_float(ccy), __int_as_float(ccz));
+            p.C = make_float4(w.tau, __int_as_float(ccx), __int_as_float(ccy), __int_as_float(ccz | (lq << SOC_LQ_SHIFT)));
             p.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)w.scat << 24) | ((uint32_t)w.level << 29), CL ? cl_cell : 0u);
         } else {
         p.C = make_float4(w.tau, w.dens, __int_as_float(lid | ((OCT ? w.level : 0) << SOC_LVL_SHIFT) | (lq << SOC_LCH_SHIFT)), __int_as_float(w.ind));
@@ -1229,7 +1163,7 @@ __global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const S
     const SocSimPack &K = *Kp;
     const int b = (int)blockIdx.x;
     if (b < nwalk) {
-        soc_lbrick_walk<WINT, KIND>(G, K, A, b);
+        soc_lbrick_walk<WINT>(G, K, A, b);
     } else {
         const int e = b - nwalk;
         soc_brick_events<true, false, WINT, KIND, true>(G, K, A, e / slices, e % slices);
@@ -1542,8 +1476,8 @@ static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_
                                    const SocBrickArgs &A, int nwalk, int slices)
 {
 #define SOC_LB_CASE(W, KD) soc_lbrick_launch_one<W, KD>(nblocks, T, lds, st, G, K, A, nwalk, slices)
-    if (wint) { if (kind == 3) SOC_LB_CASE(true, 3);  else if (kind == 2) SOC_LB_CASE(true, 2);  else if (kind == 1) SOC_LB_CASE(true, 1);  else SOC_LB_CASE(true, 0); }
-    else      { if (kind == 3) SOC_LB_CASE(false, 3); else if (kind == 2) SOC_LB_CASE(false, 2); else if (kind == 1) SOC_LB_CASE(false, 1); else SOC_LB_CASE(false, 0); }
+    if (wint) { if (kind == 4) SOC_LB_CASE(true, 4);  else if (kind == 3) SOC_LB_CASE(true, 3);  else if (kind == 2) SOC_LB_CASE(true, 2);  else if (kind == 1) SOC_LB_CASE(true, 1);  else SOC_LB_CASE(true, 0); }
+    else      { if (kind == 4) SOC_LB_CASE(false, 4); else if (kind == 3) SOC_LB_CASE(false, 3); else if (kind == 2) SOC_LB_CASE(false, 2); else if (kind == 1) SOC_LB_CASE(false, 1); else SOC_LB_CASE(false, 0); }
 #undef SOC_LB_CASE
 }
 
@@ -1631,9 +1565,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             int k = 1;
             while ((1 << k) <= std::max(G.NX, std::max(G.NY, G.NZ))) k++;
             A.sib_thr = ldexpf(1.0f, k - 29);
-            for (int l = 0; l < SOC_MAXL; l++) A.lt_thr[l] = ldexpf(1.0f, k + l - 30);
+            A.kexp = k - 30;
             A.slow_every = tune.slow_every;
-            A.lean_step = tune.lean_step;
             A.P = (tune.P > 0) ? tune.P : 16384;
             A.KCAP = (tune.KCAP > 0) ? tune.KCAP : 64;
             A.FTH = (tune.FTH > 0) ? tune.FTH : 16;
@@ -1750,11 +1683,11 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.posq = bb.posq;  A.hist = bb.hist;  A.off = bb.off;  A.total = bb.total;
     A.admit = bb.admit;
     A.nl = K.n;
-    for (int l = 0; l <= SOC_MAXLAUNCH; l++) A.first[l] = K.first[l];
+    A.first = (const uint32_t *)((const char *)bb.pack + offsetof(SocSimPack, first));
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 3 * SOC_MAXLAUNCH + SOC_MAXL + 3 + SOC_MAXLAUNCH + 1) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
@@ -1764,10 +1697,14 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     bool all_bg = (kind == 0);
     for (int l = 0; l < K.n; l++) {
         const int kl = (K.S[l].SOURCE == SOC_SOURCE_CL) ? 2 : (K.S[l].SOURCE == SOC_SOURCE_HP) ? 1 : 0;
-        if (kl != kind) return hipErrorInvalidValue;                  // one kind per sweep (soc_capi.hip sees to it)
+        if (kl != kind) {                                             // launches of several kinds: brick-local hierarchies only, where the walk
+            if (!A.LT) return hipErrorInvalidValue;                   // takes the kind from the launch (soc_capi.hip sees to it elsewhere)
+            kind = 4;
+            break;
+        }
         all_bg = all_bg && (K.S[l].SOURCE == 1);
     }
-    if (all_bg && !tune.nolean) kind = 3;               // background packets only: the lean kernel
+    if (kind != 4 && all_bg && !tune.nolean) kind = 3;  // background packets only: the lean kernel
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((live + A.P - 1) / A.P) + (A.EQ + 1) * K.n) * slices;
 

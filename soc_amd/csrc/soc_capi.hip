@@ -74,11 +74,16 @@ struct soc_ctx {
     int    batch_max = 4;
     std::vector<SocSim> pending;
     float *dCSCslot[SOC_MAXLAUNCH] = {};
-    float2 *dOPTslots = nullptr;                  // [SOC_MAXLAUNCH][CELLS] per-cell opacities of deferred launches
+    float2 *dOPTslots = nullptr;                  // [SOC_OPT_SLOTS][CELLS] per-cell opacities of deferred launches (one buffer: the sweep strides through it)
     float *dHPslots = nullptr;                    // [SOC_MAXLAUNCH][2][49152] Healpix skies of deferred SimRAM_HP launches
-    float *dEMITslots = nullptr;                  // [SOC_MAXLAUNCH][2][CELLS] EMIT, EMWEI of deferred SimRAM_CL launches
-    float *dINTslots = nullptr;                   // [SOC_MAXLAUNCH][CELLS] INT tallies of deferred launches (soc_batch_read_int)
+    // EMIT | EMWEI copies of deferred SimRAM_CL launches and INT tallies of deferred launches (soc_batch_read_int): one buffer per
+    // launch slot, allocated when a batch first reaches that slot (128 slots of a 5e7-cell model up front would be 50 GB)
+    float *dEMITslot[SOC_MAXLAUNCH] = {};
+    float *dINTslot[SOC_MAXLAUNCH] = {};
     size_t intslot_cells = 0;
+    unsigned long long emit_gen = 0;              // bumped by soc_set_emission: launches deferred without a change in between share one copy
+    unsigned long long emit_slot_gen = 0;
+    int    emit_slot_last = -1;
     int    int_slots_done = 0;                    // launches of the last executed sweep whose INT can be read
     bool   batch_keep_int = false;                // soc_batch_begin_int: deferred launches keep their own INT tally
     size_t emitslot_cells = 0;
@@ -248,7 +253,9 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
-    void *bufs[] = { c->dINTslots, c->dEMITslots, c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dINTV, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
+    for (float *q : c->dEMITslot) if (q) (void)hipFree(q);
+    for (float *q : c->dINTslot) if (q) (void)hipFree(q);
+    void *bufs[] = { c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dINTV, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
                      c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
@@ -400,7 +407,7 @@ int soc_set_tuning(soc_ctx *c, const char *name, int value)
     struct { const char *n; int *p; } tab[] = {
         { "threads", &c->tune.T }, { "chunk", &c->tune.P }, { "steps_per_visit", &c->tune.KCAP }, { "swap_lanes", &c->tune.FTH },
         { "climb_lanes", &c->tune.CTH }, { "brick_cells", &c->tune.CAP }, { "tail_lanes", &c->tune.TAIL }, { "park_below", &c->tune.park }, { "population", &c->tune.POP },
-        { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every }, { "lean_step", &c->tune.lean_step },
+        { "hash_slots", &c->tune.HS }, { "global_tree", &c->tune.global_tree }, { "slow_every", &c->tune.slow_every },
         { "general_kernel", &c->tune.nolean }, { "oversubscribe", &c->tune.oversub }, { "verbose", &c->tune.verbose } };
     for (auto &t : tab)
         if (!strcmp(name, t.n)) {
@@ -560,6 +567,7 @@ int soc_set_emission(soc_ctx *c, const float *EMIT, const float *EMWEI)
     }
     HIPCHK(c, hipMemcpyAsync(c->dEMIT, EMIT, n * 4, hipMemcpyHostToDevice, c->stream));
     if (EMWEI) HIPCHK(c, hipMemcpyAsync(c->dEMWEI, EMWEI, n * 4, hipMemcpyHostToDevice, c->stream));
+    c->emit_gen++;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
 }
@@ -708,6 +716,7 @@ static int upload_sources(soc_ctx *c, const char *who, SocSim &S, const float *P
 }
 
 static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot);
+#define SOC_OPT_SLOTS 16        // launches with per-cell opacities per sweep (8 B per cell and launch, in one buffer)
 
 // a sweep runs one kernel variant: launches of one kind (SimRAM_PB, _HP or _CL), all with or all without per-cell opacities
 // soc_batch_begin_int: the next launch of the batch -- deferred or not -- gets its own, zeroed INT tally
@@ -717,24 +726,28 @@ static int take_int_slot(soc_ctx *c, const char *who, SocSim &S)
     if (c->int_slots_done >= c->batch_max)
         return fail(c, SOC_ERR_STATE, "%s: %d launches of this batch hold an INT tally; soc_batch_end and soc_batch_read_int first", who, c->batch_max);
     const size_t cells = (size_t)c->G.CELLS;
-    if (c->intslot_cells != cells) {
+    if (c->intslot_cells != cells) {                       // another grid: the slots are re-made as they are reached
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, dev_alloc(&c->dINTslots, cells * SOC_MAXLAUNCH));
+        for (float *&q : c->dINTslot) if (q) { (void)hipFree(q);  q = nullptr; }
         c->intslot_cells = cells;
     }
-    S.INT = c->dINTslots + (size_t)c->int_slots_done * cells;
+    if (!c->dINTslot[c->int_slots_done]) HIPCHK(c, dev_alloc(&c->dINTslot[c->int_slots_done], cells));
+    S.INT = c->dINTslot[c->int_slots_done];
     HIPCHK(c, hipMemsetAsync(S.INT, 0, cells * 4, c->stream));
     c->int_slots_done++;
     return SOC_OK;
 }
 
+// ... except on brick-local hierarchies, where the walk and the event workgroups take the kind from the launch: there the
+// point-source, background, Healpix and cell-emission launches of a TABS-only run share one sweep
 static bool same_sweep(const soc_ctx *c, int source, bool abu)
 {
     if (c->pending.empty()) return true;
     const SocSim &P = c->pending[0];
     const int kp = (P.SOURCE == SOC_SOURCE_CL) ? 2 : (P.SOURCE == SOC_SOURCE_HP) ? 1 : 0;
     const int kn = (source == SOC_SOURCE_CL) ? 2 : (source == SOC_SOURCE_HP) ? 1 : 0;
-    return kp == kn && ((P.OPT != nullptr) == abu);
+    if ((P.OPT != nullptr) != abu) return false;
+    return kp == kn || (lt_capable(c, abu) && !c->batch_keep_int);
 }
 
 int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
@@ -791,7 +804,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         r = snapshot_inputs(c, S, V, slot);
         if (r) return r;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {
@@ -832,7 +845,7 @@ int soc_batch_read_int(soc_ctx *c, int k, float *out, long n)
     if (k < 0 || k >= c->int_slots_done) return fail(c, SOC_ERR_ARG, "soc_batch_read_int: launch %d of %d deferred with the INT tally", k, c->int_slots_done);
     if (!out || n != (long)c->G.CELLS) return fail(c, SOC_ERR_ARG, "soc_batch_read_int: the tally has %d cells, buffer %ld", c->G.CELLS, n);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out, c->dINTslots + (size_t)k * c->G.CELLS, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->dINTslot[k], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SOC_OK;
 }
@@ -977,10 +990,11 @@ static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot)
     HIPCHK(c, hipMemcpyAsync(c->dCSCslot[slot], c->dCSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
     S.CSC = c->dCSCslot[slot];
     if (V.abu) {                                            // the per-cell opacities of this launch: slot of one buffer
+        if (slot >= SOC_OPT_SLOTS) return fail(c, SOC_ERR_STATE, "a batch holds at most %d launches with per-cell opacities", SOC_OPT_SLOTS);
         const size_t cells = (size_t)c->G.CELLS;
         if (c->optslot_cells != cells) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, dev_alloc(&c->dOPTslots, cells * SOC_MAXLAUNCH));
+            HIPCHK(c, dev_alloc(&c->dOPTslots, cells * SOC_OPT_SLOTS));
             c->optslot_cells = cells;
         }
         HIPCHK(c, hipMemcpyAsync(c->dOPTslots + (size_t)slot * cells, c->dOPT, cells * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1028,7 +1042,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         HIPCHK(c, hipMemcpyAsync(sky + 49152, c->dHPBGP, 49152 * 4, hipMemcpyDeviceToDevice, c->stream));
         S.HPBG = sky;  S.HPBGP = sky + 49152;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {
@@ -1086,15 +1100,24 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         const size_t cells = (size_t)c->G.CELLS;
         if (c->emitslot_cells != cells) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, dev_alloc(&c->dEMITslots, cells * 2 * SOC_MAXLAUNCH));
+            for (float *&q : c->dEMITslot) if (q) { (void)hipFree(q);  q = nullptr; }
             c->emitslot_cells = cells;
+            c->emit_slot_last = -1;
         }
-        float *em = c->dEMITslots + (size_t)slot * 2 * cells;
-        HIPCHK(c, hipMemcpyAsync(em, c->dEMIT, cells * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(em + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+        // (the copy of an earlier launch of this batch serves when soc_set_emission has not been called since)
+        int es = slot;
+        if (c->emit_slot_last >= 0 && c->emit_slot_last < slot && c->emit_slot_gen == c->emit_gen) {
+            es = c->emit_slot_last;
+        } else {
+            if (!c->dEMITslot[slot]) HIPCHK(c, dev_alloc(&c->dEMITslot[slot], cells * 2));
+            HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot], c->dEMIT, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot] + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+            c->emit_slot_last = slot;  c->emit_slot_gen = c->emit_gen;
+        }
+        float *em = c->dEMITslot[es];
         S.EMIT = em;  S.EMWEI = em + cells;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= c->batch_max) FLUSH(c);
+        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
         return SOC_OK;
     }
     if (bricks) {

@@ -65,8 +65,8 @@ struct SocSim {
 
 // Several launches of SimRAM_PB executed in one brick sweep (soc_brick.hip): launch l owns the
 // sweep's work items [first[l], first[l+1]); geometry and tallies are shared.  Lives in device memory
-// (16 launches exceed the 4 KB of kernel arguments).
-#define SOC_MAXLAUNCH 16
+// (16 launches exceed the 4 KB of kernel arguments).  128: the two source blocks of a 50-frequency run (ASOC.py:1028-1545) fit one sweep.
+#define SOC_MAXLAUNCH 128
 struct SocSimPack {
     int      n;
     uint32_t first[SOC_MAXLAUNCH + 1];
@@ -168,7 +168,6 @@ hipError_t soc_launch_eqsolver(const SocEqTArgs &A, hipStream_t st);
 struct SocBrickTune {
     int T, P, KCAP, FTH, CTH, CAP, TAIL, POP, HS;
     int global_tree;           // hierarchies: the walk that reads the hierarchy from global memory, also where brick-local ones apply
-    int lean_step;             // brick-local hierarchies, experiment: fewer kinds of moves settled in the step arm
     int park;                  // brick-local hierarchies: brick queues shorter than this (and than the mean queue) wait for more packets (0 = built-in 4096, 1 = never)
     int slow_every;            // brick-local hierarchies, test knob: every n-th step below the root grid goes through the slow-step queue
     int nolean;                // keep the general SimRAM_PB kernel for background-only sweeps

@@ -169,4 +169,103 @@ SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, c
     return soc_lt_descend(tree, K, level, cx, cy, cz, slot, dens, l, Rx, Ry, Rz) && (l == level);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The walk's form of all of the above: ONE straight path for every kind of move, so that a wavefront whose lanes make
+// different moves (root cell -> root cell, sibling, up, down, into the next brick) executes one instruction stream
+// instead of one per kind.
+//
+// The point reached by the step is written as integer cell coordinates on the FINEST level,
+//     F = (o << D) + floor(pos * 2^D),     o = origin of the packet's octet on its level L (0 on the root grid),
+//                                           D = Lmax - L,
+// which is exact: pos * 2^D is a power-of-two scaling, floor() and the conversion are exact below 2^24, and the
+// binary digits of pos - floor(pos) are the octants Index() picks with 2*fmod(POS,1) on the way down (:268-273) --
+// also for a negative coordinate, whose fractional part a float subtraction would round.  The ancestors of the
+// point's cell are F >> (Lmax - l), so the descent from the brick's root cell (or, for a sibling, from the packet's
+// own octet) is one loop with one LDS read per level, and the new local position is one fma, as in soc_lt_settle.
+//
+//   what == SOC_LTM_STEP   : pos has been advanced by GetStep's arithmetic; the packet's cell is (level, c, slot);
+//   what == SOC_LTM_ARRIVE : the same for a packet that comes from another brick (its slot means nothing here);
+//   what == SOC_LTM_PLACE  : find slot and density of the packet's own cell (level, c); pos is not touched.
+// Returns SOC_LT_INSIDE / LEAVE / EXIT / SLOW as soc_lt_step does (LEAVE, EXIT and SLOW change nothing), or
+// SOC_LT_LOST when a placement does not find the cell (a broken record; the walk retires the packet).
+// kexp = k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_degenerate (2^(kexp+L)) and of the sibling case (2^(kexp+1)).
+// ---------------------------------------------------------------------------------------------------------------
+enum { SOC_LTM_STEP = 0, SOC_LTM_ARRIVE = 1, SOC_LTM_PLACE = 2 };
+enum { SOC_LT_LOST = 4 };
+
+template <typename TREE>
+SOC_HD int soc_lt_move(const TREE tree, const SocLBrick &K, const int NX, const int NY, const int NZ, const int Lmax, const int kexp,
+                       const int what, float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens,
+                       int &Rx, int &Ry, int &Rz)
+{
+    const int  L = level, D = Lmax - L;
+    const bool place = (what == SOC_LTM_PLACE);
+    const int  om = (L > 0) ? ~1 : 0;
+    const int  ox = cx & om, oy = cy & om, oz = cz & om;
+    int Jx, Jy, Jz;                                          // floor(pos * 2^D): the cell within the octet and D digits below it
+    if (place) {
+        Jx = (int)((unsigned)(cx - ox) << D);  Jy = (int)((unsigned)(cy - oy) << D);  Jz = (int)((unsigned)(cz - oz) << D);
+    } else {
+        const float sc = soc_lt_pow2(D);
+        Jx = (int)soc_floorf(px * sc);  Jy = (int)soc_floorf(py * sc);  Jz = (int)soc_floorf(pz * sc);
+    }
+    const int ix = Jx >> D, iy = Jy >> D, iz = Jz >> D;      // floor(pos)
+    const int Fx = (int)((unsigned)ox << D) + Jx, Fy = (int)((unsigned)oy << D) + Jy, Fz = (int)((unsigned)oz << D) + Jz;
+    bool sib = false, slow = false, out0 = false;
+    if (!place) {
+        if (L > 0) {
+            sib = (((ix | iy | iz) & ~1) == 0);
+            if (sib) {
+                slow = !(soc_fminf(px, soc_fminf(py, pz)) >= soc_lt_pow2(kexp + 1));
+            } else {
+                slow = soc_lt_degenerate(px, py, pz, soc_floorf(px), soc_floorf(py), soc_floorf(pz), soc_lt_pow2(kexp + L));
+            }
+        } else {
+            out0 = (px == 0.0f) | (py == 0.0f) | (pz == 0.0f);               // root grid: pos <= 0 leaves the model (:214)
+        }
+    }
+    Rx = Fx >> Lmax;  Ry = Fy >> Lmax;  Rz = Fz >> Lmax;
+    if (slow) return SOC_LT_SLOW;
+    const int  rx = Rx - K.x0, ry = Ry - K.y0, rz = Rz - K.z0;
+    const bool inbox = !(((unsigned)rx >= (unsigned)K.bx) | ((unsigned)ry >= (unsigned)K.by) | ((unsigned)rz >= (unsigned)K.bz));
+    if (!sib && !inbox) {
+        if (place) return SOC_LT_LOST;
+        if (out0 | ((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ)) return SOC_LT_EXIT;
+        return SOC_LT_LEAVE;
+    }
+    if (out0) return SOC_LT_EXIT;
+    // descent: from the packet's own octet for a sibling, else from the root cell of the box
+    int s = sib ? (slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2))) : ((rz * K.by + ry) * K.bx + rx);
+    int l = sib ? L : 0;
+    const int lstop = place ? L : Lmax;
+    float rec = tree[s];
+    while (!(rec > 0.0f) && (l < lstop)) {
+        l++;
+        const int sh = Lmax - l;
+        s = soc_lt_link(rec) + (((Fx >> sh) & 1) | (((Fy >> sh) & 1) << 1) | (((Fz >> sh) & 1) << 2));
+        rec = tree[s];
+    }
+    if (place) {
+        if (l != L) return SOC_LT_LOST;
+        slot = s;  dens = rec;
+        return SOC_LT_INSIDE;
+    }
+    const int sh = Lmax - l;
+    const int nx = Fx >> sh, ny = Fy >> sh, nz = Fz >> sh;   // the leaf, on its level
+    const int qm = (l > 0) ? ~1 : 0;
+    const int qx = nx & qm, qy = ny & qm, qz = nz & qm;
+    if ((l != L) | (qx != ox) | (qy != oy) | (qz != oz)) {
+        // pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)); the constant is a dyadic number of few bits: exact
+        const float sc = soc_lt_pow2(l - L);
+        px = SOC_FMA(px, sc, SOC_FMA((float)ox, sc, -(float)qx));
+        py = SOC_FMA(py, sc, SOC_FMA((float)oy, sc, -(float)qy));
+        pz = SOC_FMA(pz, sc, SOC_FMA((float)oz, sc, -(float)qz));
+    }
+    cx = nx;  cy = ny;  cz = nz;
+    level = l;
+    slot = s;
+    dens = rec;
+    return SOC_LT_INSIDE;
+}
+
 #endif  // SOC_LTREE_H

@@ -123,6 +123,69 @@ int lt_trace(void *h, const float *pos, const float *dir, int maxsteps, int *lev
     return n;
 }
 
+// The same ray through soc_lt_move(), the single-path form the device walk uses: steps, arrivals in the next brick and --
+// after every move -- a placement of the packet's own cell, which must find the slot and the density the move reported.
+// status as lt_trace; -3: a placement disagreed.
+int lt_trace_move(void *h, const float *pos, const float *dir, int maxsteps, int *levels, int *cells, float *dss, float *endpos, int *status)
+{
+    Harness *H = (Harness *)h;
+    const int NX = H->NX, NY = H->NY, NZ = H->NZ, Lmax = H->LEVELS - 1;
+    int k = 1;
+    const int nmax = NX > NY ? (NX > NZ ? NX : NZ) : (NY > NZ ? NY : NZ);
+    while ((1 << k) <= nmax) k++;
+    const int kexp = k - 30;
+    float px = pos[0], py = pos[1], pz = pos[2];
+    const float ux = dir[0], uy = dir[1], uz = dir[2];
+    int level = 0, cx = 0, cy = 0, cz = 0, slot = -1, n = 0, Rx, Ry, Rz;
+    float dens = 0.0f;
+    *status = 0;
+    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
+    if ((px <= 0.0f) || (py <= 0.0f) || (pz <= 0.0f) || (px >= NX) || (py >= NY) || (pz >= NZ)) return 0;      // IndexG
+    int brick = H->B.rbrick[((int)floorf(pz) * NY + (int)floorf(py)) * NX + (int)floorf(px)];
+    int what = SOC_LTM_ARRIVE;                              // IndexG = an arrival of a root-level packet
+    while (true) {
+        const SocLBrick &K = H->B.bricks[brick];
+        const float *tree = H->B.btree.data() + K.base;
+        if (what == SOC_LTM_STEP) {
+            if (n >= maxsteps) { *status = 1;  break; }
+            levels[n] = level;
+            cells[n]  = H->B.bcell[K.base + slot];
+            const float ax = (ux > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(px)) / ux) : ((-PEPS - soc_fmod1f(px)) / ux);
+            const float ay = (uy > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(py)) / uy) : ((-PEPS - soc_fmod1f(py)) / uy);
+            const float az = (uz > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(pz)) / uz) : ((-PEPS - soc_fmod1f(pz)) / uz);
+            const float s = soc_fminf(ax, soc_fminf(ay, az));
+            px += s * ux;  py += s * uy;  pz += s * uz;
+            dss[n] = soc_scale_down(s, level);
+            n++;
+        }
+        const int L0 = level, c0x = cx, c0y = cy, c0z = cz;
+        const int r = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+        if (r == SOC_LT_EXIT) {
+            if (L0 > 0) {      // Index() leaves the root-grid position behind (kernel_ASOC_aux.c:238-241); the device walk has no use for it
+                const float sc = soc_lt_pow2(-L0);
+                px = SOC_FMA(px, sc, (float)(c0x & ~1) * sc);  py = SOC_FMA(py, sc, (float)(c0y & ~1) * sc);  pz = SOC_FMA(pz, sc, (float)(c0z & ~1) * sc);
+            }
+            break;
+        }
+        if (r == SOC_LT_SLOW) { *status = 2;  break; }
+        if (r == SOC_LT_LOST) { *status = -1;  break; }
+        if (r == SOC_LT_LEAVE) {
+            brick = H->B.rbrick[(Rz * NY + Ry) * NX + Rx];
+            what = SOC_LTM_ARRIVE;
+            continue;
+        }
+        {   // placement of the cell just found
+            int s2 = -1, l2 = level, ax2 = cx, ay2 = cy, az2 = cz, qx, qy, qz;
+            float d2 = 0.0f, p2x = px, p2y = py, p2z = pz;
+            const int r2 = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, SOC_LTM_PLACE, p2x, p2y, p2z, l2, ax2, ay2, az2, s2, d2, qx, qy, qz);
+            if (r2 != SOC_LT_INSIDE || s2 != slot || d2 != dens || l2 != level || p2x != px) { *status = -3;  break; }
+        }
+        what = SOC_LTM_STEP;
+    }
+    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
+    return n;
+}
+
 // soc_octbricks.h (bricks of the sweep that reads the hierarchy from global memory): build, then check what the device
 // relies on -- every cell owns exactly one (brick, slot) word, slots of a brick are dense and below 2^SOC_SLOT_BITS,
 // a brick exceeds `cap` cells only when it is a single refined cell standing for an oversized subtree's head,
