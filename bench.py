@@ -93,13 +93,14 @@ def c3_workload(GLOBAL_0):
         d = cloud.DENS[a:b]
         EMIT[a:b] = np.where(d > 0.0, 1.0e-30 * d, 0.0) * (C3_GL * launch.PARSEC / (8.0 ** level))
 
-    def step(i):
-        f = (21 * (i // 2) + 45) % NFREQ
-        kind = "ps" if (i % 2) == 0 else "cl"
+    def step_for(f, kind):
         dsc, csc = tables[f]
         return dict(kind=kind, L=LPS if kind == "ps" else LCL, ABS=AFABS[0][f], SCA=AFSCA[0][f], CSC=csc, DSC=dsc,
                     TW=np.float32(launch.trapezoid_weight(FFREQ, f)), BG=np.float32(0.0), IFREQ=f,
                     PS=PS[f:f + 1], PSPOS=PSPOS, EMIT=EMIT)
+
+    def step(i):
+        return step_for((21 * (i // 2) + 45) % NFREQ, "ps" if (i % 2) == 0 else "cl")
     name = ("C3: 256^3-root octree, LEVELS 4 (%d cells), GL 0.02 pc, 50 frequencies 1.5e11-2e15 Hz (own ABS, SCA, HG(g) "
             "table each), noabsorbed; step i = frequency (21*(i//2)+45)%%50, even: point source at (128.3,128.3,128.3) pspackets 1e9 "
             "= %d work items x BATCH %d = %d packets; odd: diffuse emission diffpack 1e9 = BATCH %d per cell = %d packets, "
@@ -107,7 +108,7 @@ def c3_workload(GLOBAL_0):
             "editing it (ASOC.py:86 hard-codes 32768; the `global` key is read by ASOCS.py:82 only)"
             % (cloud.CELLS, LPS["GLOBAL"], LPS["BATCH"], LPS["PACKETS"], LCL["BATCH"], LCL["BATCH"] * cloud.CELLS,
                min(LCL["GLOBAL"], cloud.CELLS), GLOBAL_0))
-    return dict(name=name, cloud=cloud, step=step, SEED=0.7853981634, ref_tag="oct256", kinds=("ps", "cl"))
+    return dict(name=name, cloud=cloud, step=step, step_for=step_for, NFREQ=NFREQ, SEED=0.7853981634, ref_tag="oct256", kinds=("ps", "cl"))
 
 
 def host_cores():
@@ -197,14 +198,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scaling", choices=["weak", "strong", "auto"], default="auto",
-                    help="auto = strong for N > 1 (work-item ranges of every launch), weak = replicas with per-rank seeds")
+    ap.add_argument("--scaling", choices=["weak", "strong", "launches", "auto"], default="auto",
+                    help="auto = strong for N > 1 (work-item ranges of every launch: equal packets and events per rank); launches = "
+                         "every rank a contiguous share of the launch sequence (whole launches + a work-item range at either end); "
+                         "weak = replicas with per-rank seeds")
+    ap.add_argument("--separate-kinds", action="store_true", help="point-source and diffuse launches in sweeps of their own (as in round 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-shape", action="store_true")
+    ap.add_argument("--no-per-kind", action="store_true", help="skip the per-kind sweeps after the timed region")
     ap.add_argument("--cpu-budget", type=float, default=16.0)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="launches executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
-                         "0 = the launches of one kind in equal sweeps of at most 16")
+                         "0 = all steps in one sweep (at most 128 launches)")
     ap.add_argument("--workload", choices=["C2", "C3"], default="C3",
                     help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]")
     ap.add_argument("--global", dest="global0", type=int, default=16777216,
@@ -257,41 +262,60 @@ def main():
     eng.zero(0)
 
     weak = args.scaling == "weak"
+    mixed_sweeps = (args.workload == "C3") and not args.separate_kinds     # the config-3 hierarchy: brick-local walk, kinds share sweeps
+    inflight = [0]                                                   # work items of this rank in its first sweep
     KDEV = 1.0 / world if weak else 1.0                              # ASOC.py:180,1501
 
-    def run_steps(i0, n, in_flight):
-        """Steps i0 .. i0+n-1, grouped by kind; every group in sweeps of at most `in_flight` launches; one all-reduce
-        of TABS per sweep when several ranks share the launches.  Returns the HIP-event time of the kernels [ms]."""
+    def run_steps(i0, n, in_flight, kinds=None):
+        """Steps i0 .. i0+n-1 (optionally those of some kinds only) in sweeps of at most `in_flight` launches (0: as many as a
+        sweep takes, 128).  On the config-3 hierarchy the kinds share sweeps; elsewhere a sweep holds one kind, so the launches
+        are ordered by kind.  Several ranks: every launch is split by work items (identical streams to one GPU), or -- --scaling
+        launches -- every rank takes a contiguous share of the launch sequence; ONE all-reduce of TABS after the last sweep.
+        Returns the HIP-event time of the kernels [ms]."""
         dev_id, ndev = (rank, world) if weak else (0, 1)
+        todo = [i for i in range(i0, i0 + n) if kinds is None or work["step"](i)["kind"] in kinds]
+        if not mixed_sweeps:
+            todo.sort(key=lambda i: work["kinds"].index(work["step"](i)["kind"]))
+        if weak or world == 1:
+            parts = [(0, work["step"](i)["L"]["GLOBAL"]) for i in todo]
+        elif args.scaling == "launches":
+            parts = launch.shard_launches([work["step"](i)["L"]["GLOBAL"] for i in todo], [work["step"](i)["L"]["PACKETS"] for i in todo], rank, world)
+        else:
+            parts = [launch.shard_range(work["step"](i)["L"]["GLOBAL"], rank, world) for i in todo]
+        mine = [(i, f, c) for i, (f, c) in zip(todo, parts) if c > 0]
+        cap = in_flight if in_flight > 0 else 128
+        chunks = []
+        for m in mine:
+            new = (not chunks or len(chunks[-1]) >= cap
+                   or (args.separate_kinds and work["step"](chunks[-1][-1][0])["kind"] != work["step"](m[0])["kind"]))
+            if new:
+                chunks.append([])
+            chunks[-1].append(m)
         eng.timer_start()
-        for kind in work["kinds"]:
-            todo = [i for i in range(i0, i0 + n) if work["step"](i)["kind"] == kind]
-            if not todo:
-                continue
-            nsw = -(-len(todo) // 16) if in_flight == 0 else -(-len(todo) // in_flight)
-            per = -(-len(todo) // nsw)
-            for a in range(0, len(todo), per):
-                eng.batch_begin(min(16, per))
-                for i in todo[a:a + per]:
-                    s = work["step"](i)
-                    L = s["L"]
-                    first, count = (0, L["GLOBAL"]) if weak else launch.shard_range(L["GLOBAL"], rank, world)
-                    seed = launch.launch_seed(work["SEED"], s["IFREQ"], DEVICES=ndev, ID=dev_id)
-                    eng.set_optical(s["ABS"], s["SCA"])
-                    eng.set_scatter_table(s["DSC"], s["CSC"])
-                    if kind == "cl":
-                        eng.sim_cl(2, L["PACKETS"], L["BATCH"], seed, np.float32(s["TW"] * KDEV), L["GLOBAL"], gid_first=first, gid_count=count)
-                    elif kind == "ps":
-                        eng.sim_pb(0, L["PACKETS"], L["BATCH"], seed, 0.0, s["TW"], PSPOS=s["PSPOS"], PS=s["PS"] * np.float32(KDEV),
-                                   GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-                    else:
-                        eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, np.float32(s["BG"] * KDEV), s["TW"],
-                                   GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-                eng.batch_end()
-                if world > 1:
-                    if stream is None:
-                        eng.sync()
-                    dist.all_reduce(tabs)
+        for chunk in chunks:
+            eng.batch_begin(len(chunk))
+            for i, first, count in chunk:
+                s = work["step"](i)
+                L = s["L"]
+                seed = launch.launch_seed(work["SEED"], s["IFREQ"], DEVICES=ndev, ID=dev_id)
+                eng.set_optical(s["ABS"], s["SCA"])
+                eng.set_scatter_table(s["DSC"], s["CSC"])
+                if s["kind"] == "cl":
+                    eng.sim_cl(2, L["PACKETS"], L["BATCH"], seed, np.float32(s["TW"] * KDEV), L["GLOBAL"], gid_first=first, gid_count=count)
+                elif s["kind"] == "ps":
+                    eng.sim_pb(0, L["PACKETS"], L["BATCH"], seed, 0.0, s["TW"], PSPOS=s["PSPOS"], PS=s["PS"] * np.float32(KDEV),
+                               GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+                else:
+                    eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, np.float32(s["BG"] * KDEV), s["TW"],
+                               GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+            eng.batch_end()
+        if world > 1:
+            # TABS integrates over frequency on the device (ASOC.py:1533): one all-reduce per source block, here per call.
+            # The local tally is the rank's share only, so the sum over ranks is the one-GPU tally (to summation order).
+            if stream is None:
+                eng.sync()
+            dist.all_reduce(tabs)
+        inflight[0] = max(inflight[0], max([sum(c for _, _, c in ch) for ch in chunks] or [0]))
         return eng.timer_stop()
 
     def fence():
@@ -318,6 +342,21 @@ def main():
 
     packets_rank = st["packets"]
     events_rank = st["tally_events"]
+    scat_rank = st["scatterings"]
+    freqs = sorted({int(work["step"](i)["IFREQ"]) for i in range(args.warmup, args.warmup + args.steps)})
+    # per-kind rates: the kinds share the timed sweep, so each kind's launches of the first 8 timed steps are run again in a
+    # sweep of their own (outside the timed region; fewer launches per sweep than the timed one)
+    per_kind = None
+    if rank == 0 and world == 1 and len(work["kinds"]) > 1 and not args.no_per_kind:
+        per_kind = {}
+        for kd in work["kinds"]:
+            eng.stats(reset=True)
+            ms = run_steps(args.warmup, min(args.steps, 8), 0, kinds=(kd,))
+            eng.sync()
+            sk = eng.stats()
+            if sk["packets"]:
+                per_kind[kd] = {"packets_per_s": sk["packets"] / ms * 1e3, "tally_events_per_packet": sk["tally_events"] / sk["packets"],
+                                "scatterings_per_packet": sk["scatterings"] / sk["packets"], "launches_in_the_sweep": min(args.steps, 8) // 2}
     if world > 1:
         dev = "cpu" if os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU") else "cuda"
         t = torch.tensor([elapsed, float(packets_rank), float(events_rank)], dtype=torch.float64, device=dev)
@@ -364,16 +403,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": work["name"], "packets_per_step_per_gpu": packets_rank // max(args.steps, 1),
                        "cells": cloud.CELLS, "tally_events_per_packet": events_rank / max(packets_rank, 1),
-                       "launches_per_sweep": args.in_flight if args.in_flight else "the launches of one kind, at most 16",
+                       "scatterings_per_packet": scat_rank / max(packets_rank, 1),
+                       "frequencies_in_the_timed_steps": freqs,
+                       "launches_per_sweep": args.in_flight if args.in_flight else "all steps in one sweep (point-source and diffuse launches together; at most 128)",
+                       "work_items_in_flight_rank0": inflight[0],
                        "parallelism": "1 process per GPU; %s" % (
-                           "replicas with per-rank seeds, weight 1/N + 1 RCCL all-reduce of TABS per sweep" if weak
-                           else "work-item ranges of every launch + 1 RCCL all-reduce of TABS per sweep (TABS integrates over frequency on the device)")},
+                           "replicas with per-rank seeds, weight 1/N + 1 RCCL all-reduce of TABS" if weak
+                           else ("a contiguous share of the launch sequence per rank" if args.scaling == "launches" else "work-item ranges of every launch")
+                           + " + 1 RCCL all-reduce of TABS after the last sweep (TABS integrates over frequency on the device)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
                          "kernel": kernel_name,
@@ -382,6 +425,8 @@ def main():
         }
         if ref_shape is not None:
             out["config"]["reference_launch_shape"] = ref_shape
+        if per_kind:
+            out["config"]["per_kind"] = per_kind
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(work, args.cpu_budget)

@@ -257,6 +257,14 @@ class AbsorptionRun:
             n = e.set_roi_save(U.ROI, U.ROI_STEP, U.ROI_NSIDE)
             self.ROI_SAVE = files.create_roi_save(U.FILE_ROI_SAVE, U.ROI, U.ROI_STEP, U.ROI_NSIDE, NFREQ) if self.rank == 0 \
                 else np.zeros((NFREQ, n), np.float32)
+        # TABS-only runs (noabsorbed): nothing is read back per frequency and CTABS is the sum over the source blocks, so ALL
+        # launches of the constant sources are handed to the engine as one batch: on hierarchies walked brick-locally the
+        # point-source, background and diffuse launches of all frequencies share brick sweeps (include/soc_hip.h:
+        # soc_batch_begin; up to 128 launches per sweep), elsewhere the engine starts a new sweep where the kind changes.
+        one_batch = (not self.with_int) and (not U.WITH_ROI_SAVE) and hasattr(e, "batch_begin") and U.ITERATIONS >= 1
+        if one_batch:
+            e.zero(0)
+            e.batch_begin(0)
         for II in range(4):
             if U.ITERATIONS < 1:
                 continue
@@ -285,10 +293,11 @@ class AbsorptionRun:
                 L = launch.roi_launch(U.ROIPAC, files.roi_elements(self.ROI_DIM), U.ROI_NSIDE)
                 self.log("=== ROI: GLOBAL %d, BATCH %d, elements %d" % (L["GLOBAL"], L["BATCH"], L["PACKETS"]))
             first, count = self.comm.shard(L["GLOBAL"]) if self.comm else (0, L["GLOBAL"])
-            e.zero(0)
+            if not one_batch:
+                e.zero(0)
             # TABS-only runs (noabsorbed): nothing is read back per frequency, so consecutive frequencies
             # are handed to the engine together and share brick sweeps (include/soc_hip.h: soc_batch_begin)
-            deferred = (not self.with_int) and self.ROI_SAVE is None and hasattr(e, "batch_begin")   # the engine decides per launch
+            deferred = (not one_batch) and (not self.with_int) and self.ROI_SAVE is None and hasattr(e, "batch_begin")   # the engine decides per launch
             # runs that keep the per-frequency absorptions, Cartesian grids: up to 16 frequencies per batch, every launch
             # with its own INT tally, read after the batch -- and summed over the ranks then, on its way to the host array.
             # (Hierarchies: one launch at a time; with `global` large enough each is a brick sweep of its own, the INT
@@ -366,7 +375,7 @@ class AbsorptionRun:
                     if len(group) == 16:
                         end_group()
                         e.batch_begin_int(16)
-                elif not deferred:
+                elif not (deferred or one_batch):
                     e.sync()
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
@@ -397,12 +406,25 @@ class AbsorptionRun:
                 t0 = time.time()
                 end_group()
                 self.timers["Tkernel"] += time.time() - t0
+            if one_batch:
+                continue                                   # the tally is read once, after the last block
             if self.comm:
                 self.comm.all_reduce_tally(e, 0)          # TABS: integrated over frequency on the device
             t0 = time.time()
             CTABS += e.read_tally(0)
             self.timers["Tpull"] += time.time() - t0
             self.log("******  CONSTANT   %10s   CTABS -> %12.4e" % (['PS', 'BG', 'DE', 'ROI'][II], float(np.mean(CTABS))))
+        if one_batch:
+            t0 = time.time()
+            e.batch_end()
+            e.sync()
+            self.timers["Tkernel"] += time.time() - t0
+            if self.comm:
+                self.comm.all_reduce_tally(e, 0)          # ONE all-reduce of TABS for all source blocks
+            t0 = time.time()
+            CTABS += e.read_tally(0)
+            self.timers["Tpull"] += time.time() - t0
+            self.log("******  CONSTANT   all source blocks   CTABS -> %12.4e" % float(np.mean(CTABS)))
         if self.ROI_LOAD is not None:
             e.set_roi_load(None, 0, None)
         if isinstance(self.ROI_SAVE, np.memmap):

@@ -89,6 +89,10 @@ struct SocDesc { int brick, start, count, pad; };
 #endif
 typedef float soc_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t soc_u2v __attribute__((ext_vector_type(2)));
+// Pointers that reach a kernel inside a struct are generic: the compiler emits FLAT loads and stores for them, and a flat
+// operation counts as an LDS operation too (lgkmcnt) -- every wait for an LDS read then waits for the global loads in flight
+// as well, the prefetched packet records included.  The walk's loop casts its pointers to the global address space.
+#define SOC_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ float4 soc_ld4(const float4 *p) { const soc_f4v v = SOC_NT_LOAD((const soc_f4v *)p);  return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void soc_st4(float4 *p, float4 a) { soc_f4v v = { a.x, a.y, a.z, a.w };  SOC_NT_STORE(v, (soc_f4v *)p); }
 
@@ -622,7 +626,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     const bool parked = __builtin_amdgcn_readfirstlane(D.pad) != 0;      // too few packets for a workgroup: they stay in the queue this pass (soc_brick_scan)
     const int BV = A.CAP;                                  // slots in LDS
     const int nthr = (int)blockDim.x;
-    SocPk2 *pk = A.pk;
+    SOC_GLOBAL SocPk2 *pk = (SOC_GLOBAL SocPk2 *)A.pk;
 
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
@@ -660,15 +664,15 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     // lanes of a spill VGPR (v_readlane, no memory).
     int NX = G.NX, NY = G.NY, NZ = G.NZ, Lmax = G.LEVELS - 1, kexp = A.kexp;
     asm volatile("" : "+s"(NX), "+s"(NY), "+s"(NZ), "+s"(Lmax), "+s"(kexp));
-    uint32_t *keyq_c = A.keyq + D.start;                  // this chunk's part of the queue arrays
-    const uint32_t *idq_c = A.idq + D.start;
+    SOC_GLOBAL uint32_t *keyq_c = (SOC_GLOBAL uint32_t *)(A.keyq + D.start);          // this chunk's part of the queue arrays
+    const SOC_GLOBAL uint32_t *idq_c = (const SOC_GLOBAL uint32_t *)(A.idq + D.start);
     asm volatile("" : "+s"(pk), "+s"(keyq_c), "+s"(idq_c));
     float px = 0.0f, py = 0.0f, pz = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
     float photons = 0.0f, free_path = 0.0f, tau = 0.0f, dens = 0.0f;
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;                 // GetStep's target inside the cell per axis: 1 + PEPS or -PEPS
     float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
-    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;
+    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, obase = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;      // obase: slot of the first cell of the packet's octet
     int   what = SOC_LTM_STEP;                              // what the Index() part has to do for the lane: finish a step, an arrival, or find the packet's cell
     bool  nonudge = false;                                 // SimRAM_CL: no nudge after a failed step (kernel_ASOC.c:1530-1540 has none)
     uint32_t dz = 0, dw = 0, wid = 0;
@@ -685,7 +689,10 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     // The loop has two arms.  SWAP (entered when A.FTH lanes of the wave wait for it, or nobody can step): the lane's packet
     // goes back to memory with the queue it belongs to next, the prefetched one is taken up.  STEP (every iteration): GetStep's
     // arithmetic and the tally -- skipped by a lane whose packet has just come in from another brick or still needs its
-    // cell looked up -- and then Index() in the one-path form of soc_ltree.h (soc_lt_move), which serves all of them.
+    // cell looked up -- and Index() in the one-path form of soc_ltree.h (soc_lt_aim / soc_lt_land), which serves all of them.
+    // Reads of LDS are issued ahead of the arithmetic that does not need them (the slot Index() starts from before the
+    // exponential of the tally; the three reads of the swap arm together, before the stores), so a wave waits for LDS once
+    // per arm, not once per read.
     while (!parked) {
         {
             SOC_PROF(0, 1);  SOC_PROF(1, __popcll(__ballot(mode == SOC_BM_STEP)));  SOC_PROF(7, __popcll(__ballot(mode == SOC_BM_IDLE)));
@@ -702,51 +709,58 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     // visit ahead of its use, so nothing in this arm waits for global memory.  The chunk itself is never
                     // copied: ids, queues and places stay in global memory (idq, keyq, posq), so a chunk may be the whole
                     // queue of the brick.
+                    // (1) the lane reserves the packet after next: one LDS atomic per wave, neighbouring lanes read neighbouring ids
+                    const unsigned long long am = __ballot(true);
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                    int base = 0;
+                    if (rank == 0) base = atomicAdd(&sCtl[0], __popcll(am));
                     asm volatile("" :: "v"(na), "v"(nb), "v"(nc), "v"(ndzw), "v"(nnwid));      // what is in flight has landed: no later use waits behind the stores below
+                    // (2) what the prefetched packet needs from LDS -- its launch's constants and, for a root-level packet, the root cell
+                    // it is in (or comes into: ARRIVE) -- is asked for now; addresses from a stale record (no packet) stay inside the arrays
+                    const int  n_cz = __float_as_int(nc.w);
+                    const int  n_lq = (int)(((uint32_t)n_cz >> SOC_LQ_SHIFT) & (SOC_MAXLAUNCH - 1));
+                    const bool n_arrive = (ndzw.y & SOC_LT_ARRIVE) != 0u;
+                    const int  n_ix = n_arrive ? (int)soc_floorf(na.x) : __float_as_int(nc.y), n_iy = n_arrive ? (int)soc_floorf(na.y) : __float_as_int(nc.z),
+                               n_iz = n_arrive ? (int)soc_floorf(na.z) : (n_cz & ((1 << SOC_LQ_SHIFT) - 1));
+                    int n_s2 = SOC_MAD24(SOC_MAD24(n_iz - KB.z0, KB.by, n_iy - KB.y0), KB.bx, n_ix - KB.x0);
+                    n_s2 = ((unsigned)n_s2 < (unsigned)KB.nslot) ? n_s2 : 0;
+                    const soc_f4v l4 = *(const soc_f4v *)&sL[4 * n_lq];
+                    const float n_rec = sD[n_s2];
+                    // (3) the packet in hand goes back to memory
                     if (have) {
-                        SocPk2 *q = pk + wid;
+                        SOC_GLOBAL SocPk2 *q = pk + wid;
                         // (the brick of the root cell a leaving packet goes to -- key < 0: -1 - root cell -- is looked up after
                         // the walk, for all packets of the chunk at once: loaded when the packet leaves it made EVERY iteration
                         // wait for all loads in flight, 19 % of the wave's cycles; loaded here, every entry of this arm one L2 latency)
-                        soc_st4(&q->A, make_float4(px, py, pz, photons));
-                        soc_st4(&q->C, make_float4(tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz | (lq << SOC_LQ_SHIFT))));
+                        { const soc_f4v v = { px, py, pz, photons };  SOC_NT_STORE(v, (SOC_GLOBAL soc_f4v *)&q->A); }
+                        { const soc_f4v v = { tau, __int_as_float(cx), __int_as_float(cy), __int_as_float(cz | (lq << SOC_LQ_SHIFT)) };  SOC_NT_STORE(v, (SOC_GLOBAL soc_f4v *)&q->C); }
                         q->D.z = (dz & 0x1fffffffu) | ((uint32_t)level << 29);
                         q->D.w = dw;
                         SOC_NT_STORE((uint32_t)key, &keyq_c[cslot]);              // its rank in that queue is settled after the walk, for all packets at once
                     }
-                    // the prefetched packet becomes the current one
+                    // (4) the prefetched packet becomes the current one
                     have = nhave;
                     wid = nwid;  cslot = nslot;
                     if (have) {
-                        dz = ndzw.x;  dw = ndzw.y;
+                        dz = ndzw.x;  dw = ndzw.y & ~SOC_LT_ARRIVE;
                         px = na.x;  py = na.y;  pz = na.z;  photons = na.w;
                         ux = nb.x;  uy = nb.y;  uz = nb.z;  free_path = nb.w;
                         rux = 1.0f / ux;  ruy = 1.0f / uy;  ruz = 1.0f / uz;
                         gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;
-                        tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = __float_as_int(nc.w);
-                        lq = (int)((uint32_t)cz >> SOC_LQ_SHIFT);  cz &= (1 << SOC_LQ_SHIFT) - 1;      // the launch of the work item
+                        tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = n_cz & ((1 << SOC_LQ_SHIFT) - 1);
+                        lq = n_lq;                                                // the launch of the work item
                         level = (int)(dz >> 29);
-                        {
-                            const soc_f4v l4 = *(const soc_f4v *)&sL[4 * lq];
-                            kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = (__float_as_int(l4.w) & 1) != 0;
-                        }
+                        kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = (__float_as_int(l4.w) & 1) != 0;
                         nvisit = 0;
                         mode = SOC_BM_STEP;
-                        slot = -1;
+                        slot = -1;  obase = -1;
                         // The first pass of the packet through the Index() part finds its cell in this brick: the second half of
                         // the step that brought it here (ARRIVE), or the cell its coordinates name.  A root-level packet in (or
                         // into) a root cell that is not refined -- the common case -- is settled here.
-                        const bool arrive = (dw & SOC_LT_ARRIVE) != 0u;
-                        dw &= ~SOC_LT_ARRIVE;
-                        what = arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE;
-                        if (level == 0) {
-                            const int ix = arrive ? (int)soc_floorf(px) : cx, iy = arrive ? (int)soc_floorf(py) : cy, iz = arrive ? (int)soc_floorf(pz) : cz;
-                            const int s2 = ((iz - KB.z0) * KB.by + (iy - KB.y0)) * KB.bx + (ix - KB.x0);
-                            const float rec = sD[s2];
-                            if (!arrive || (rec > 0.0f)) { slot = s2;  dens = rec;  cx = ix;  cy = iy;  cz = iz;  what = SOC_LTM_STEP; }
-                        }
+                        what = n_arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE;
+                        if ((level == 0) && (!n_arrive || (n_rec > 0.0f))) { slot = n_s2;  dens = n_rec;  cx = n_ix;  cy = n_iy;  cz = n_iz;  what = SOC_LTM_STEP; }
                     }
-                    // the record of the packet after it (its id has arrived)
+                    // (5) the record of the packet after it (its id has arrived), and the id of the one after that
                     nhave = nnhave;
                     nwid = nnwid;  nslot = nnslot;
                     asm volatile("" : "+v"(nwid) :: "memory");                // (the copy is made HERE: nnwid is dead below and the load at the end of the arm lands
@@ -754,17 +768,11 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                                                                               //  EVERY load in flight -- the records just asked for -- and copies: 14 % of the cycles)
                     if (nhave) {
                         // (vector-typed loop variables: the loads land in the registers that carry the values around the loop)
-                        const SocPk2 *q = pk + nwid;
-                        na = SOC_NT_LOAD((const soc_f4v *)&q->A);  nb = SOC_NT_LOAD((const soc_f4v *)&q->B);  nc = SOC_NT_LOAD((const soc_f4v *)&q->C);
-                        ndzw = *(const soc_u2v *)&q->D.z;
+                        const SOC_GLOBAL SocPk2 *q = pk + nwid;
+                        na = SOC_NT_LOAD((const SOC_GLOBAL soc_f4v *)&q->A);  nb = SOC_NT_LOAD((const SOC_GLOBAL soc_f4v *)&q->B);  nc = SOC_NT_LOAD((const SOC_GLOBAL soc_f4v *)&q->C);
+                        ndzw = *(const SOC_GLOBAL soc_u2v *)&q->D.z;
                     }
-                    {   // and the lane reserves the one after that: one LDS atomic per wave, neighbouring lanes read neighbouring ids
-                        const unsigned long long am = __ballot(true);
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                        int base = 0;
-                        if (rank == 0) base = atomicAdd(&sCtl[0], __popcll(am));
-                        nnslot = __builtin_amdgcn_readfirstlane(base) + rank;
-                    }
+                    nnslot = __builtin_amdgcn_readfirstlane(base) + rank;
                     nnhave = nnslot < D.count;
                     if (nnhave) nnwid = SOC_NT_LOAD(&idq_c[nnslot]);
                     if (!have) mode = (nhave | nnhave) ? SOC_BM_SWAP : SOC_BM_IDLE;      // (the first two turns of a lane only reserve)
@@ -776,7 +784,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
         if (mode == SOC_BM_STEP) {
             bool move = true;
             const int slot0 = slot;
-            // ---- one cell step (kernel_ASOC.c:565-683) ----
+            float tauA = 0.0f, dtau = 0.0f;
+            // ---- one cell step (kernel_ASOC.c:565-683): GetStep ----
             if (what == SOC_LTM_STEP) {
                 const float p0x = px, p0y = py, p0z = pz;
                 float fx, fy, fz;
@@ -793,31 +802,41 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 py += ds * uy;
                 pz += ds * uz;
                 ds = ds * soc_lt_pow2(-level);                                    // ldexp(ds, -level)
-                const float tauA = ds * dens * kabs;
-                const float dtau = ds * dens * ksca;
+                tauA = ds * dens * kabs;
+                dtau = ds * dens * ksca;
                 if (free_path < (tau + dtau)) {
                     px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
                     mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 1;             // -> scattering queue of its launch
                     move = false;
-                } else {
-                    const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
-                    const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                    atomicAdd(&sT[slot0], delta * tw);
-                    if (WINT) atomicAdd(&sI[slot0], delta);
-                    n_tally++;
-                    photons *= e;
-                    tau += dtau;
                 }
             }
-            SOC_PROF_T(1);                                 // step
-            // ---- Index (kernel_ASOC_aux.c:198-278) ----
+            // ---- Index (kernel_ASOC_aux.c:198-278), first half: where the point is, and the read of the slot the descent starts from ----
+            SocLtAim AM;
+            int   r = SOC_LT_LOST;
+            float rec = 1.0f;
             if (move) {
-                int r, Rx, Ry, Rz;
-                if ((A.slow_every > 0) && (what == SOC_LTM_STEP) && (level > 0) && (((n_tally + wid) % (unsigned)A.slow_every) == 0u)) {
+                if ((A.slow_every > 0) && (what == SOC_LTM_STEP) && (level > 0) && (((n_tally + 1u + wid) % (unsigned)A.slow_every) == 0u)) {
                     r = SOC_LT_SLOW;                                              // test knob: this step goes through the slow-step queue
                 } else {
-                    r = soc_lt_move(sD, KB, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+                    soc_lt_aim(KB, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, obase, AM);
+                    r = AM.r;
+                    rec = sD[AM.s];
                 }
+            }
+            // ---- the tally of the step (the LDS read above is in flight meanwhile) ----
+            if (move && (what == SOC_LTM_STEP)) {
+                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
+                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+                atomicAdd(&sT[slot0], delta * tw);
+                if (WINT) atomicAdd(&sI[slot0], delta);
+                n_tally++;
+                photons *= e;
+                tau += dtau;
+            }
+            SOC_PROF_T(1);                                 // GetStep + tally
+            // ---- Index, second half: the descent to the leaf, the packet's new place ----
+            if (move) {
+                if (r == SOC_LT_INSIDE) r = soc_lt_land(sD, AM, Lmax, what, rec, px, py, pz, level, cx, cy, cz, slot, obase, dens);
                 if (r == SOC_LT_INSIDE) {
                     if (what != SOC_LTM_PLACE) {
                         if (!nonudge && (slot == slot0)) {                        // failed step: nudge (SimRAM_PB / HP only)
@@ -827,7 +846,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
                     }
                 } else if (r == SOC_LT_LEAVE) {
-                    mode = SOC_BM_SWAP;  key = -1 - ((Rz * NY + Ry) * NX + Rx);  dw |= SOC_LT_ARRIVE;      // (the brick of that root cell: looked up after the walk)
+                    mode = SOC_BM_SWAP;  key = -1 - SOC_MAD24(SOC_MAD24(AM.Rz, NY, AM.Ry), NX, AM.Rx);  dw |= SOC_LT_ARRIVE;   // (the brick of that root cell: looked up after the walk; N < 4096)
                 } else if (r == SOC_LT_EXIT) {
                     mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
                 } else if (r == SOC_LT_SLOW) {
@@ -1550,7 +1569,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     // grid does not allow it (per-cell opacities, more than 8 levels, coordinates beyond 24 bits, a root cell whose
     // subtree exceeds the brick) or soc_set_tuning("global_tree", 1) asks for the older form
     if (V.octree && V.dbl && !V.abu && !tune.global_tree && G.LEVELS <= 8
-        && ((long long)std::max(G.NX, std::max(G.NY, G.NZ)) << (G.LEVELS - 1)) < (1LL << 24)) {
+        && ((long long)std::max(G.NX, std::max(G.NY, G.NZ)) << (G.LEVELS - 1)) < (1LL << 24)
+        && std::max(G.NX, std::max(G.NY, G.NZ)) < 4096) {        // (root-cell numbers from 24-bit multiplies: SOC_MAD24)
         // cells per brick: what lets two workgroups share a CU's 160 KB of LDS (8 B per cell, 12 B with the INT tally, + 9 KB)
         const int capl = (tune.CAP > 0) ? tune.CAP : (V.wint ? 5888 : 8704);
         if (capl < 8 || capl > 36864) return hipErrorInvalidValue;

@@ -154,7 +154,7 @@ static bool lt_capable(const soc_ctx *c, bool abu)
     const SocGrid &G = c->G;
     const int n = G.NX > G.NY ? (G.NX > G.NZ ? G.NX : G.NZ) : (G.NY > G.NZ ? G.NY : G.NZ);
     return G.LEVELS > 1 && G.LEVELS <= 8 && G.NX > ((G.LEVELS < 3) ? 399 : 100) && !abu && !c->tune.global_tree
-           && (((long long)n << (G.LEVELS - 1)) < (1LL << 24));
+           && (((long long)n << (G.LEVELS - 1)) < (1LL << 24)) && n < 4096;
 }
 #define SOC_LT_LONE_LAUNCH 1000000                           // work items from which a lone launch goes to the sweep there
 

@@ -35,6 +35,19 @@ struct SocLBrick {
 
 enum { SOC_LT_INSIDE = 0, SOC_LT_LEAVE = 1, SOC_LT_EXIT = 2, SOC_LT_SLOW = 3 };
 
+// a * b + c of small non-negative numbers (slots of a brick's box: all below 2^24).  On the device a 24-bit multiply: for the
+// plain int expression the compiler picks v_mad_u64_u32, whose 64-bit addend is a register PAIR -- the unused half may be a
+// register with a load in flight, and the instruction then waits for ALL loads in flight (seen in the walk: the prefetched
+// packet records).
+#if defined(__HIP_DEVICE_COMPILE__)
+// (b is workgroup-uniform wherever this is used: a scalar register.  Written as the instruction itself: where the compiler
+// can bound the operands it turns __mul24 back into a plain multiply and selects the 64-bit form again.)
+__device__ __forceinline__ int soc_mad24(int a, int b, int c) { int r;  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));  return r; }
+#  define SOC_MAD24(a, b, c) soc_mad24((a), (b), (c))
+#else
+#  define SOC_MAD24(a, b, c) ((a) * (b) + (c))
+#endif
+
 SOC_HD int soc_lt_link(float d) { return (int)(soc_f2u(d) ^ 0x80000000u); }
 
 // exact 2^k for -126 <= k <= 127
@@ -183,89 +196,113 @@ SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, c
 // point's cell are F >> (Lmax - l), so the descent from the brick's root cell (or, for a sibling, from the packet's
 // own octet) is one loop with one LDS read per level, and the new local position is one fma, as in soc_lt_settle.
 //
-//   what == SOC_LTM_STEP   : pos has been advanced by GetStep's arithmetic; the packet's cell is (level, c, slot);
-//   what == SOC_LTM_ARRIVE : the same for a packet that comes from another brick (its slot means nothing here);
-//   what == SOC_LTM_PLACE  : find slot and density of the packet's own cell (level, c); pos is not touched.
-// Returns SOC_LT_INSIDE / LEAVE / EXIT / SLOW as soc_lt_step does (LEAVE, EXIT and SLOW change nothing), or
-// SOC_LT_LOST when a placement does not find the cell (a broken record; the walk retires the packet).
+// Two halves, so that the walk can put other work between the first LDS read and its use:
+//   soc_lt_aim()   where the point is: F, its root cell R, the outcome if it is already known (LEAVE, EXIT, SLOW) and
+//                  the slot `s` (on level `l`) at which the descent starts;
+//   soc_lt_land()  given tree[s]: the descent to the leaf and the packet's new place.
+// The packet's place is (level, c, slot, obase): obase = slot of the first cell of its octet (level > 0).
+//   what == SOC_LTM_STEP   : pos has been advanced by GetStep's arithmetic;
+//   what == SOC_LTM_ARRIVE : the same for a packet that comes from another brick (slot and obase mean nothing yet);
+//   what == SOC_LTM_PLACE  : find slot, obase and density of the packet's own cell (level, c); pos is not touched.
+// Outcomes as soc_lt_step (LEAVE, EXIT and SLOW change nothing), or SOC_LT_LOST when a placement does not find the cell
+// (a broken record; the walk retires the packet).
 // kexp = k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_degenerate (2^(kexp+L)) and of the sibling case (2^(kexp+1)).
 // ---------------------------------------------------------------------------------------------------------------
 enum { SOC_LTM_STEP = 0, SOC_LTM_ARRIVE = 1, SOC_LTM_PLACE = 2 };
 enum { SOC_LT_LOST = 4 };
 
-template <typename TREE>
-SOC_HD int soc_lt_move(const TREE tree, const SocLBrick &K, const int NX, const int NY, const int NZ, const int Lmax, const int kexp,
-                       const int what, float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens,
-                       int &Rx, int &Ry, int &Rz)
+struct SocLtAim {
+    int Fx, Fy, Fz;            // the point on the finest level
+    int Rx, Ry, Rz;            // its root cell
+    int ox, oy, oz;            // origin of the packet's octet on its level (0 on the root grid)
+    int s, l;                  // the descent starts at slot s, a cell of level l
+    int r;                     // SOC_LT_INSIDE: go on with soc_lt_land(tree[s]); else the outcome
+};
+
+SOC_HD void soc_lt_aim(const SocLBrick &K, const int NX, const int NY, const int NZ, const int Lmax, const int kexp, const int what,
+                       const float px, const float py, const float pz, const int level, const int cx, const int cy, const int cz,
+                       const int obase, SocLtAim &A)
 {
     const int  L = level, D = Lmax - L;
-    const bool place = (what == SOC_LTM_PLACE);
-    const int  om = (L > 0) ? ~1 : 0;
-    const int  ox = cx & om, oy = cy & om, oz = cz & om;
+    const bool place = (what == SOC_LTM_PLACE), deep = (L > 0);
+    const int  om = deep ? ~1 : 0;
+    A.ox = cx & om;  A.oy = cy & om;  A.oz = cz & om;
     int Jx, Jy, Jz;                                          // floor(pos * 2^D): the cell within the octet and D digits below it
-    if (place) {
-        Jx = (int)((unsigned)(cx - ox) << D);  Jy = (int)((unsigned)(cy - oy) << D);  Jz = (int)((unsigned)(cz - oz) << D);
-    } else {
+    {
         const float sc = soc_lt_pow2(D);
         Jx = (int)soc_floorf(px * sc);  Jy = (int)soc_floorf(py * sc);  Jz = (int)soc_floorf(pz * sc);
     }
-    const int ix = Jx >> D, iy = Jy >> D, iz = Jz >> D;      // floor(pos)
-    const int Fx = (int)((unsigned)ox << D) + Jx, Fy = (int)((unsigned)oy << D) + Jy, Fz = (int)((unsigned)oz << D) + Jz;
-    bool sib = false, slow = false, out0 = false;
-    if (!place) {
-        if (L > 0) {
-            sib = (((ix | iy | iz) & ~1) == 0);
-            if (sib) {
-                slow = !(soc_fminf(px, soc_fminf(py, pz)) >= soc_lt_pow2(kexp + 1));
-            } else {
-                slow = soc_lt_degenerate(px, py, pz, soc_floorf(px), soc_floorf(py), soc_floorf(pz), soc_lt_pow2(kexp + L));
-            }
-        } else {
-            out0 = (px == 0.0f) | (py == 0.0f) | (pz == 0.0f);               // root grid: pos <= 0 leaves the model (:214)
-        }
-    }
-    Rx = Fx >> Lmax;  Ry = Fy >> Lmax;  Rz = Fz >> Lmax;
-    if (slow) return SOC_LT_SLOW;
-    const int  rx = Rx - K.x0, ry = Ry - K.y0, rz = Rz - K.z0;
+    if (place) { Jx = (int)((unsigned)(cx - A.ox) << D);  Jy = (int)((unsigned)(cy - A.oy) << D);  Jz = (int)((unsigned)(cz - A.oz) << D); }
+    A.Fx = (int)((unsigned)A.ox << D) + Jx;  A.Fy = (int)((unsigned)A.oy << D) + Jy;  A.Fz = (int)((unsigned)A.oz << D) + Jz;
+    A.Rx = A.Fx >> Lmax;  A.Ry = A.Fy >> Lmax;  A.Rz = A.Fz >> Lmax;
+    // a sibling in the packet's own octet: floor(pos) in {0,1}^3, i.e. nothing of J above bit D
+    const bool sib = deep & !place & ((((unsigned)(Jx | Jy | Jz)) >> (D + 1)) == 0u);
+    // not for exact geometry to decide (soc_lt_degenerate; a sibling: POS/2 + octant only, bound 2^(kexp+1))
+    const float mabs = soc_fminf(soc_fabsf(px), soc_fminf(soc_fabsf(py), soc_fabsf(pz)));
+    const float mmin = soc_fminf(px, soc_fminf(py, pz));
+    const bool onface = (px == soc_floorf(px)) || (py == soc_floorf(py)) || (pz == soc_floorf(pz));
+    const bool slow = deep & !place & (sib ? !(mmin >= soc_lt_pow2(kexp + 1)) : (!(mabs >= soc_lt_pow2(kexp + L)) | onface));
+    const bool out0 = !deep & !place & ((px == 0.0f) | (py == 0.0f) | (pz == 0.0f));   // root grid: pos <= 0 leaves the model (:214)
+    const int  rx = A.Rx - K.x0, ry = A.Ry - K.y0, rz = A.Rz - K.z0;
     const bool inbox = !(((unsigned)rx >= (unsigned)K.bx) | ((unsigned)ry >= (unsigned)K.by) | ((unsigned)rz >= (unsigned)K.bz));
-    if (!sib && !inbox) {
-        if (place) return SOC_LT_LOST;
-        if (out0 | ((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ)) return SOC_LT_EXIT;
-        return SOC_LT_LEAVE;
-    }
-    if (out0) return SOC_LT_EXIT;
-    // descent: from the packet's own octet for a sibling, else from the root cell of the box
-    int s = sib ? (slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (ix | (iy << 1) | (iz << 2))) : ((rz * K.by + ry) * K.bx + rx);
-    int l = sib ? L : 0;
-    const int lstop = place ? L : Lmax;
-    float rec = tree[s];
+    const bool outside = out0 | ((unsigned)A.Rx >= (unsigned)NX) | ((unsigned)A.Ry >= (unsigned)NY) | ((unsigned)A.Rz >= (unsigned)NZ);
+    const int  sroot = SOC_MAD24(SOC_MAD24(rz, K.by, ry), K.bx, rx);
+    const int  ssib  = obase + (((Jx >> D) & 1) | (((Jy >> D) & 1) << 1) | (((Jz >> D) & 1) << 2));
+    const bool go = !slow & (sib | (inbox & !out0));
+    A.s = go ? (sib ? ssib : sroot) : 0;
+    A.l = sib ? L : 0;
+    A.r = go ? SOC_LT_INSIDE : (slow ? SOC_LT_SLOW : (place ? SOC_LT_LOST : (outside ? SOC_LT_EXIT : SOC_LT_LEAVE)));
+}
+
+// rec = tree[A.s].  Only for A.r == SOC_LT_INSIDE.
+template <typename TREE>
+SOC_HD int soc_lt_land(const TREE tree, const SocLtAim &A, const int Lmax, const int what, float rec,
+                       float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, int &obase, float &dens)
+{
+    const int  L = level;
+    const bool place = (what == SOC_LTM_PLACE);
+    const int  lstop = place ? L : Lmax;
+    int s = A.s, l = A.l, base = obase;
     while (!(rec > 0.0f) && (l < lstop)) {
         l++;
         const int sh = Lmax - l;
-        s = soc_lt_link(rec) + (((Fx >> sh) & 1) | (((Fy >> sh) & 1) << 1) | (((Fz >> sh) & 1) << 2));
+        base = soc_lt_link(rec);
+        s = base + (((A.Fx >> sh) & 1) | (((A.Fy >> sh) & 1) << 1) | (((A.Fz >> sh) & 1) << 2));
         rec = tree[s];
     }
     if (place) {
         if (l != L) return SOC_LT_LOST;
-        slot = s;  dens = rec;
+        slot = s;  obase = base;  dens = rec;
         return SOC_LT_INSIDE;
     }
     const int sh = Lmax - l;
-    const int nx = Fx >> sh, ny = Fy >> sh, nz = Fz >> sh;   // the leaf, on its level
+    const int nx = A.Fx >> sh, ny = A.Fy >> sh, nz = A.Fz >> sh;            // the leaf, on its level
     const int qm = (l > 0) ? ~1 : 0;
-    const int qx = nx & qm, qy = ny & qm, qz = nz & qm;
-    if ((l != L) | (qx != ox) | (qy != oy) | (qz != oz)) {
-        // pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)); the constant is a dyadic number of few bits: exact
-        const float sc = soc_lt_pow2(l - L);
-        px = SOC_FMA(px, sc, SOC_FMA((float)ox, sc, -(float)qx));
-        py = SOC_FMA(py, sc, SOC_FMA((float)oy, sc, -(float)qy));
-        pz = SOC_FMA(pz, sc, SOC_FMA((float)oz, sc, -(float)qz));
-    }
+    // pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)); the constant is a dyadic number of few bits: exact.  Same level and
+    // same octet: pos * 1 + 0 = pos (pos is never a zero here: a coordinate on a cell face went to SOC_LT_SLOW or SOC_LT_EXIT).
+    const float sc = soc_lt_pow2(l - L);
+    px = SOC_FMA(px, sc, SOC_FMA((float)A.ox, sc, -(float)(nx & qm)));
+    py = SOC_FMA(py, sc, SOC_FMA((float)A.oy, sc, -(float)(ny & qm)));
+    pz = SOC_FMA(pz, sc, SOC_FMA((float)A.oz, sc, -(float)(nz & qm)));
     cx = nx;  cy = ny;  cz = nz;
     level = l;
     slot = s;
+    obase = base;
     dens = rec;
     return SOC_LT_INSIDE;
+}
+
+// both halves in one call (host harness, slow paths)
+template <typename TREE>
+SOC_HD int soc_lt_move(const TREE tree, const SocLBrick &K, const int NX, const int NY, const int NZ, const int Lmax, const int kexp,
+                       const int what, float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, int &obase,
+                       float &dens, int &Rx, int &Ry, int &Rz)
+{
+    SocLtAim A;
+    soc_lt_aim(K, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, obase, A);
+    Rx = A.Rx;  Ry = A.Ry;  Rz = A.Rz;
+    if (A.r != SOC_LT_INSIDE) return A.r;
+    return soc_lt_land(tree, A, Lmax, what, tree[A.s], px, py, pz, level, cx, cy, cz, slot, obase, dens);
 }
 
 #endif  // SOC_LTREE_H

@@ -132,6 +132,34 @@ def shard_range(GLOBAL, rank, world):
     return first, last - first
 
 
+def shard_launches(globals_, weights, rank, world):
+    """Split a SEQUENCE of launches (the frequencies of the source blocks of a run, ASOC.py:1028-1545) over `world` GPUs:
+    rank r executes a contiguous share of the sequence -- whole launches, at full population, and a work-item range of
+    the launch at either end of its share -- so that every rank simulates the same number of packets (`weights`: packets
+    per launch).  Returns [(first, count)] per launch (count 0: not this rank's).  Cut points depend on the sequence only,
+    so all ranks agree; boundaries are multiples of 64 work items.  With one launch this is shard_range."""
+    n = len(globals_)
+    cum = [0.0]
+    for w in weights:
+        cum.append(cum[-1] + float(w))
+    total = cum[-1]
+    out = []
+    for i in range(n):
+        G = int(globals_[i])
+        a, b = cum[i], cum[i + 1]
+
+        def cut(k):
+            x = total * k / world
+            if x <= a or b <= a:
+                return 0
+            if x >= b:
+                return G
+            return min(G, Fix(int(G * (x - a) / (b - a)), 64))
+        first, last = cut(rank), (G if rank == world - 1 else cut(rank + 1))
+        out.append((first, max(0, last - first)))
+    return out
+
+
 H_K_D = 4.79924335e-11                 # ASOC_aux.py:36
 H_CC20 = 7.372496678e-28                # ASOC_aux.py:40
 NE_TEMPERATURE = 30000                  # ASOC.py:641

@@ -136,7 +136,7 @@ int lt_trace_move(void *h, const float *pos, const float *dir, int maxsteps, int
     const int kexp = k - 30;
     float px = pos[0], py = pos[1], pz = pos[2];
     const float ux = dir[0], uy = dir[1], uz = dir[2];
-    int level = 0, cx = 0, cy = 0, cz = 0, slot = -1, n = 0, Rx, Ry, Rz;
+    int level = 0, cx = 0, cy = 0, cz = 0, slot = -1, obase = -1, n = 0, Rx, Ry, Rz;
     float dens = 0.0f;
     *status = 0;
     endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
@@ -159,7 +159,7 @@ int lt_trace_move(void *h, const float *pos, const float *dir, int maxsteps, int
             n++;
         }
         const int L0 = level, c0x = cx, c0y = cy, c0z = cz;
-        const int r = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
+        const int r = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, slot, obase, dens, Rx, Ry, Rz);
         if (r == SOC_LT_EXIT) {
             if (L0 > 0) {      // Index() leaves the root-grid position behind (kernel_ASOC_aux.c:238-241); the device walk has no use for it
                 const float sc = soc_lt_pow2(-L0);
@@ -172,13 +172,14 @@ int lt_trace_move(void *h, const float *pos, const float *dir, int maxsteps, int
         if (r == SOC_LT_LEAVE) {
             brick = H->B.rbrick[(Rz * NY + Ry) * NX + Rx];
             what = SOC_LTM_ARRIVE;
+            slot = obase = -1;                                 // (they mean nothing in the next brick)
             continue;
         }
         {   // placement of the cell just found
-            int s2 = -1, l2 = level, ax2 = cx, ay2 = cy, az2 = cz, qx, qy, qz;
+            int s2 = -1, b2 = -1, l2 = level, ax2 = cx, ay2 = cy, az2 = cz, qx, qy, qz;
             float d2 = 0.0f, p2x = px, p2y = py, p2z = pz;
-            const int r2 = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, SOC_LTM_PLACE, p2x, p2y, p2z, l2, ax2, ay2, az2, s2, d2, qx, qy, qz);
-            if (r2 != SOC_LT_INSIDE || s2 != slot || d2 != dens || l2 != level || p2x != px) { *status = -3;  break; }
+            const int r2 = soc_lt_move(tree, K, NX, NY, NZ, Lmax, kexp, SOC_LTM_PLACE, p2x, p2y, p2z, l2, ax2, ay2, az2, s2, b2, d2, qx, qy, qz);
+            if (r2 != SOC_LT_INSIDE || s2 != slot || d2 != dens || l2 != level || p2x != px || (level > 0 && b2 != obase)) { *status = -3;  break; }
         }
         what = SOC_LTM_STEP;
     }

@@ -2,7 +2,7 @@
 """Tuning experiments on the C3 geometry (256^3-root octree, 4 levels): steps/s of the brick sweep for a list of
 soc_set_tuning settings.
 
-    python tools/exp_c3.py [--kind ps|cl|bg] [--n N] [--launches K] [--packets P] '{"brick_cells": 6144}' '{"global_tree": 1}' ...
+    python tools/exp_c3.py [--kind ps|cl|bg|mix] [--n N] [--launches K] [--packets P] '{"brick_cells": 6144}' '{"global_tree": 1}' ...
 
 Every setting runs K launches (different seeds/frequencies) of about P packets each in one sweep and prints
 packets/s, steps/s and the passes.  Not a benchmark of record (bench.py is); used to choose the built-in values.
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--packets", type=float, default=2.5e8)
     ap.add_argument("--global0", type=int, default=4194304)
     ap.add_argument("--freq", type=int, default=30)
+    ap.add_argument("--fstride", type=int, default=1, help="frequency of launch k: freq + k * fstride (mod 50)")
     ap.add_argument("--int", dest="with_int", type=int, default=0, help="1: launches keep the per-frequency INT tally and run one at a time (read after each)")
     ap.add_argument("tunes", nargs="*")
     a = ap.parse_args()
@@ -62,20 +63,21 @@ def main():
                 prof(buf, 1)
             eng.timer_start()
             if not a.with_int:
-                eng.batch_begin(min(16, a.launches))
+                eng.batch_begin(min(128, a.launches))
             for k in range(a.launches):
                 if a.with_int:
                     eng.zero(1)
-                f = (a.freq + k) % 50
-                s = work["step"](2 * f + (0 if a.kind == "ps" else 1))
+                kind = a.kind if a.kind != "mix" else ("ps", "cl")[k % 2]      # mix: point-source and diffuse launches share the sweep
+                f = (a.freq + (k // 2 if a.kind == "mix" else k) * a.fstride) % 50
+                s = work["step_for"](f, "ps" if kind == "ps" else "cl")
                 L = dict(s["L"])
                 eng.set_optical(s["ABS"], s["SCA"])
                 eng.set_scatter_table(s["DSC"], s["CSC"])
                 seed = launch.launch_seed(work["SEED"], f)
-                if a.kind == "cl":
+                if kind == "cl":
                     G = int(min(L["GLOBAL"], cloud.CELLS) * min(1.0, a.packets / (L["BATCH"] * cloud.CELLS)))
                     eng.sim_cl(2, L["PACKETS"], L["BATCH"], seed, s["TW"], L["GLOBAL"], gid_first=0, gid_count=max(G, 65536))
-                elif a.kind == "ps":
+                elif kind == "ps":
                     B = max(1, int(a.packets / L["GLOBAL"]))
                     eng.sim_pb(0, L["GLOBAL"] * B, B, seed, 0.0, s["TW"], PSPOS=s["PSPOS"], PS=s["PS"], GLOBAL=L["GLOBAL"])
                 else:
@@ -95,15 +97,14 @@ def main():
                 p = list(buf)
                 tt = max(sum(p[8:16]), 1)
                 print("   wave-iterations %.3e: stepping lanes %.1f, idle lanes %.1f | swap arm every %.1f iterations with %.1f lanes | "
-                      "deferred Index every %.1f with %.1f lanes | wave cycles: swap %.1f %%, step %.1f %%, climb %.1f %%" % (
+                      "wave cycles: swap %.1f %%, GetStep + tally %.1f %%, Index %.1f %%" % (
                           p[0], p[1] / max(p[0], 1), p[7] / max(p[0], 1), p[0] / max(p[4], 1), p[5] / max(p[4], 1),
-                          p[0] / max(p[2], 1), p[3] / max(p[2], 1), 100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
+                          100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
                 if p[16] or p[18] or p[20]:
                     print("   idle lanes by where: chunks < 4 packets per lane %.1f %% of the iterations with %.1f idle lanes; < 16 per lane %.1f %% with %.1f; "
                           "end of a chunk (nothing prefetched in the wave) %.1f %% with %.1f" % (
                               100 * p[16] / max(p[0], 1), p[17] / max(p[16], 1), 100 * p[18] / max(p[0], 1), p[19] / max(p[18], 1),
                               100 * p[20] / max(p[0], 1), p[21] / max(p[20], 1)), flush=True)
-                print("   switch / exchange arm every %.1f iterations; wave cycles: switch / exchange %.1f %%, loop head %.1f %%, outcome %.1f %%" % (p[0] / max(p[6], 1), 100 * p[11] / tt, 100 * p[14] / tt, 100 * p[13] / tt), flush=True)
         eng.set_tuning(**reset)
     eng.close()
 
