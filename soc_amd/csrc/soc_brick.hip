@@ -581,11 +581,11 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
 // The workgroup copies its brick's cells into LDS (sD: density, or the link to the octet's slots), so a cell step
 // reads and writes LDS only: GetStep's arithmetic, the tally (ds_add_f32), then the new cell from the packet's
 // integer cell coordinates -- a sibling by slot arithmetic, anything else by a descent from the brick's root cells
-// (soc_lt_step) -- and the new local position from one fma.  Global memory is touched when a packet is taken from
+// (soc_lt_aim / soc_lt_land) -- and the new local position from one fma.  Global memory is touched when a packet is taken from
 // the queue or put back, and for the brick of the root cell a leaving packet goes to (rbrick).
 // Packet record here: A = position, photons | B = direction, free path | C = tau, cell coordinates (cx, cy, cz on the
 // cell's level) | D = RNG state, III | scatterings << 24 | level << 29, SimRAM_CL: emitting cell; bit 31: the step
-// into the next brick is not finished (old cell + advanced position: soc_lt_arrive completes it there).
+// into the next brick is not finished (old cell + advanced position: the Index() part completes it there).
 // ---------------------------------------------------------------------------------------
 #define SOC_LT_ARRIVE 0x80000000u
 #define SOC_LQ_SHIFT 24           // packet word C.w of this form: cz | launch << 24 (coordinates stay below 2^24, see soc_brick_run_pb)
@@ -672,7 +672,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     float rux = 1.0f, ruy = 1.0f, ruz = 1.0f;              // correctly rounded reciprocals of the direction
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;                 // GetStep's target inside the cell per axis: 1 + PEPS or -PEPS
     float kabs = 0.0f, ksca = 0.0f, tw = 0.0f;
-    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, obase = 0, nvisit = 0, key = 0, cslot = 0, lq = 0;      // obase: slot of the first cell of the packet's octet
+    int   cx = 0, cy = 0, cz = 0, level = 0, slot = 0, obase = 0, nvisit = 0, key = 0, cslot = 0, lq = 0, evq = 0;      // evq: first event queue of the packet's launch      // obase: slot of the first cell of the packet's octet
     int   what = SOC_LTM_STEP;                              // what the Index() part has to do for the lane: finish a step, an arrival, or find the packet's cell
     bool  nonudge = false;                                 // SimRAM_CL: no nudge after a failed step (kernel_ASOC.c:1530-1540 has none)
     uint32_t dz = 0, dw = 0, wid = 0;
@@ -749,6 +749,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         gx = (ux > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gy = (uy > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;  gz = (uz > 0.0f) ? (1.0f + SOC_PEPS) : -SOC_PEPS;
                         tau = nc.x;  cx = __float_as_int(nc.y);  cy = __float_as_int(nc.z);  cz = n_cz & ((1 << SOC_LQ_SHIFT) - 1);
                         lq = n_lq;                                                // the launch of the work item
+                        evq = A.NBQ + A.EQ * n_lq;
                         level = (int)(dz >> 29);
                         kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = (__float_as_int(l4.w) & 1) != 0;
                         nvisit = 0;
@@ -806,7 +807,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 dtau = ds * dens * ksca;
                 if (free_path < (tau + dtau)) {
                     px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 1;             // -> scattering queue of its launch
+                    mode = SOC_BM_SWAP;  key = evq + 1;                           // -> scattering queue of its launch
                     move = false;
                 }
             }
@@ -848,9 +849,9 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 } else if (r == SOC_LT_LEAVE) {
                     mode = SOC_BM_SWAP;  key = -1 - SOC_MAD24(SOC_MAD24(AM.Rz, NY, AM.Ry), NX, AM.Rx);  dw |= SOC_LT_ARRIVE;   // (the brick of that root cell: looked up after the walk; N < 4096)
                 } else if (r == SOC_LT_EXIT) {
-                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq;                 // -> creation queue
+                    mode = SOC_BM_SWAP;  key = evq;                               // -> creation queue
                 } else if (r == SOC_LT_SLOW) {
-                    mode = SOC_BM_SWAP;  key = A.NBQ + A.EQ * lq + 2;  dw |= SOC_LT_ARRIVE;          // -> slow-step queue: old cell, advanced position
+                    mode = SOC_BM_SWAP;  key = evq + 2;  dw |= SOC_LT_ARRIVE;     // -> slow-step queue: old cell, advanced position
                 } else {
                     mode = SOC_BM_SWAP;  key = NQ - 1;                            // cannot happen (the sender looked the brick up): retire rather than walk off the tree
                 }

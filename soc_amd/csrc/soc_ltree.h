@@ -9,7 +9,7 @@
 // returns is
 //     the leaf that contains the point, and  pos' = RN_float(pos * 2^(l-L) + B)
 // with l the leaf's level and B the (dyadic, exactly representable) distance between the two octet origins in
-// units of the new level.  That is what soc_lt_step() computes, from integers:
+// units of the new level.  That is what soc_lt_aim() / soc_lt_land() compute, from integers:
 //   * the packet carries the integer coordinates (cx, cy, cz) of its cell on the cell's own level instead of ind;
 //   * the cell that holds the point has coordinates t = (c & ~1) + floor(pos) on level L, its ancestors t >> j;
 //   * the brick's cells sit in LDS (`tree`: a leaf holds its density, a refined cell the link to the slots of its
@@ -61,129 +61,8 @@ SOC_HD bool soc_lt_degenerate(float px, float py, float pz, float flx, float fly
     return !(m >= thr) || (px == flx) || (py == fly) || (pz == flz);
 }
 
-// The brick's slot of the cell with integer coordinates (tx, ty, tz) on level L -- or of the leaf above it, if the
-// hierarchy ends earlier: descent from the root cell of the box.  Returns false (and the root cell of the point in
-// R) when that root cell lies outside the box of this brick.
-template <typename TREE>
-SOC_HD bool soc_lt_descend(const TREE tree, const SocLBrick &K, const int L, const int tx, const int ty, const int tz,
-                           int &s, float &rec, int &l, int &Rx, int &Ry, int &Rz)
-{
-    Rx = tx >> L;  Ry = ty >> L;  Rz = tz >> L;
-    const int rx = Rx - K.x0, ry = Ry - K.y0, rz = Rz - K.z0;
-    if (((unsigned)rx >= (unsigned)K.bx) | ((unsigned)ry >= (unsigned)K.by) | ((unsigned)rz >= (unsigned)K.bz)) return false;
-    s = (rz * K.by + ry) * K.bx + rx;
-    rec = tree[s];
-    l = 0;
-    while (!(rec > 0.0f) && (l < L)) {                       // the ancestors of t, from the root cell down
-        l++;
-        const int sh = L - l;
-        s = soc_lt_link(rec) + (((tx >> sh) & 1) | (((ty >> sh) & 1) << 1) | (((tz >> sh) & 1) << 2));
-        rec = tree[s];
-    }
-    return true;
-}
-
-// A packet of level L (cell c, pos local to c's octet) whose point lies in the level-L cell t has been traced down
-// to slot s (record rec) on level l <= L.  Go on to the leaf if t itself is refined -- octants from the position
-// inside t, as Index() does with 2*fmod(POS,1), exactly -- and re-express pos in the leaf's octet:
-//     pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)),   O = octet origin on the cell's level (0 on the root grid).
-template <typename TREE>
-SOC_HD void soc_lt_settle(const TREE tree, const int tx, const int ty, const int tz, int s, float rec, int l,
-                          float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens)
-{
-    const int L = level;
-    int nx = tx >> (L - l), ny = ty >> (L - l), nz = tz >> (L - l);          // the cell found so far, on its level l
-    if (!(rec > 0.0f)) {
-        float fx = px - soc_floorf(px), fy = py - soc_floorf(py), fz = pz - soc_floorf(pz);
-        while (!(rec > 0.0f)) {
-            l++;
-            fx *= 2.0f;  fy *= 2.0f;  fz *= 2.0f;
-            const int bx = (fx >= 1.0f) ? 1 : 0, by = (fy >= 1.0f) ? 1 : 0, bz = (fz >= 1.0f) ? 1 : 0;
-            fx -= (float)bx;  fy -= (float)by;  fz -= (float)bz;
-            nx = 2 * nx + bx;  ny = 2 * ny + by;  nz = 2 * nz + bz;
-            s = soc_lt_link(rec) + (bx | (by << 1) | (bz << 2));
-            rec = tree[s];
-        }
-    }
-    const int ox = (L > 0) ? (cx & ~1) : 0, oy = (L > 0) ? (cy & ~1) : 0, oz = (L > 0) ? (cz & ~1) : 0;
-    const int qx = (l > 0) ? (nx & ~1) : 0, qy = (l > 0) ? (ny & ~1) : 0, qz = (l > 0) ? (nz & ~1) : 0;
-    const int k = l - L;
-    const float sc = soc_lt_pow2(k);
-    if (k <= 0) {
-        if ((k < 0) | (ox != qx) | (oy != qy) | (oz != qz)) {
-            const float Bx = (float)(ox - (qx << (-k))) * sc, By = (float)(oy - (qy << (-k))) * sc, Bz = (float)(oz - (qz << (-k))) * sc;
-            px = SOC_FMA(px, sc, Bx);  py = SOC_FMA(py, sc, By);  pz = SOC_FMA(pz, sc, Bz);
-        }
-    } else {
-        px = SOC_FMA(px, sc, (float)((ox << k) - qx));  py = SOC_FMA(py, sc, (float)((oy << k) - qy));  pz = SOC_FMA(pz, sc, (float)((oz << k) - qz));
-    }
-    cx = nx;  cy = ny;  cz = nz;
-    level = l;
-    slot = s;
-    dens = rec;
-}
-
-// Index() after a step, for a packet inside the brick: pos has been advanced by GetStep's arithmetic.
-//   SOC_LT_INSIDE: the packet's place is the new leaf (slot, level, c, pos, dens updated);
-//   SOC_LT_LEAVE : the point lies in root cell (Rx, Ry, Rz) of another brick -- nothing changed: the packet keeps its
-//                  old cell and the advanced pos, and the brick of that root cell completes the step (soc_lt_arrive);
-//   SOC_LT_EXIT  : the point lies outside the model (level > 0; a root-level packet is tested by the caller with the
-//                  reference's float comparisons, kernel_ASOC_aux.c:214);
-//   SOC_LT_SLOW  : not a step exact geometry decides (see the file header): nothing changed.
-// thr: 2^(k+level-30) for this level, sib_thr = 2^(k-29) (the bound of the sibling case: POS/2 + octant only).
-template <typename TREE>
-SOC_HD int soc_lt_step(const TREE tree, const SocLBrick &K, const int NX, const int NY, const int NZ, const float thr, const float sib_thr,
-                       float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz, int &slot, float &dens,
-                       int &Rx, int &Ry, int &Rz)
-{
-    const float flx = soc_floorf(px), fly = soc_floorf(py), flz = soc_floorf(pz);
-    const int   fx = (int)flx, fy = (int)fly, fz = (int)flz;
-    const int   L = level;
-    int   tx = fx, ty = fy, tz = fz, s = 0, l = L;
-    float rec = 0.0f;
-    if (L > 0) {
-        tx += cx & ~1;  ty += cy & ~1;  tz += cz & ~1;
-        if ((((fx | fy | fz) & ~1) == 0)) {
-            // a sibling in the same octet: Index() climbs one level and comes back to the same position
-            if (!(soc_fminf(px, soc_fminf(py, pz)) >= sib_thr)) return SOC_LT_SLOW;
-            s = slot - ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2)) + (fx | (fy << 1) | (fz << 2));
-            rec = tree[s];
-            soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
-            return SOC_LT_INSIDE;
-        }
-        if (soc_lt_degenerate(px, py, pz, flx, fly, flz, thr)) return SOC_LT_SLOW;
-    }
-    if (!soc_lt_descend(tree, K, L, tx, ty, tz, s, rec, l, Rx, Ry, Rz)) {
-        if (((unsigned)Rx >= (unsigned)NX) | ((unsigned)Ry >= (unsigned)NY) | ((unsigned)Rz >= (unsigned)NZ)) return SOC_LT_EXIT;
-        return SOC_LT_LEAVE;
-    }
-    soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
-    return SOC_LT_INSIDE;
-}
-
-// The second half of a step that crossed into this brick (the sender returned SOC_LT_LEAVE and kept old cell + advanced pos).
-template <typename TREE>
-SOC_HD bool soc_lt_arrive(const TREE tree, const SocLBrick &K, float &px, float &py, float &pz, int &level, int &cx, int &cy, int &cz,
-                          int &slot, float &dens)
-{
-    int tx = (int)soc_floorf(px), ty = (int)soc_floorf(py), tz = (int)soc_floorf(pz), s = 0, l = 0, Rx, Ry, Rz;
-    float rec = 0.0f;
-    if (level > 0) { tx += cx & ~1;  ty += cy & ~1;  tz += cz & ~1; }
-    if (!soc_lt_descend(tree, K, level, tx, ty, tz, s, rec, l, Rx, Ry, Rz)) return false;
-    soc_lt_settle(tree, tx, ty, tz, s, rec, l, px, py, pz, level, cx, cy, cz, slot, dens);
-    return true;
-}
-
-// The slot of the packet's own cell (a leaf, or the refined cell a SimRAM_CL packet starts "in"); pos is not used.
-template <typename TREE>
-SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, const int cx, const int cy, const int cz, int &slot, float &dens)
-{
-    int l = 0, Rx, Ry, Rz;
-    return soc_lt_descend(tree, K, level, cx, cy, cz, slot, dens, l, Rx, Ry, Rz) && (l == level);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The walk's form of all of the above: ONE straight path for every kind of move, so that a wavefront whose lanes make
+// ONE straight path for every kind of move, so that a wavefront whose lanes make
 // different moves (root cell -> root cell, sibling, up, down, into the next brick) executes one instruction stream
 // instead of one per kind.
 //
@@ -194,7 +73,7 @@ SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, c
 // binary digits of pos - floor(pos) are the octants Index() picks with 2*fmod(POS,1) on the way down (:268-273) --
 // also for a negative coordinate, whose fractional part a float subtraction would round.  The ancestors of the
 // point's cell are F >> (Lmax - l), so the descent from the brick's root cell (or, for a sibling, from the packet's
-// own octet) is one loop with one LDS read per level, and the new local position is one fma, as in soc_lt_settle.
+// own octet) is one loop with one LDS read per level, and the new local position is one fma.
 //
 // Two halves, so that the walk can put other work between the first LDS read and its use:
 //   soc_lt_aim()   where the point is: F, its root cell R, the outcome if it is already known (LEAVE, EXIT, SLOW) and
@@ -204,7 +83,9 @@ SOC_HD bool soc_lt_place(const TREE tree, const SocLBrick &K, const int level, c
 //   what == SOC_LTM_STEP   : pos has been advanced by GetStep's arithmetic;
 //   what == SOC_LTM_ARRIVE : the same for a packet that comes from another brick (slot and obase mean nothing yet);
 //   what == SOC_LTM_PLACE  : find slot, obase and density of the packet's own cell (level, c); pos is not touched.
-// Outcomes as soc_lt_step (LEAVE, EXIT and SLOW change nothing), or SOC_LT_LOST when a placement does not find the cell
+// Outcomes: SOC_LT_INSIDE (the packet's place is the new leaf), SOC_LT_LEAVE (the point lies in root cell R of another brick: the
+// packet keeps its old cell and the advanced pos, the brick of that root cell completes the step), SOC_LT_EXIT (outside the model),
+// SOC_LT_SLOW (not a step exact geometry decides) -- the last three change nothing -- or SOC_LT_LOST when a placement does not find the cell
 // (a broken record; the walk retires the packet).
 // kexp = k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_degenerate (2^(kexp+L)) and of the sibling case (2^(kexp+1)).
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // ltree_host.cpp -- host harness for soc_amd/csrc/soc_ltree.h + soc_lbricks.h (TEST CODE): follows rays through the
-// brick-local hierarchies exactly as the device walk does (GetStep's float arithmetic, then soc_lt_step / soc_lt_arrive)
+// brick-local hierarchies exactly as the device walk does (GetStep's float arithmetic, then soc_lt_aim / soc_lt_land)
 // and reports every step, so that tests/test_ltree.py can compare it with the oracle's IndexG/GetStep/Index
 // (oracle/soc_oracle.c, double Index) step by step.  Built by tests/util.py with g++ (optionally with sanitizers).
 #include <cmath>
@@ -15,7 +15,6 @@ struct Harness {
     int NX, NY, NZ, LEVELS;
     std::vector<int> LCELLS, OFF;
     SocLBricksHost B;
-    float thr[16], sib_thr;
 };
 
 extern "C" {
@@ -27,11 +26,6 @@ void *lt_build(int NX, int NY, int NZ, int LEVELS, const int *LCELLS, const int 
     H->LCELLS.assign(LCELLS, LCELLS + LEVELS);
     H->OFF.assign(OFF, OFF + LEVELS);
     if (!soc_lbricks_build(NX, NY, NZ, LEVELS, LCELLS, OFF, DENS, cap, H->B)) { delete H;  return nullptr; }
-    int k = 1;
-    const int n = NX > NY ? (NX > NZ ? NX : NZ) : (NY > NZ ? NY : NZ);
-    while ((1 << k) <= n) k++;
-    for (int l = 0; l < 16; l++) H->thr[l] = ldexpf(1.0f, k + l - 30);
-    H->sib_thr = ldexpf(1.0f, k - 29);
     return H;
 }
 
@@ -72,60 +66,10 @@ int lt_check(void *h, const float *DENS, long cells)
     return 0;
 }
 
-// Follow one ray.  Per step: level, global cell index, step length (root units), as orc_trace reports them.
-// Returns the number of steps; *status: 0 left the model, 1 maxsteps, 2 stopped at a step that needs the generic Index.
-int lt_trace(void *h, const float *pos, const float *dir, int maxsteps, int *levels, int *cells, float *dss, float *endpos, int *status)
-{
-    Harness *H = (Harness *)h;
-    const int NX = H->NX, NY = H->NY, NZ = H->NZ;
-    float px = pos[0], py = pos[1], pz = pos[2];
-    const float ux = dir[0], uy = dir[1], uz = dir[2];
-    int level = 0, cx = 0, cy = 0, cz = 0, slot = 0, n = 0, Rx, Ry, Rz;
-    float dens = 0.0f;
-    *status = 0;
-    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
-    if ((px <= 0.0f) || (py <= 0.0f) || (pz <= 0.0f) || (px >= NX) || (py >= NY) || (pz >= NZ)) return 0;      // IndexG
-    int brick = H->B.rbrick[((int)floorf(pz) * NY + (int)floorf(py)) * NX + (int)floorf(px)];
-    {
-        const SocLBrick &K = H->B.bricks[brick];
-        if (!soc_lt_arrive(H->B.btree.data() + K.base, K, px, py, pz, level, cx, cy, cz, slot, dens)) { *status = -1;  return 0; }
-    }
-    while (n < maxsteps) {
-        const SocLBrick &K = H->B.bricks[brick];
-        const float *tree = H->B.btree.data() + K.base;
-        levels[n] = level;
-        cells[n]  = H->B.bcell[K.base + slot];
-        // GetStep (kernel_ASOC_aux.c:300-308)
-        const float ax = (ux > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(px)) / ux) : ((-PEPS - soc_fmod1f(px)) / ux);
-        const float ay = (uy > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(py)) / uy) : ((-PEPS - soc_fmod1f(py)) / uy);
-        const float az = (uz > 0.0f) ? (((1.0f + PEPS) - soc_fmod1f(pz)) / uz) : ((-PEPS - soc_fmod1f(pz)) / uz);
-        float s = soc_fminf(ax, soc_fminf(ay, az));
-        px += s * ux;  py += s * uy;  pz += s * uz;
-        dss[n] = soc_scale_down(s, level);
-        n++;
-        if (level == 0 && ((px <= 0.0f) || (px >= NX) || (py <= 0.0f) || (py >= NY) || (pz <= 0.0f) || (pz >= NZ))) break;
-        const int r = soc_lt_step(tree, K, NX, NY, NZ, H->thr[level], H->sib_thr, px, py, pz, level, cx, cy, cz, slot, dens, Rx, Ry, Rz);
-        if (r == SOC_LT_EXIT) {
-            // Index() leaves the root-grid position behind (kernel_ASOC_aux.c:238-241); the device walk has no use for it
-            const float sc = soc_lt_pow2(-level);
-            px = SOC_FMA(px, sc, (float)(cx & ~1) * sc);  py = SOC_FMA(py, sc, (float)(cy & ~1) * sc);  pz = SOC_FMA(pz, sc, (float)(cz & ~1) * sc);
-            break;
-        }
-        if (r == SOC_LT_SLOW) { *status = 2;  break; }
-        if (r == SOC_LT_LEAVE) {
-            brick = H->B.rbrick[(Rz * NY + Ry) * NX + Rx];
-            const SocLBrick &K2 = H->B.bricks[brick];
-            if (!soc_lt_arrive(H->B.btree.data() + K2.base, K2, px, py, pz, level, cx, cy, cz, slot, dens)) { *status = -2;  break; }
-        }
-    }
-    if (n >= maxsteps && *status == 0) *status = 1;
-    endpos[0] = px;  endpos[1] = py;  endpos[2] = pz;
-    return n;
-}
-
-// The same ray through soc_lt_move(), the single-path form the device walk uses: steps, arrivals in the next brick and --
+// Follow one ray through soc_lt_move(), the single-path form the device walk uses: steps, arrivals in the next brick and --
 // after every move -- a placement of the packet's own cell, which must find the slot and the density the move reported.
-// status as lt_trace; -3: a placement disagreed.
+// Per step: level, global cell index, step length (root units), as orc_trace reports them.  Returns the number of steps;
+// *status: 0 left the model, 1 maxsteps, 2 stopped at a step that needs the generic Index, -1 lost, -3 a placement disagreed.
 int lt_trace_move(void *h, const float *pos, const float *dir, int maxsteps, int *levels, int *cells, float *dss, float *endpos, int *status)
 {
     Harness *H = (Harness *)h;

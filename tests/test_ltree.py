@@ -38,9 +38,8 @@ class LTree:
         L.lt_free.argtypes = [C.c_void_p]
         L.lt_info.argtypes = [C.c_void_p, _I, _I, C.POINTER(C.c_long)]
         L.lt_check.argtypes = [C.c_void_p, _F, C.c_long]
-        for f in (L.lt_trace, L.lt_trace_move):
-            f.restype = C.c_int
-            f.argtypes = [C.c_void_p, _F, _F, C.c_int, _I, _I, _F, _F, _I]
+        L.lt_trace_move.restype = C.c_int
+        L.lt_trace_move.argtypes = [C.c_void_p, _F, _F, C.c_int, _I, _I, _F, _F, _I]
         self.cloud = cloud
         self.LCELLS = np.ascontiguousarray(cloud.LCELLS, np.int32)
         self.OFF = np.ascontiguousarray(cloud.OFF, np.int32)
@@ -56,7 +55,7 @@ class LTree:
     def check(self):
         return self.lib.lt_check(self.h, self.DENS.ctypes.data_as(_F), self.cloud.CELLS)
 
-    def trace(self, pos, d, maxsteps=20000, move=False):
+    def trace(self, pos, d, maxsteps=20000):
         pos = np.ascontiguousarray(pos, np.float32)
         d = np.ascontiguousarray(d, np.float32)
         lev = np.zeros(maxsteps, np.int32)
@@ -64,7 +63,7 @@ class LTree:
         ds = np.zeros(maxsteps, np.float32)
         end = np.zeros(3, np.float32)
         st = C.c_int()
-        n = (self.lib.lt_trace_move if move else self.lib.lt_trace)(self.h, pos.ctypes.data_as(_F), d.ctypes.data_as(_F), maxsteps, lev.ctypes.data_as(_I),
+        n = self.lib.lt_trace_move(self.h, pos.ctypes.data_as(_F), d.ctypes.data_as(_F), maxsteps, lev.ctypes.data_as(_I),
                               cel.ctypes.data_as(_I), ds.ctypes.data_as(_F), end.ctypes.data_as(_F), C.byref(st))
         return lev[:n], cel[:n], ds[:n], end, st.value
 
@@ -98,10 +97,9 @@ CLOUDS = {
 }
 
 
-@pytest.mark.parametrize("move", [False, True], ids=["lt_step", "lt_move"])
 @pytest.mark.parametrize("name,cap", [("oct104_l4", 6144), ("oct104_l4", 700), ("oct128_l5", 4096)])
-def test_local_tree_steps_are_the_oracles_steps(name, cap, move, oracle_soc):
-    """both forms of the neighbour search: soc_lt_step / soc_lt_arrive (by case) and soc_lt_move (one path, the device walk's)"""
+def test_local_tree_steps_are_the_oracles_steps(name, cap, oracle_soc):
+    """soc_lt_aim / soc_lt_land (one path for every kind of move, the device walk's) against the oracle's Index, step by step"""
     cloud = CLOUDS[name]()
     lt = LTree(cloud, cap)
     assert lt.h, "bricks could not be built"
@@ -113,7 +111,7 @@ def test_local_tree_steps_are_the_oracles_steps(name, cap, move, oracle_soc):
     steps = slow = 0
     deeper = set()
     for i in range(len(pos)):
-        lev, cel, ds, end, st = lt.trace(pos[i], u[i], move=move)
+        lev, cel, ds, end, st = lt.trace(pos[i], u[i])
         assert st in (0, 2), "ray %d: status %d" % (i, st)
         olev, oind, ods, oend = oracle_soc.trace(job, pos[i], u[i], maxsteps=20000)
         n = len(lev)
@@ -155,7 +153,6 @@ def _sanitized_body(lib):
         pos, u = _rays(cloud, 200, rng)
         for i in range(len(pos)):
             lt.trace(pos[i], u[i])
-            lt.trace(pos[i], u[i], move=True)
         lt.close()
     # one root cell with more cells below it than the cap: refused, not mis-built
     deep = synth.octree_cloud(4, levels=4, frac=0.5, seed=1)
