@@ -73,10 +73,18 @@ class AbsorptionRun:
     """The constant-source part of an ASOC run.  ``engine`` is a soc_amd.lib.Engine (or an
     object with the same methods); ``comm`` a soc_amd.dist.Comm."""
 
-    def __init__(self, USER, engine, comm=None, verbose=None, workdir="."):
+    def __init__(self, USER, engine, comm=None, verbose=None, workdir=".", shard="items"):
+        """shard (several ranks): "items" -- every launch is split by work-item ranges (identical packets and events per rank, one
+        all-reduce of the per-cell buffer per frequency when absorptions are saved); "launches" -- the launches themselves are
+        dealt out: a run that keeps the per-frequency absorptions gives every frequency to ONE rank, which owns that column of
+        the absorbed file (no collective for INT at all; TABS is reduced once); a TABS-only run gives every rank a contiguous
+        share of the launch sequence (launch.shard_launches).  Same packets and streams either way."""
         self.U = USER
         self.eng = engine
         self.comm = comm
+        if shard not in ("items", "launches"):
+            raise ValueError("shard: 'items' or 'launches'")
+        self.shard = shard
         self.rank = comm.rank if comm else 0
         self.world = comm.world if comm else 1
         self.verbose = USER.VERBOSE if verbose is None else verbose
@@ -234,6 +242,46 @@ class AbsorptionRun:
                     else:
                         self.INTENSITY[a:b, IFREQ] += coeff * v[a:b] / c.DENS[a:b]
 
+    def _constant_launch(self, II):
+        """Launch shape of source block II (ASOC.py:1036-1110), or None when the block is not simulated."""
+        U, c = self.U, self.cloud
+        if II == 0:
+            if (self.PSPAC < 1) or (U.NO_PS < 1):
+                return None
+            return launch.ps_launch(self.PSPAC, U.NO_PS, U.GL, self.GLOBAL_0)
+        if II == 1:
+            if self.BGPAC < 1:
+                return None
+            return launch.hpbg_launch(self.BGPAC, c.NX, c.NY, c.NZ) if len(self.HPBG) > 0 else launch.bg_launch(self.BGPAC, int(U.AREA))
+        if II == 2:
+            if len(self.DIFFUSERAD) < 1 or self.DFPAC < 1:
+                return None
+            return launch.cl_launch(self.DFPAC, c.CELLS, self.GLOBAL_0)
+        if U.ROIPAC < 1 or self.ROI_LOAD is None:
+            return None
+        return launch.roi_launch(U.ROIPAC, files.roi_elements(self.ROI_DIM), U.ROI_NSIDE)
+
+    def _launch_shares(self, by_frequency):
+        """shard == "launches": {(II, IFREQ): (first, count)} for this rank over the sequence of launches of the constant sources.
+        by_frequency: whole launches, the k-th simulated frequency to rank k % world (the rank then owns that frequency's INT)."""
+        U = self.U
+        seq = []
+        for II in range(4):
+            L = self._constant_launch(II)
+            if L is None:
+                continue
+            for IFREQ in range(self.NFREQ):
+                FREQ = float(self.FFREQ[IFREQ])
+                if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
+                    continue
+                seq.append((II, IFREQ, L))
+        if by_frequency:
+            sim = sorted({f for _, f, _ in seq})
+            owner = {f: k % self.world for k, f in enumerate(sim)}
+            return {(II, f): ((0, L["GLOBAL"]) if owner[f] == self.rank else (0, 0)) for II, f, L in seq}, owner
+        parts = launch.shard_launches([L["GLOBAL"] for _, _, L in seq], [L["PACKETS"] for _, _, L in seq], self.rank, self.world)
+        return {(II, f): pc for (II, f, _), pc in zip(seq, parts)}, None
+
     def simulate_constant_sources(self):
         """for II in (point sources, background, diffuse): for IFREQ: launch (ASOC.py:1028-1545).
         Returns CTABS[CELLS] and FABSORBED[CELLS,NFREQ] (or None with noabsorbed)."""
@@ -262,6 +310,15 @@ class AbsorptionRun:
         # point-source, background and diffuse launches of all frequencies share brick sweeps (include/soc_hip.h:
         # soc_batch_begin; up to 128 launches per sweep), elsewhere the engine starts a new sweep where the kind changes.
         one_batch = (not self.with_int) and (not U.WITH_ROI_SAVE) and hasattr(e, "batch_begin") and U.ITERATIONS >= 1
+        # several ranks, shard == "launches": the launches themselves are dealt out (see __init__).  Runs that keep the per-frequency
+        # absorptions: a frequency belongs to one rank (not with the intensity file, region-of-interest records or emission iterations,
+        # which need every frequency on every rank -- those keep the work-item split)
+        shares, self.freq_owner = None, None
+        if self.shard == "launches" and self.comm and self.world > 1 and U.ITERATIONS >= 1:
+            own_freq = self.with_int
+            if (not own_freq) or (FABSORBED is not None and U.SAVE_INTENSITY == 0 and (not U.WITH_ROI_SAVE) and self.CLPAC < 1 and thin == 1):
+                shares, self.freq_owner = self._launch_shares(by_frequency=own_freq)
+        owned = self.freq_owner is not None
         if one_batch:
             e.zero(0)
             e.batch_begin(0)
@@ -310,7 +367,7 @@ class AbsorptionRun:
                 e.batch_end()
                 for k, f in enumerate(group):
                     arr = e.batch_read_int(k)
-                    if self.comm and self.world > 1:
+                    if self.comm and self.world > 1 and not owned:
                         arr = self.comm.all_reduce_host(arr)
                     FABSORBED[:, f] += arr[0::self.absthin]
                 del group[:]
@@ -336,6 +393,10 @@ class AbsorptionRun:
                     seed = float(rng.random())
                     if self.comm and self.world > 1:      # every rank must use the same streams
                         seed = self._bcast_seed(seed)
+                if shares is not None:
+                    first, count = shares.get((II, IFREQ), (0, 0))
+                    if count == 0:
+                        continue                          # another rank's launch
                 if II == 2:
                     dr_ind = IFREQ + (self.DIFFUSERAD.shape[1] - NFREQ)
                     if dr_ind < 0 or dr_ind >= self.DIFFUSERAD.shape[1]:
@@ -368,7 +429,7 @@ class AbsorptionRun:
                     e.sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, FF,
                              PSPOS=U.PSPOS[:max(U.NO_PS, 1), :3], PS=PS, XPS=self.XPS,
                              GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-                if self.with_int and self.comm and not int_batched:
+                if self.with_int and self.comm and not int_batched and not owned:
                     self.comm.all_reduce_tally(e, 1)      # one all-reduce of the per-cell buffer per frequency
                 if int_batched:
                     group.append(IFREQ)
@@ -802,12 +863,23 @@ class AbsorptionRun:
         if self.rank == 0:
             if len(U.file_constant_save) > 0:
                 CTABS.tofile(U.file_constant_save)                 # ASOC.py:1547-1549
-            if FABSORBED is not None:
+            if FABSORBED is not None and getattr(self, "freq_owner", None) is None:
                 files.scale_absorbed(FABSORBED, self.cloud, U.GL, U.NNNLIMIT, self.absthin)
                 files.write_absorbed(U.file_absorbed, FABSORBED)   # ASOC.py:2866-2875
-            else:
+            elif FABSORBED is None:
                 prefix = U.KEYS.get('prefix', ['soc'])[0] if U.KEYS.get('prefix') else 'soc'
                 CTABS.tofile(prefix + ".ctabs")
+        if FABSORBED is not None and getattr(self, "freq_owner", None) is not None:
+            # every rank holds the columns of the frequencies it simulated and writes them itself: no collective (as a2e.run_sharded)
+            files.scale_absorbed(FABSORBED, self.cloud, U.GL, U.NNNLIMIT, self.absthin)
+            if self.rank == 0:
+                files.create_absorbed(U.file_absorbed, FABSORBED.shape[0], FABSORBED.shape[1])
+            self.comm.barrier()
+            mine = [f for f, r in self.freq_owner.items() if r == self.rank]
+            if self.rank == 0:
+                mine += [f for f in range(FABSORBED.shape[1]) if f not in self.freq_owner]      # frequencies outside `simum`: nobody's
+            files.write_absorbed_columns(U.file_absorbed, FABSORBED, mine)
+            self.comm.barrier()
         wall = time.time() - t00
         if self.rank == 0 and self.verbose:
             print("Tkernel %.3f  Tpush %.3f  Tpull %.3f" % (self.timers["Tkernel"], self.timers["Tpush"], self.timers["Tpull"]))

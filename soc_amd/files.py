@@ -200,6 +200,26 @@ def write_absorbed(filename, FABSORBED):
         FABSORBED.tofile(fp)
 
 
+def create_absorbed(filename, rows, nfreq):
+    """An absorbed file of the right size with its header, columns to be filled by write_absorbed_columns (several ranks, each the
+    frequencies it simulated: no collective for the per-frequency absorptions)."""
+    with open(filename, 'wb') as fp:
+        np.asarray([rows, nfreq], np.int32).tofile(fp)
+        fp.truncate(8 + 4 * int(rows) * int(nfreq))
+
+
+def write_absorbed_columns(filename, FABSORBED, columns):
+    """Write the given frequency columns of FABSORBED[CELLS, NFREQ] into an existing absorbed file."""
+    dims = np.fromfile(filename, np.int32, 2)
+    if tuple(int(x) for x in dims) != tuple(FABSORBED.shape):
+        raise FileError("%s: holds %s, the run has %s" % (filename, tuple(dims), FABSORBED.shape))
+    mm = np.memmap(filename, np.float32, mode='r+', offset=8, shape=FABSORBED.shape)
+    for f in columns:
+        mm[:, f] = FABSORBED[:, f]
+    mm.flush()
+    del mm
+
+
 def read_absorbed(filename):
     dims = np.fromfile(filename, np.int32, 2)
     return np.fromfile(filename, np.float32, offset=8).reshape(int(dims[0]), int(dims[1]))

@@ -18,7 +18,7 @@ from soc_amd.dist import Comm
 from oracle_engine import OracleEngine
 comm = Comm(backend="gloo")
 os.chdir(sys.argv[2] + "/r%d" % comm.rank)
-run = AbsorptionRun(User(sys.argv[1]), OracleEngine("soc"), comm, verbose=0)
+run = AbsorptionRun(User(sys.argv[1]), OracleEngine("soc"), comm, verbose=0, shard=(sys.argv[3] if len(sys.argv) > 3 else "items"))
 C, F = run.run()
 np.save("ctabs_rank%d.npy" % comm.rank, C)
 comm.close()
@@ -61,6 +61,59 @@ def test_two_rank_sharded_run_equals_single(grid, tmp_path):
     A = files.read_absorbed(os.path.join(d, "abs.data"))
     want = F1                                   # (run() has scaled the array it returns, as it wrote it)
     assert np.allclose(A, want, rtol=1e-5, atol=1e-7 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("noabsorbed", [False, True], ids=["absorbed_file", "tabs_only"])
+def test_two_ranks_share_the_launch_sequence(noabsorbed, tmp_path):
+    """shard="launches": an absorbed-file run gives every frequency to one rank, which simulates it whole and writes its column
+    of the file itself (no collective for the per-frequency absorptions); a TABS-only run gives each rank a contiguous share of the
+    launch sequence.  Same packets and streams as one process: results equal to summation order."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_host import _write_model
+    from oracle_engine import OracleEngine
+    from soc_amd import synth, files
+    from soc_amd.ini import User
+    from soc_amd.asoc import AbsorptionRun
+    d = str(tmp_path)
+    cloud = synth.octree_cloud(6, levels=2, frac=0.1, seed=9)
+    ini = _write_model(d, cloud, with_ps=True, with_diffuse=True, extra="noabsorbed\n" if noabsorbed else "")
+    for r in (0, 1):
+        os.makedirs(os.path.join(d, "r%d" % r))
+    os.makedirs(os.path.join(d, "single"))
+    os.chdir(os.path.join(d, "single"))
+    C1, F1 = AbsorptionRun(User(ini), OracleEngine("soc"), verbose=0).run()
+    if not noabsorbed:
+        os.remove(os.path.join(d, "abs.data"))
+    script = os.path.join(d, "worker.py")
+    with open(script, "w") as fp:
+        fp.write(WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", script, ini, d, "launches"],
+                          env=env, timeout=600)
+    for r in (0, 1):
+        C = np.load(os.path.join(d, "r%d" % r, "ctabs_rank%d.npy" % r))
+        assert np.allclose(C, C1, rtol=1e-5, atol=1e-7 * np.abs(C1).max())
+    if not noabsorbed:
+        A = files.read_absorbed(os.path.join(d, "abs.data"))
+        assert A.shape == F1.shape and np.allclose(A, F1, rtol=1e-5, atol=1e-7 * np.abs(F1).max())
+
+
+def test_launch_shares_partition_the_sequence():
+    from soc_amd import launch
+    G = [16777216, 4096, 100000, 16777216, 64]
+    W = [1e9, 3e5, 7e6, 9.9e8, 4e3]
+    for world in (1, 2, 3, 8):
+        tot = [0] * len(G)
+        per_rank = []
+        for r in range(world):
+            sh = launch.shard_launches(G, W, r, world)
+            assert all(f % 64 == 0 for f, c in sh if c)
+            for i, (f, c) in enumerate(sh):
+                tot[i] += c
+            per_rank.append(sum(c * W[i] / G[i] for i, (f, c) in enumerate(sh)))
+        assert tot == G                                          # every work item exactly once
+        assert max(per_rank) - min(per_rank) <= 0.02 * sum(W) / world + 64 * 1e9 / 16777216      # equal packets per rank
 
 
 SCA_WORKER = r"""
