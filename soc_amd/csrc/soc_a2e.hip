@@ -5,132 +5,216 @@
 // interleaved by LOCAL (NE=128 -> 266 MB per batch of 8192 cells; the source comments put
 // most of the run time into building and re-reading it), a private XL[NE].
 //
-// Here: ONE WAVE PER CELL, L lives in LDS (32.5 KB at NE=128) and never touches HBM:
-//   1. heating rates: the (l,u) pairs are spread over the 64 lanes; each entry is the
-//      reference's sequential sum over its frequency window (host-built pair tables give the
-//      window, the weight offset and the slot in L), clamped at 0;
-//   2. suffix sums over u: one column per lane, rows walked downwards as in the reference;
-//   3. forward substitution: row j is a dot product over lanes + wave butterfly reduction
-//      (the only place where the fp32 summation order differs from the reference's serial
-//      loop), followed by the reference's /Tdown, clamp and 1e-20 rescaling;
-//   4. normalisation (wave reduction) and emission: one frequency per lane, serial over the
-//      enthalpy bins from Ibeg[f] exactly as the reference.
+// Here: a workgroup of sixteen waves solves C cells (C = 4 where four matrices fit the CU's LDS: NE <= 128); L lives in LDS
+// (32.5 KB per cell at NE=128) and never touches HBM:
+//   1. heating rates, by ALL lanes of the workgroup for ALL its cells: the (l,u) pairs are spread over the 1024 lanes; a lane
+//      reads a pair's integration weights once and adds them up for its C cells (the weights are the same for every cell:
+//      read per cell -- as the first form of this kernel did, one wave per cell -- the 650 KB table of NE=128 came from L2
+//      8192 times per batch).  Each entry is the reference's sequential sum over its frequency window (host-built pair
+//      tables give the window, the weight offset and the slot in L), clamped at 0;
+//   then wave w < C goes on with cell w alone (the other waves wait at the barriers):
+//   2. suffix sums over u: a lane owns columns, the running sum in a register, rows walked downwards as in the reference;
+//   3. forward substitution, row per lane: a lane adds up its row in the reference's order (i ascending, multiply then
+//      add), finished values go down the rows with v_readlane -- no barrier, no tree reduction: the reference's bits;
+//   4. normalisation and emission: one frequency per lane, serial over the enthalpy bins from Ibeg[f] exactly as the reference.
 // Algorithmic HBM bytes per cell and size: 4*NFREQ in + 4*NFREQ out (tables are L2-resident).
 //
 // EqTemperature (kernel_A2E.c:110-154) is one lane per cell, operation for operation.
 #include "soc_dev.h"
 #include "soc_math.h"
 
-__device__ __forceinline__ float soc_wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 #define A2E_IND(a, b) (((a) * (a) - (a)) / 2 + (b))
 
-__global__ __launch_bounds__(64) void soc_a2e_dosolve_kernel(const SocA2EArgs A)
+// cycles per phase of DoSolve for experiments (-DSOC_A2E_PROF; tools/exp_a2e.py prints them): wave 0 of every workgroup
+#if defined(SOC_A2E_PROF)
+__device__ unsigned long long g_a2e_prof[8];
+#define A2E_PROF_DECL unsigned long long pt_ = __builtin_readcyclecounter()
+#define A2E_PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter();  if (threadIdx.x == 0) atomicAdd(&g_a2e_prof[i], t_ - pt_);  pt_ = t_; } while (0)
+extern "C" __attribute__((visibility("default"))) void soc_a2e_prof_read(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a2e_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = { 0 };  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a2e_prof), z, sizeof(z)); }
+}
+#else
+#define A2E_PROF_DECL
+#define A2E_PROF(i) do { } while (0)
+#endif
+// s = sum_{i<n} Lr[i] * X[i], i ascending, multiply then add -- the order of the reference's serial loop (kernel_A2E.c:82) -- with the
+// LDS reads of eight terms in flight before the first addition needs one
+__device__ __forceinline__ float a2e_row_sum(const float *Lr, const float *X, const int n)
+{
+    float s = 0.0f;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float l[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { l[u] = Lr[i + u];  x[u] = X[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += l[u] * x[u];
+    }
+    for (; i < n; i++) s += Lr[i] * X[i];
+    return s;
+}
+
+#define A2E_T 1024                   // threads per workgroup: sixteen waves build the matrices (their LDS leaves room for one workgroup
+                                     // per CU, so the waves that hide the latency of the weight reads must be its own); four of them solve
+#define A2E_Q 2                      // pairs a lane has in flight in step 1
+
+template <int C>
+__global__ __launch_bounds__(A2E_T) void soc_a2e_dosolve_kernel(const SocA2EArgs A)
 {
     extern __shared__ float lds[];
-    const int NE = A.NE, NFREQ = A.NFREQ, lane = threadIdx.x;
-    float *L    = lds;                                   // [(NE*NE-NE)/2]
-    float *XL   = L + (NE * NE - NE) / 2;                // [NE]
-    float *sABS = XL + NE;                               // [NFREQ]
-    float *sAF  = sABS + NFREQ;                          // [NFREQ]
-    const int cell = blockIdx.x;
-    if (cell >= A.batch) return;
-    const float *ABS = A.AABS + (size_t)cell * NFREQ;
-    for (int i = lane; i < NFREQ; i += 64) { sABS[i] = ABS[i];  sAF[i] = A.AF[i]; }
+    const int T = (int)blockDim.x;                       // 1024, or 256 where the matrices are small (several workgroups per CU)
+    const int NE = A.NE, NFREQ = A.NFREQ, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int LSZ = (NE * NE - NE) / 2;
+    float *Lall = lds;                                   // [C][(NE*NE-NE)/2]
+    float *XLall = Lall + C * LSZ;                       // [C][NE]
+    float *sABS = XLall + C * NE;                        // [C][NFREQ]
+    float *sAF  = sABS + C * NFREQ;                      // [NFREQ]
+    const int cell0 = blockIdx.x * C;
+    const int nc = (A.batch - cell0 < C) ? (A.batch - cell0) : C;          // cells of this workgroup (>= 1)
+    for (int i = tid; i < C * NFREQ; i += T) {
+        const int c = i / NFREQ;
+        sABS[i] = (c < nc) ? A.AABS[(size_t)(cell0 + c) * NFREQ + (i - c * NFREQ)] : 0.0f;
+    }
+    for (int i = tid; i < NFREQ; i += T) sAF[i] = A.AF[i];
     __syncthreads();
+    A2E_PROF_DECL;
 
-    // 1. heating: L[u,l] = max(sum_i ABS[i]*Iw*AF[i], 0)   (kernel_A2E.c:45-54).  Four pairs per lane at a time: their
-    //    descriptors and weights are asked for together (one wave per SIMD here: nothing else hides the latency of the
-    //    table reads); every sum runs over its own window in the reference's order.
-    for (int e0 = lane; e0 < A.npair; e0 += 256) {
-        int   i0[4], n[4], dst[4];
-        const float *w[4];
-        float I[4];
+    // 1. heating: L[u,l] = max(sum_i ABS[i]*Iw*AF[i], 0)   (kernel_A2E.c:45-54); every sum runs over its own window in the
+    //    reference's order, the C cells side by side
+    for (int e0 = tid; e0 < A.npair; e0 += T * A2E_Q) {
+        int   i0[A2E_Q], n[A2E_Q], dst[A2E_Q];
+        const float *w[A2E_Q];
+        float I[A2E_Q][C];
         int   nmax = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = e0 + 64 * q;
+        for (int q = 0; q < A2E_Q; q++) {
+            const int e = e0 + T * q;
             const bool on = e < A.npair;
             i0[q]  = on ? A.pair_first[e] : 0;
             n[q]   = on ? (A.pair_last[e] - i0[q] + 1) : 0;
             w[q]   = A.Iw + (on ? A.pair_iw[e] : 0);
             dst[q] = on ? A.pair_dst[e] : -1;
-            I[q]   = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; c++) I[q][c] = 0.0f;
             nmax   = n[q] > nmax ? n[q] : nmax;
         }
         for (int t = 0; t < nmax; t++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (t < n[q]) I[q] += sABS[i0[q] + t] * w[q][t] * sAF[i0[q] + t];
-        }
+            for (int q = 0; q < A2E_Q; q++)
+                if (t < n[q]) {
+                    const float wt = w[q][t], af = sAF[i0[q] + t];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (dst[q] >= 0) L[dst[q]] = __builtin_fmaxf(I[q], 0.0f);
+                    for (int c = 0; c < C; c++) I[q][c] += sABS[c * NFREQ + i0[q] + t] * wt * af;
+                }
+        }
+        (void)nmax;
+#pragma unroll
+        for (int q = 0; q < A2E_Q; q++)
+            if (dst[q] >= 0) {
+#pragma unroll
+                for (int c = 0; c < C; c++) Lall[c * LSZ + dst[q]] = __builtin_fmaxf(I[q][c], 0.0f);
+            }
     }
     __syncthreads();
-    // 2. suffix sums over the upper level (kernel_A2E.c:72-77): a lane owns the columns lane, lane + 64, ... and walks
-    //    them together, row by row from the bottom -- per column the reference's order, several chains in flight
-    for (int j = NE - 3; j > 0; j--) {
-        for (int i = lane; i < j; i += 64) L[A2E_IND(j, i)] += L[A2E_IND(j + 1, i)];
+    A2E_PROF(0);                                         // heating rates
+    // wave wv goes on with cell wv (a wave without a cell walks along idle: the barriers below are the workgroup's)
+    const bool mine = (wv < nc);
+    float *L = Lall + (mine ? wv : 0) * LSZ, *XL = XLall + (mine ? wv : 0) * NE;
+    // 2. suffix sums over the upper level (kernel_A2E.c:72-77): L[j,i] += L[j+1,i] for j = NE-3 .. 1.  A lane owns the columns
+    //    lane, lane + 64, ...; the running sum of a column stays in a register (the reference reads back what it has just
+    //    written: the same additions), so the reads of a column do not wait for its writes
+    if (mine) {
+        for (int i = lane; i < NE - 3; i += 64) {
+            float acc = L[A2E_IND(NE - 2, i)];
+            int j = NE - 3;
+            for (; j - 3 > i; j -= 4) {                                   // four rows of the column read together
+                const float a0 = L[A2E_IND(j, i)], a1 = L[A2E_IND(j - 1, i)], a2 = L[A2E_IND(j - 2, i)], a3 = L[A2E_IND(j - 3, i)];
+                acc = a0 + acc;  L[A2E_IND(j, i)] = acc;
+                acc = a1 + acc;  L[A2E_IND(j - 1, i)] = acc;
+                acc = a2 + acc;  L[A2E_IND(j - 2, i)] = acc;
+                acc = a3 + acc;  L[A2E_IND(j - 3, i)] = acc;
+            }
+            for (; j > i; j--) {
+                acc = L[A2E_IND(j, i)] + acc;
+                L[A2E_IND(j, i)] = acc;
+            }
+        }
     }
     __syncthreads();
+    A2E_PROF(1);                                         // suffix sums
     // 3. forward substitution (kernel_A2E.c:80-88), row per lane: lane r of a block of 64 rows keeps the sum of its row
     //    XL[j] = sum_{i<j} L[j,i] * XL[i], added up in the reference's order (i ascending, mul then add); the rows of a
     //    block are finished one after the other, the finished XL[j] handed to the rows below by v_readlane.  No barrier,
     //    no tree reduction: the same fp32 operations as the serial loop, so the same bits.
-    if (lane == 0) XL[0] = 1.0e-20f;
-    for (int j0 = 0; j0 < NE; j0 += 64) {
-        const int row = j0 + lane;
-        const bool live = (row < NE);
-        float s = 0.0f;
-        if (live) for (int i = 0; i < j0; i++) s += L[A2E_IND(row, i)] * XL[i];       // the blocks above: all XL[i] final
-        const int kend = (NE - j0 < 64) ? (NE - j0) : 64;
-        const float td = live ? (A.Tdown[row] + 1.0e-30f) : 1.0f;                     // lane k finishes row j0 + k
-        for (int k = 0; k < kend; k++) {
-            const int jk = j0 + k;
-            float x = 1.0e-20f;                                                       // XL[0]
-            if (jk > 0) {
-                x = s / td;
+    //    Inside a block nothing goes through LDS: a finished value stays in its lane's register (written to XL once, after the
+    //    block), and the matrix element of the next row to finish is read before the division of this one is waited for.
+    if (mine) {
+        for (int j0 = 0; j0 < NE; j0 += 64) {
+            const int row = j0 + lane;
+            const bool live = (row < NE);
+            float s = 0.0f;
+            if (live) s = a2e_row_sum(L + A2E_IND(row, 0), XL, j0);                       // the blocks above: all XL[i] final
+            const int kend = __builtin_amdgcn_readfirstlane((NE - j0 < 64) ? (NE - j0) : 64);
+            const float td = live ? (A.Tdown[row] + 1.0e-30f) : 1.0f;                     // lane k finishes row j0 + k
+            const float *Lrow = L + (live ? A2E_IND(row, j0) : 0);                        // L[row, j0 + k], k < lane
+            float xmine = 0.0f;                                                           // XL[row], once lane `lane` has finished
+            float lnext = (live && lane > 0) ? Lrow[0] : 0.0f;
+            for (int k = 0; k < kend; k++) {
+                const int jk = j0 + k;
+                const float lcur = lnext;
+                lnext = (live && lane > k + 1) ? Lrow[k + 1] : 0.0f;                      // (asked for now, used in the next turn)
+#if defined(A2E_X_MUL)
+                float x = s * td;                                                         // timing experiment only (wrong numbers)
+#else
+                float x = s / td;
+#endif
                 x = __builtin_fmaxf(x, 0.0f);
+                if (jk == 0) x = 1.0e-20f;                                                // XL[0]
+                float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k));
+                if (xk > 1.0e20f) {
+                    // rescaling (kernel_A2E.c:86-88): XL[0..jk] *= 1e-20, and every later row is summed from those values --
+                    // the sums in hand were taken with the old ones, so they are taken again (rare).  The values of this block
+                    // that are finished go to LDS first, scaled, so that the sums can be taken from there
+                    for (int i = lane; i < j0; i += 64) XL[i] *= 1.0e-20f;
+                    xk *= 1.0e-20f;
+                    if (lane < k) { xmine *= 1.0e-20f;  XL[row] = xmine; }
+                    if (lane == k) { xmine = xk;  XL[jk] = xk; }
+                    s = 0.0f;
+                    if (live && row > jk) s = a2e_row_sum(L + A2E_IND(row, 0), XL, jk + 1);
+                    lnext = (live && lane > k + 1) ? Lrow[k + 1] : 0.0f;
+                } else {
+                    if (lane == k) xmine = xk;
+                    if (live && row > jk) s += lcur * xk;
+                }
             }
-            float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k));
-            if (xk > 1.0e20f) {
-                // rescaling (kernel_A2E.c:86-88): XL[0..jk] *= 1e-20, and every later row is summed from those values --
-                // the sums in hand were taken with the old ones, so they are taken again (rare)
-                for (int i = lane; i < jk; i += 64) XL[i] *= 1.0e-20f;
-                xk *= 1.0e-20f;
-                if (lane == k) XL[jk] = xk;
-                s = 0.0f;
-                if (live && row > jk) for (int i = 0; i <= jk; i++) s += L[A2E_IND(row, i)] * XL[i];
-            } else {
-                if (lane == k) XL[jk] = xk;
-                if (live && row > jk) s += L[A2E_IND(row, jk)] * xk;
-            }
+            if (live) XL[row] = xmine;
         }
     }
     __syncthreads();
+    A2E_PROF(2);                                         // forward substitution
     // normalise (kernel_A2E.c:90-92): the sum in the reference's order, every lane for itself (broadcast reads)
     float nrm = 0.0f;
     for (int i = 0; i < NE; i++) nrm += XL[i];
     nrm = 1.0f / nrm;
     __syncthreads();
-    for (int i = lane; i < NE; i += 64) XL[i] = XL[i] * nrm;
+    if (mine) for (int i = lane; i < NE; i += 64) XL[i] = XL[i] * nrm;
     __syncthreads();
+    A2E_PROF(3);                                         // normalisation
     // 4. emission (kernel_A2E.c:95-100): one frequency per lane, serial over the bins
-    float *EMIT = A.AEMIT + (size_t)cell * NFREQ;
-    for (int f = lane; f < NFREQ; f += 64) {
-        float I = 0.0f;
-        const float *ea = A.EA + f;                       // EA transposed: [bin][frequency]
-        const int ib = A.Ibeg[f];
+    if (mine) {
+        float *EMIT = A.AEMIT + (size_t)(cell0 + wv) * NFREQ;
+        for (int f = lane; f < NFREQ; f += 64) {
+            float I = 0.0f;
+            const float *ea = A.EA + f;                       // EA transposed: [bin][frequency]
+            const int ib = A.Ibeg[f];
 #pragma unroll 8
-        for (int i = ib; i < NE; i++) I += ea[(size_t)i * NFREQ] * XL[i];
-        EMIT[f] = I;
+            for (int i = ib; i < NE; i++) I += ea[(size_t)i * NFREQ] * XL[i];
+            EMIT[f] = I;
+        }
     }
+    A2E_PROF(4);                                         // emission
 }
 
 // EqTemperature (kernel_A2E.c:110-154): trapezoid E_in, log-table lookup of T, Planck emission
@@ -189,17 +273,28 @@ hipError_t soc_launch_eqsolver(const SocEqTArgs &A, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int C>
+static hipError_t a2e_launch(const SocA2EArgs &A, size_t lds, hipStream_t st)
+{
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)soc_a2e_dosolve_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // sixteen waves per workgroup where one workgroup fills the CU's LDS; four where four or more fit (NE <= 64)
+    const int T = (lds * 4 <= 160 * 1024) ? 256 : A2E_T;
+    soc_a2e_dosolve_kernel<C><<<(A.batch + C - 1) / C, T, lds, st>>>(A);
+    return hipGetLastError();
+}
+
 hipError_t soc_launch_a2e_dosolve(const SocA2EArgs &A, hipStream_t st)
 {
     if (A.batch <= 0) return hipSuccess;
-    const size_t lds = (size_t)((A.NE * A.NE - A.NE) / 2 + A.NE + 2 * A.NFREQ) * 4;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)soc_a2e_dosolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    soc_a2e_dosolve_kernel<<<A.batch, 64, lds, st>>>(A);
-    return hipGetLastError();
+    // cells per workgroup: four (one per wave) where their matrices fit the 160 KB of LDS, else two, else one
+    const size_t per_cell = (size_t)((A.NE * A.NE - A.NE) / 2 + A.NE + A.NFREQ) * 4, shared = (size_t)A.NFREQ * 4;
+    if (per_cell + shared > 160 * 1024) return hipErrorInvalidValue;
+    if (4 * per_cell + shared <= 160 * 1024) return a2e_launch<4>(A, 4 * per_cell + shared, st);
+    if (2 * per_cell + shared <= 160 * 1024) return a2e_launch<2>(A, 2 * per_cell + shared, st);
+    return a2e_launch<1>(A, per_cell + shared, st);
 }
 
 hipError_t soc_launch_a2e_eqtemp(const SocEqTArgs &A, hipStream_t st)

@@ -25,6 +25,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
+    prof = None
+    if os.environ.get("SOC_HIP_LIB"):                     # a -DSOC_A2E_PROF build (tools/build_prof.sh): cycles per phase
+        import ctypes as C
+        from soc_amd import lib as soclib
+        L = soclib.load_library(os.environ["SOC_HIP_LIB"])
+        if hasattr(L, "soc_a2e_prof_read"):
+            prof = L.soc_a2e_prof_read
     eng = Engine(0)
     sol = synth.synth_solver(NFREQ=a.nfreq, NE=a.ne, NSIZE=1, seed=5)
     rng = np.random.default_rng(1)
@@ -37,6 +44,16 @@ def main():
         eng.timer_start()
         eng.a2e_run(a.batch)
         ms.append(eng.timer_stop())
+    if prof:
+        buf = (C.c_ulonglong * 8)()
+        prof(buf, 1)
+        eng.a2e_run(a.batch)
+        eng.sync()
+        prof(buf, 0)
+        p = list(buf)
+        tot = max(sum(p[:5]), 1)
+        print("cycles of wave 0 per workgroup phase: heating %.1f %%, suffix sums %.1f %%, substitution %.1f %%, normalisation %.1f %%, emission %.1f %%"
+              % tuple(100.0 * x / tot for x in p[:5]), file=sys.stderr)
     t0 = time.time()
     out = eng.a2e_solve(ABS)
     t1 = time.time()
