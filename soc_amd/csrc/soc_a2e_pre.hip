@@ -1,165 +1,201 @@
 // soc_a2e_pre.hip -- what A2E_pre.py computes per grain size when it writes a <dust>.solver file: the integration
-// weights of the transitions between enthalpy bins (PrepareIntegrationWeightsTrapezoid, kernel_A2E_pre.c:580-736) and the
-// cooling rates of the thermal continuous approximation (PrepareTdown, :123-212).
+// weights of the transitions between enthalpy bins (the quantities of PrepareIntegrationWeightsTrapezoid,
+// kernel_A2E_pre.c:580-736) and the cooling rates of the thermal continuous approximation (PrepareTdown, :123-212).
 //
-// One-off preprocessing (seconds per dust model): the launch shape is the reference's -- one lane per lower bin l
-// (weights), one per upper bin u (cooling) -- and the arithmetic its mix of float and double, operation for operation,
-// so that a solver file written here equals one written by A2E_pre.py (weights, L1, L2: bit for bit; the cooling rates
-// go through exp() in double, which the device evaluates with its own library).
+// The reference gives one work item a lower bin l and lets it walk all upper bins u one after the other, the packed
+// weights of l growing behind a running index.  The transitions (l, u) are independent, so here
+//   * soc_pre_weights_kernel: one WORKGROUP per lower bin, one LANE per upper bin.  A lane integrates its transition's
+//     window function over the frequency grid into a column of LDS (NFREQ floats per lane, lane-minor: no bank
+//     conflicts), finds the first and the last frequency that got weight, and a workgroup-wide prefix sum over the
+//     window lengths gives every transition its place in l's packed segment -- no serial index;
+//   * soc_pre_cooling_kernel: one WAVE per upper bin, one lane per frequency interval (its eight sub-steps), the
+//     interval sums added in double by a wave reduction.
+// Arithmetic contract with the reference (tests/test_a2e_pre.py: weights, L1, L2 bit for bit against the x86 build of
+// kernel_A2E_pre.c): every accumulation into a weight is `float += double`, and the pieces of a transition's window are
+// deposited in ascending energy, as there.  The cooling rates go through exp() in double, which the device evaluates with
+// its own library, and are summed in another order: equal to ~1e-15 relative, compared at 1e-6.
 #include "soc_dev.h"
 
 #define PRE_BOLTZMANN (1.3806488e-16f)
 #define PRE_PLANCK    (6.6260696e-27f)
-#define PRE_SS        8
+#define PRE_SUBSTEPS  8
+#define PRE_T         64          // lanes of the weights workgroup = upper bins in flight
 
-// Interpolate (kernel_A2E_pre.c:10-23)
-__device__ __forceinline__ float soc_pre_interpolate(const int n, const float *x, const float *y, const float x0)
+// y(x0) on the table (x, y), linear, clamped at the ends (kernel_A2E_pre.c:10-23 `Interpolate`: bisection down to a
+// window of at most five nodes, then the first node at or above x0)
+__device__ __forceinline__ float soc_pre_table(const int n, const float *x, const float *y, const float x0)
 {
     if (x0 <= x[0])     return y[0];
     if (x0 >= x[n - 1]) return y[n - 1];
-    int a = 0, c = n - 1, b;
-    while ((c - a) > 4) {
-        b = (a + c) / 2;
-        if (x[b] > x0) c = b; else a = b;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 4) {
+        const int mid = (lo + hi) / 2;
+        if (x[mid] > x0) hi = mid; else lo = mid;
     }
-    for (b = a; b <= c; b++) if (x[b] >= x0) break;
-    const float w = (x[b] - x0) / (x[b] - x[b - 1]);
-    return w * y[b - 1] + (1.0f - w) * y[b];
+    int k = lo;
+    while (k <= hi && !(x[k] >= x0)) k++;
+    const float w = (x[k] - x0) / (x[k] - x[k - 1]);
+    return w * y[k - 1] + (1.0f - w) * y[k];
 }
 
-__device__ __forceinline__ double soc_pre_clamp(double x, double lo, double hi) { const double m = (x < lo) ? lo : x;  return (hi < m) ? hi : m; }
-__device__ __forceinline__ double soc_pre_min(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double soc_pre_within(double x, double lo, double hi) { const double m = (x < lo) ? lo : x;  return (hi < m) ? hi : m; }
 
-__global__ __launch_bounds__(64) void soc_a2e_pre_tdown_kernel(const int NFREQ, const float *FREQ, const float *Ef, const float *SKABS,
-                                                               const int NE, const float *E, const float *T, float *Tdown)
+// One transition l -> u.  The window function of the transition (how much of bin u a photon of energy x lifts a grain of
+// bin l into) is a trapezoid over [W1, W4]: it rises from W1 to W2, is flat to W3, falls to W4 (:617-623).  It is integrated
+// against x on the frequency grid by cutting [W1, W4] at the grid nodes and at W2, W3; a piece [x0, x1] inside the grid
+// interval `node` deposits onto the two nodes of that interval with the hat-function weights of its end points.
+struct SocPreWindow {
+    float *col;                  // this lane's accumulators: col[f * PRE_T]
+    const float *Ef;
+    int    nfreq;
+    double scale;                // 1 / (Eu - El) / (FACTOR * PLANCK)
+
+    __device__ __forceinline__ void deposit(const int node, const double x0, const double x1, const double g0, const double g1)
+    {
+        const double width = Ef[node + 1] - Ef[node];
+        const double h0 = (x0 - Ef[node]) / width, h1 = (x1 - Ef[node]) / width;      // hat weights of the upper node
+        col[node * PRE_T]       += 0.5 * (x1 - x0) * (g0 * x0 * (1.0 - h0) + g1 * x1 * (1.0 - h1)) * scale;
+        col[(node + 1) * PRE_T] += 0.5 * (x1 - x0) * (g0 * x0 * h0 + g1 * x1 * h1) * scale;
+    }
+};
+
+__global__ __launch_bounds__(PRE_T) void soc_pre_weights_kernel(const int NFREQ, const int NE, const float FACTOR, const float *Ef, const float *E,
+                                                                int *L1, int *L2, float *IW, int *noIw)
 {
-    const int u = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    extern __shared__ float lds[];
+    float *acc  = lds;                                    // [NFREQ][PRE_T]
+    int   *scan = (int *)(acc + (size_t)NFREQ * PRE_T);   // [PRE_T] window lengths -> places
+    const int l = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (l >= NE - 1) return;
+    float *segment = IW + (size_t)l * NE * NFREQ;         // the packed weights of lower bin l
+    const double El = 0.5 * (E[l] + E[l + 1]), dEl = E[l + 1] - E[l];
+    int filled = 0;                                       // weights of l packed so far (the same in every lane)
+    for (int u0 = l + 1; u0 < NE; u0 += PRE_T) {
+        const int  u = u0 + lane;
+        const bool on = (u < NE);
+        int first = -1, last = -2;
+        if (on) {
+            const double Eu = 0.5 * (E[u] + E[u + 1]), dEu = E[u + 1] - E[u];
+            const double W1 = E[u] - E[l + 1];
+            const double W2 = fminf(E[u] - E[l], E[u + 1] - E[l + 1]);
+            const double W3 = fmaxf(E[u] - E[l], E[u + 1] - E[l + 1]);
+            const double W4 = E[u + 1] - E[l];
+            if (!((Ef[0] > W4) || (Ef[NFREQ - 1] < W1))) {                  // the window meets the simulated frequencies
+                SocPreWindow win;
+                win.col = acc + lane;  win.Ef = Ef;  win.nfreq = NFREQ;
+                win.scale = 1.0 / (Eu - El) / (FACTOR * PRE_PLANCK);
+                for (int f = 0; f < NFREQ; f++) win.col[f * PRE_T] = 0.0f;
+                // the grid interval that holds W1 (:631-636)
+                int node = 1;
+                while ((node < NFREQ - 1) && (Ef[node] < W1)) node++;
+                node = (node > 1) ? (node - 1) : 0;
+                // three stretches of the window, each ending at `stop`; `level` is the window function at the right end of a piece
+                double x0, x1 = soc_pre_within(W1, (double)Ef[node], (double)Ef[node + 1]), g0, g1 = (x1 - W1) / dEl;
+                const double plateau = ((dEu < dEl) ? dEu : dEl) / dEl;
+                bool opened = false;                       // the first piece starts inside its interval; the later ones where the last ended
+                for (int stretch = 0; stretch < 3; stretch++) {
+                    const double stop = (stretch == 0) ? W2 : ((stretch == 1) ? W3 : W4);
+                    while (true) {
+                        if (opened && !((node < NFREQ - 1) && (x1 < stop))) break;
+                        x0 = x1;  g0 = g1;
+                        x1 = opened ? ((stop < (double)Ef[node + 1]) ? stop : (double)Ef[node + 1]) : soc_pre_within(stop, x0, (double)Ef[node + 1]);
+                        g1 = (stretch == 0) ? ((x1 - W1) / dEl) : ((stretch == 1) ? plateau : ((W4 - 0.5 * (x0 + x1)) / dEl));
+                        win.deposit(node, x0, x1, g0, g1);
+                        opened = true;
+                        if (x1 < stop) node++;
+                    }
+                }
+                // absorptions that keep the grain inside its bin count for the step to the next one (u = l + 1, :704-719)
+                if (u == l + 1) {
+                    node = 0;
+                    x1 = Ef[0];
+                    while ((node < NFREQ - 1) && (Ef[node] < dEl)) {
+                        x0 = x1;
+                        x1 = soc_pre_within(dEl, x0, (double)Ef[node + 1]);
+                        win.deposit(node, x0, x1, 1.0 - x0 / dEl, 1.0 - x1 / dEl);
+                        node++;
+                    }
+                }
+                for (int f = 0; f < NFREQ; f++)
+                    if (win.col[f * PRE_T] > 0.0f) { if (first < 0) first = f;  last = f; }
+            } else {
+                first = -1;  last = -2;
+            }
+            L1[l * NE + u] = first;
+            L2[l * NE + u] = last;
+        }
+        // places of the windows in l's segment: exclusive prefix sum of their lengths over the lanes
+        const int len = on ? (last - first + 1) : 0;
+        scan[lane] = len;
+        __syncthreads();
+        for (int d = 1; d < PRE_T; d <<= 1) {
+            const int v = (lane >= d) ? scan[lane - d] : 0;
+            __syncthreads();
+            scan[lane] += v;
+            __syncthreads();
+        }
+        const int place = filled + scan[lane] - len;
+        const int total = scan[PRE_T - 1];
+        for (int k = 0; k < len; k++) segment[place + k] = acc[(size_t)(first + k) * PRE_T + lane];
+        filled += total;
+        __syncthreads();
+    }
+    if (lane == 0) noIw[l] = filled;
+}
+
+// the integrand of the cooling rate at photon energy e for a grain at temperature Tu (:150-152)
+__device__ __forceinline__ double soc_pre_emission(const int NFREQ, const float *FREQ, const float *SKABS, const double e, const double Tu)
+{
+    const double k = soc_pre_table(NFREQ, FREQ, SKABS, (float)(e / PRE_PLANCK));
+    return e * e * e * k / (exp(e / (PRE_BOLTZMANN * Tu)) - 1.0);
+}
+
+__global__ __launch_bounds__(64) void soc_pre_cooling_kernel(const int NFREQ, const float *FREQ, const float *Ef, const float *SKABS,
+                                                             const int NE, const float *E, const float *T, float *Tdown)
+{
+    const int u = 1 + (int)blockIdx.x, lane = (int)threadIdx.x;
     if (u >= NE) return;
-    if (u == 1) Tdown[0] = 0.0f;
-    double I = 0.0, ee0 = 0.0, ee1, yy0 = 0.0, yy1, x;
-    const double Eu = 0.5 * (E[u] + E[u + 1]);
-    const double El = 0.5 * (E[u - 1] + E[u]);
-    const double Tu = soc_pre_interpolate(NE + 1, E, T, (float)Eu);
-    int i = 0;
-    while ((i < (NFREQ - 1)) && Ef[i + 1] < Eu) {
-        ee0 = Ef[i];
-        x   = soc_pre_interpolate(NFREQ, FREQ, SKABS, (float)(ee0 / PRE_PLANCK));
-        yy0 = ee0 * ee0 * ee0 * x / (exp(ee0 / (PRE_BOLTZMANN * Tu)) - 1.0);
-        for (int j = 0; j < PRE_SS; j++) {
-            ee1 = Ef[i] + (j + 1) * (Ef[i + 1] - Ef[i]) / PRE_SS;           // float arithmetic, as written
-            x   = soc_pre_interpolate(NFREQ, FREQ, SKABS, (float)(ee1 / PRE_PLANCK));
-            yy1 = ee1 * ee1 * ee1 * x / (exp(ee1 / (PRE_BOLTZMANN * Tu)) - 1.0);
-            I  += 0.5 * (ee1 - ee0) * (yy1 + yy0);
-            ee0 = ee1;
-            yy0 = yy1;
+    if (u == 1 && lane == 0) Tdown[0] = 0.0f;
+    const double Eu = 0.5 * (E[u] + E[u + 1]), El = 0.5 * (E[u - 1] + E[u]);
+    const double Tu = soc_pre_table(NE + 1, E, T, (float)Eu);
+    // the frequency intervals below Eu are integrated whole, the one that holds Eu up to Eu (:146-181)
+    int whole = 0;
+    while ((whole < NFREQ - 1) && (Ef[whole + 1] < Eu)) whole++;
+    double mine = 0.0;
+    for (int i = lane; i <= whole && i < NFREQ - 1; i += 64) {
+        const bool cut = (i == whole);                      // the interval of Eu
+        double e0, y0;
+        if (!cut) {
+            e0 = Ef[i];
+            y0 = soc_pre_emission(NFREQ, FREQ, SKABS, e0, Tu);
+        } else if (i == 0) {
+            e0 = 0.0;  y0 = 0.0;                            // (nothing before it: the reference starts this piece from zero)
+        } else {
+            e0 = Ef[i - 1] + PRE_SUBSTEPS * (Ef[i] - Ef[i - 1]) / PRE_SUBSTEPS;      // where the interval before ended, in float as there
+            y0 = soc_pre_emission(NFREQ, FREQ, SKABS, e0, Tu);
         }
-        i++;
-    }
-    if (i < (NFREQ - 1)) {
-        for (int j = 0; j < PRE_SS; j++) {
-            ee1 = Ef[i] + (j + 1) * (Eu - Ef[i]) / PRE_SS;
-            x   = soc_pre_interpolate(NFREQ, FREQ, SKABS, (float)(ee1 / PRE_PLANCK));
-            yy1 = ee1 * ee1 * ee1 * x / (exp(ee1 / (PRE_BOLTZMANN * Tu)) - 1.0);
-            I  += 0.5 * (ee1 - ee0) * (yy1 + yy0);
-            ee0 = ee1;
-            yy0 = yy1;
+        for (int j = 0; j < PRE_SUBSTEPS; j++) {
+            const double e1 = cut ? (Ef[i] + (j + 1) * (Eu - Ef[i]) / PRE_SUBSTEPS) : (double)(Ef[i] + (j + 1) * (Ef[i + 1] - Ef[i]) / PRE_SUBSTEPS);
+            const double y1 = soc_pre_emission(NFREQ, FREQ, SKABS, e1, Tu);
+            mine += 0.5 * (e1 - e0) * (y1 + y0);
+            e0 = e1;  y0 = y1;
         }
     }
-    I *= 9.612370e+58 / (Eu - El);
-    Tdown[u] = (float)I;
-}
-
-// the contribution of one piece [a, b] of a frequency bin to the two weights at its ends (the four statements the
-// reference repeats in every section of the integral)
-#define SOC_PRE_ADD(F1, F2) do { \
-        temp_Iw[i]     += 0.5 * (b - a) * ((F1) * a * (1.0 - alpha) + (F2) * b * (1.0 - beta)) * coeff; \
-        temp_Iw[i + 1] += 0.5 * (b - a) * ((F1) * a * alpha + (F2) * b * beta) * coeff; } while (0)
-
-__global__ __launch_bounds__(64) void soc_a2e_pre_weights_kernel(const int NFREQ, const int NE, const float FACTOR, const float *Ef, const float *E,
-                                                                 int *L1, int *L2, float *IW, float *wrk, int *noIw)
-{
-    const int l = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (l >= (NE - 1)) return;
-    int index = 0, i;
-    float *temp_Iw = &wrk[(size_t)l * NFREQ];
-    float *Iw = &IW[(size_t)l * NE * NFREQ];
-    const double El = 0.5 * (E[l] + E[l + 1]);
-    const double dEl = E[l + 1] - E[l];
-    for (int u = l + 1; u < NE; u++) {
-        const double Eu = 0.5 * (E[u] + E[u + 1]);
-        const double dEu = E[u + 1] - E[u];
-        const double W1 = E[u] - E[l + 1];
-        const double W2 = fminf(E[u] - E[l], E[u + 1] - E[l + 1]);
-        const double W3 = fmaxf(E[u] - E[l], E[u + 1] - E[l + 1]);
-        const double W4 = E[u + 1] - E[l];
-        if ((Ef[0] > W4) || (Ef[NFREQ - 1] < W1)) {
-            L1[l * NE + u] = -1;
-            L2[l * NE + u] = -2;
-            continue;
-        }
-        for (i = 0; i < NFREQ; i++) temp_Iw[i] = 0.0f;
-        const double coeff = 1.0 / (Eu - El) / (FACTOR * PRE_PLANCK);
-        double a, b, alpha, beta, G1, G2;
-        i = 1;
-        while ((i < (NFREQ - 1)) && (Ef[i] < W1)) i += 1;
-        i = (i - 1 > 0) ? (i - 1) : 0;
-        // The integrand G(E) E C_abs(E) over [W1, W4] is piecewise: G rises on [W1, W2], is flat on [W2, W3], falls on
-        // [W3, W4].  Every section is cut at the frequency grid; a piece [a, b] adds to the weights of its two grid
-        // points.  The first piece starts inside the bin of W1, the others continue from where the last one ended.
-        a     = soc_pre_clamp(W1, (double)Ef[i], (double)Ef[i + 1]);
-        b     = soc_pre_clamp(W2, a, (double)Ef[i + 1]);
-        alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-        beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-        G1    = (a - W1) / dEl;
-        G2    = (b - W1) / dEl;
-        SOC_PRE_ADD(G1, G2);
-        if (b < W2) i += 1;
-        for (int section = 0; section < 3; section++) {
-            const double Wend = (section == 0) ? W2 : ((section == 1) ? W3 : W4);
-            while ((i < (NFREQ - 1)) && (b < Wend)) {
-                a     = b;
-                G1    = G2;
-                b     = soc_pre_min(Wend, (double)Ef[i + 1]);
-                alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-                beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-                G2    = (section == 0) ? ((b - W1) / dEl) : ((section == 1) ? (soc_pre_min(dEl, dEu) / dEl) : ((W4 - 0.5 * (a + b)) / dEl));
-                SOC_PRE_ADD(G1, G2);
-                if (b < Wend) i += 1;
-            }
-        }
-        // inside the bin (u = l + 1)
-        if (u == (l + 1)) {
-            i = 0;
-            b = Ef[0];
-            while ((i < (NFREQ - 1)) && (Ef[i] < dEl)) {
-                a     = b;
-                b     = soc_pre_clamp(dEl, a, (double)Ef[i + 1]);
-                alpha = (a - Ef[i]) / (Ef[i + 1] - Ef[i]);
-                beta  = (b - Ef[i]) / (Ef[i + 1] - Ef[i]);
-                SOC_PRE_ADD(1.0 - a / dEl, 1.0 - b / dEl);
-                i += 1;
-            }
-        }
-        int first_non_zero = -1, last_non_zero = -2;
-        for (i = 0; i < NFREQ; i++) {
-            if (temp_Iw[i] > 0.0 && first_non_zero < 0) first_non_zero = i;
-            if (temp_Iw[i] > 0.0) last_non_zero = i;
-        }
-        L1[l * NE + u] = first_non_zero;
-        L2[l * NE + u] = last_non_zero;
-        for (i = first_non_zero; i <= last_non_zero; i++) {
-            Iw[index] = (i < NFREQ) ? temp_Iw[i] : 0.0f;
-            index++;
-        }
-    }
-    noIw[l] = index;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) Tdown[u] = (float)(mine * (9.612370e+58 / (Eu - El)));
 }
 
 hipError_t soc_launch_a2e_pre(int NFREQ, int NE, float FACTOR, const float *FREQ, const float *Ef, const float *SKABS, const float *E, const float *T,
                               int *L1, int *L2, float *IW, float *wrk, int *noIw, float *Tdown, hipStream_t st)
 {
-    const int nb = (NE + 63) / 64;
-    soc_a2e_pre_weights_kernel<<<nb, 64, 0, st>>>(NFREQ, NE, FACTOR, Ef, E, L1, L2, IW, wrk, noIw);
-    soc_a2e_pre_tdown_kernel<<<nb, 64, 0, st>>>(NFREQ, FREQ, Ef, SKABS, NE, E, T, Tdown);
+    (void)wrk;                                             // (the accumulators live in LDS)
+    const size_t lds = ((size_t)NFREQ * PRE_T + PRE_T) * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;     // NFREQ <= 639
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)soc_pre_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    soc_pre_weights_kernel<<<NE - 1, PRE_T, lds, st>>>(NFREQ, NE, FACTOR, Ef, E, L1, L2, IW, noIw);
+    soc_pre_cooling_kernel<<<NE - 1, 64, 0, st>>>(NFREQ, FREQ, Ef, SKABS, NE, E, T, Tdown);
     return hipGetLastError();
 }

@@ -211,8 +211,29 @@ int soc_create(int device, soc_ctx **out)
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
+    if (e != hipSuccess || ndev <= 0) {
+        // two HIP runtimes in one process (torch ships its own libamdhip64.so): the one initialised second finds no device
+        std::string first, second;
+        if (FILE *fp = fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (fgets(line, sizeof line, fp)) {
+                const char *q = strstr(line, "libamdhip64");
+                if (!q) continue;
+                const char *b = strchr(line, '/');
+                if (!b) continue;
+                std::string path(b);
+                while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+                if (first.empty()) first = path;
+                else if (path != first && second.empty()) second = path;
+            }
+            fclose(fp);
+        }
+        if (!second.empty())
+            return fail(nullptr, SOC_ERR_HIP, "soc_create: no HIP device available (%s): two HIP runtimes are loaded in this process (%s and %s) and the "
+                        "one initialised second finds no device -- load torch's first (import torch before libsoc_hip.so is opened; soc_amd.lib does)",
+                        hipGetErrorString(e), first.c_str(), second.c_str());
         return fail(nullptr, SOC_ERR_HIP, "soc_create: no HIP device available (%s)", hipGetErrorString(e));
+    }
     if (device < 0 || device >= ndev)
         return fail(nullptr, SOC_ERR_ARG, "soc_create: device %d out of range (0..%d)", device, ndev - 1);
     soc_ctx *c = new soc_ctx();

@@ -114,13 +114,29 @@ class SocError(RuntimeError):
     pass
 
 
+def _torch_runtime_first():
+    """torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, without a soname), libsoc_hip.so is linked against the
+    system's (libamdhip64.so.7): a process that uses both holds two runtimes, and the one initialised second finds no device.
+    With torch's runtime loaded first both work -- so where torch is installed it is imported before libsoc_hip.so is opened,
+    whatever the order of the caller's own imports.  (Without torch there is one runtime and nothing to do.)"""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch                                   # noqa: F401
+    except Exception:                                      # a broken torch installation must not stop a run that does not need it
+        pass
+
+
 def load_library(path=None):
     """dlopen libsoc_hip.so and declare every prototype.  Raises SocError if it is missing.
-    A process that also uses torch (multi-GPU runs: soc_amd/dist.py) must import torch BEFORE this call, so that the
-    library binds to the HIP runtime torch ships; loaded the other way round, torch finds no device."""
+    Safe to call before or after `import torch` (see _torch_runtime_first)."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    _torch_runtime_first()
     path = path or LIBNAME
     if not os.path.exists(path):
         raise SocError("%s not found: build it with `python -m soc_amd.build` "

@@ -27,9 +27,8 @@ def oracle_libm():
 @pytest.fixture(scope="session")
 def engine():
     """The HIP engine on cuda:0.  Fails loudly (no fallback) when the library or GPU is missing.
-    torch is imported first: a process that uses both must load torch's HIP runtime before libsoc_hip.so binds to one
-    (two runtimes in one process: the second sees no device) -- soc_amd/dist.py and bench.py follow the same order."""
-    import torch                                   # noqa: F401
+    (soc_amd.lib loads torch's HIP runtime before libsoc_hip.so where torch is installed: two runtimes in one process, the
+    one initialised second sees no device -- tests/test_gpu_binding.py::test_library_and_torch_load_in_either_order.)"""
     from soc_amd.lib import Engine
     eng = Engine(0)
     yield eng

@@ -132,3 +132,26 @@ def test_bound_image_on_a_torch_stream(engine):
         engine.sca_bind_out(None)                                        # library-owned image again
         engine.set_stream(0)
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_library_and_torch_load_in_either_order():
+    """torch ships its own HIP runtime; the one of two runtimes that is initialised second finds no device.  soc_amd.lib loads torch's
+    first wherever torch is installed, so a caller may create the engine before or after `import torch` (a child process each: the
+    session's fixture has loaded both already)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = ("import sys; sys.path.insert(0, %r)\n"
+            "%s\n"
+            "import numpy as np\n"
+            "from soc_amd import synth\n"
+            "eng.set_cloud(synth.cartesian_cloud(8, seed=1))\n"
+            "t = torch.ones(4, device='cuda') * 2\n"
+            "assert torch.cuda.is_available() and float(t.sum().item()) == 8.0\n"
+            "eng.close()\nprint('order ok')\n")
+    first_engine = "from soc_amd.lib import Engine\neng = Engine(0)\nimport torch"
+    first_torch = "import torch\nfrom soc_amd.lib import Engine\neng = Engine(0)"
+    for order in (first_engine, first_torch):
+        out = subprocess.run([sys.executable, "-c", body % (repo, order)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "order ok" in out.stdout, out.stderr[-2000:]
