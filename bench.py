@@ -53,7 +53,7 @@ from soc_amd.lib import Engine               # noqa: E402
 C2_ABS, C2_SCA = 8.9084e-7, 5.4552e-6
 C2_FREQ = 4.677e14
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_TALLY_EVENT = 12                   # 4 B density read + 8 B tally read-modify-write
+BYTES_PER_TALLY_EVENT = 12                   # 4 B density read + 8 B tally read-modify-write; + 8 B with the INT tally
 C3_GL = 0.02                                 # pc
 C3_CELLS = 49526352                          # synth.octree_cloud(256, levels=4, frac=0.10, seed=1234); oracle/build.py ref "oct256"
 R_SUN, T_SUN = 6.957e10, 5800.0
@@ -210,8 +210,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="launches executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
                          "0 = all steps in one sweep (at most 128 launches)")
-    ap.add_argument("--workload", choices=["C2", "C3"], default="C3",
-                    help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]")
+    ap.add_argument("--workload", choices=["C2", "C3", "C3INT"], default="C3",
+                    help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]; C3INT = C3 "
+                         "without `noabsorbed`: the per-frequency absorptions INT are kept (the input of config 5) -- the two launches "
+                         "of a frequency are one sweep with one INT tally, read back after it (ASOC.py:1482-1498)")
     ap.add_argument("--global", dest="global0", type=int, default=16777216,
                     help="C3: GLOBAL_0, work items of the point-source and diffuse launches (ini key `global`; reference: 32768)")
     args = ap.parse_args()
@@ -242,11 +244,14 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    work = c3_workload(args.global0) if args.workload == "C3" else c2_workload()
+    work = c3_workload(args.global0) if args.workload in ("C3", "C3INT") else c2_workload()
+    keep_int = (args.workload == "C3INT")
+    if keep_int:
+        work["name"] = work["name"].replace("noabsorbed;", "absorbed file (per-frequency INT tally kept, read back after the two launches of a frequency);")
     cloud = work["cloud"]
     eng = Engine(local_rank)
     eng.set_cloud(cloud)
-    eng.set_features(with_int=0, ps_method=0, use_emweight=0)      # noabsorbed: TABS only
+    eng.set_features(with_int=1 if keep_int else 0, ps_method=0, use_emweight=0)      # noabsorbed: TABS only
 
     tabs = None
     stream = None
@@ -262,7 +267,7 @@ def main():
     eng.zero(0)
 
     weak = args.scaling == "weak"
-    mixed_sweeps = (args.workload == "C3") and not args.separate_kinds     # the config-3 hierarchy: brick-local walk, kinds share sweeps
+    mixed_sweeps = (args.workload in ("C3", "C3INT")) and not args.separate_kinds     # the config-3 hierarchy: brick-local walk, kinds share sweeps
     inflight = [0]                                                   # work items of this rank in its first sweep
     KDEV = 1.0 / world if weak else 1.0                              # ASOC.py:180,1501
 
@@ -287,13 +292,18 @@ def main():
         chunks = []
         for m in mine:
             new = (not chunks or len(chunks[-1]) >= cap
-                   or (args.separate_kinds and work["step"](chunks[-1][-1][0])["kind"] != work["step"](m[0])["kind"]))
+                   or (args.separate_kinds and work["step"](chunks[-1][-1][0])["kind"] != work["step"](m[0])["kind"])
+                   or (keep_int and work["step"](chunks[-1][-1][0])["IFREQ"] != work["step"](m[0])["IFREQ"]))      # one INT tally per frequency
             if new:
                 chunks.append([])
             chunks[-1].append(m)
         eng.timer_start()
         for chunk in chunks:
-            eng.batch_begin(len(chunk))
+            if keep_int:
+                eng.zero(1)
+                eng.batch_begin_shared_int(len(chunk))
+            else:
+                eng.batch_begin(len(chunk))
             for i, first, count in chunk:
                 s = work["step"](i)
                 L = s["L"]
@@ -309,6 +319,8 @@ def main():
                     eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, np.float32(s["BG"] * KDEV), s["TW"],
                                GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
             eng.batch_end()
+            if keep_int:
+                eng.read_tally(1)                                   # the frequency's column of the absorbed file (device -> host, as ASOC.py:1482)
         if world > 1:
             # TABS integrates over frequency on the device (ASOC.py:1533): one all-reduce per source block, here per call.
             # The local tally is the rank's share only, so the sum over ranks is the one-GPU tally (to summation order).
@@ -347,7 +359,7 @@ def main():
     # per-kind rates: the kinds share the timed sweep, so each kind's launches of the first 8 timed steps are run again in a
     # sweep of their own (outside the timed region; fewer launches per sweep than the timed one)
     per_kind = None
-    if rank == 0 and world == 1 and len(work["kinds"]) > 1 and not args.no_per_kind:
+    if rank == 0 and world == 1 and len(work["kinds"]) > 1 and not args.no_per_kind and not keep_int:
         per_kind = {}
         for kd in work["kinds"]:
             eng.stats(reset=True)
@@ -388,9 +400,9 @@ def main():
 
     if rank == 0:
         kavg_s = kernel_ms * 1e-3 / max(args.steps, 1)
-        alg_bytes = events_rank / max(args.steps, 1) * BYTES_PER_TALLY_EVENT
+        alg_bytes = events_rank / max(args.steps, 1) * (BYTES_PER_TALLY_EVENT + (8 if keep_int else 0))
         achieved = alg_bytes / kavg_s / 1e9
-        kname = {3: "soc_lbrick_pass<TABS-only> (brick-local hierarchies: soc_lbrick_walk + soc_brick_events)",
+        kname = {3: "soc_lbrick_pass<%s> (brick-local hierarchies: soc_lbrick_walk + soc_brick_events)" % ("TABS + INT" if keep_int else "TABS-only"),
                  2: "soc_brick_pass<octree,scalar-opacity,TABS-only>", 1: "soc_brick_pass<Cartesian,scalar-opacity,TABS-only>"}.get(form, "soc_brick_pass")
         kernel_name = ("%s (+ soc_brick_scan, soc_brick_scatter), %d passes in the last sweep: "
                        "time is the HIP-event span of all kernels of the K steps / K" % (kname, passes)) if passes else "soc_sim_pb_kernel / soc_sim_cl_kernel (direct)"
@@ -411,7 +423,8 @@ def main():
                        "cells": cloud.CELLS, "tally_events_per_packet": events_rank / max(packets_rank, 1),
                        "scatterings_per_packet": scat_rank / max(packets_rank, 1),
                        "frequencies_in_the_timed_steps": freqs,
-                       "launches_per_sweep": args.in_flight if args.in_flight else "all steps in one sweep (point-source and diffuse launches together; at most 128)",
+                       "launches_per_sweep": "the two launches of a frequency (one INT tally)" if keep_int else (
+                           args.in_flight if args.in_flight else "all steps in one sweep (point-source and diffuse launches together; at most 128)"),
                        "work_items_in_flight_rank0": inflight[0],
                        "parallelism": "1 process per GPU; %s" % (
                            "replicas with per-rank seeds, weight 1/N + 1 RCCL all-reduce of TABS" if weak

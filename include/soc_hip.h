@@ -178,6 +178,12 @@ int soc_batch_end(soc_ctx *ctx);
  * launches of one kind per batch; after soc_batch_end, soc_batch_read_int(k) copies the INT tally of the k-th launch of
  * the batch (n = CELLS).  Replaces K x [kernel launch + enqueue_copy(INT)] by K launches + K copies. */
 int soc_batch_begin_int(soc_ctx *ctx, int max_launches);
+/* The launches of ONE frequency that keep the INT tally (the source blocks of ASOC.py:1028-1545 at one IFREQ: point sources,
+ * background, diffuse emission): deferred until soc_batch_end like soc_batch_begin's, all tallying into the handle's INT buffer
+ * (soc_zero(ctx, 1) before, soc_read_tally(ctx, 1) after), so that they share brick sweeps -- and, where the walk keeps tallies
+ * in LDS per workgroup, the same brick queues.  Replaces the per-launch enqueue + finish() + enqueue_copy(INT) of ASOC.py:1360-1372,
+ * :1461, :1482-1498 for the launches of one frequency. */
+int soc_batch_begin_shared_int(soc_ctx *ctx, int max_launches);
 int soc_batch_read_int(soc_ctx *ctx, int k, float *out, long n);
 
 /* ---- region of interest of nested runs (ini keys roi, roisave, roiload, roipac, roinside) ---- */

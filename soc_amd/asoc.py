@@ -319,6 +319,14 @@ class AbsorptionRun:
             if (not own_freq) or (FABSORBED is not None and U.SAVE_INTENSITY == 0 and (not U.WITH_ROI_SAVE) and self.CLPAC < 1 and thin == 1):
                 shares, self.freq_owner = self._launch_shares(by_frequency=own_freq)
         owned = self.freq_owner is not None
+        # Runs that keep the per-frequency absorptions on a hierarchy: frequency by frequency, the source blocks of a frequency as one
+        # batch that tallies into one INT array (soc_batch_begin_shared_int), so that its point-source, background and diffuse
+        # launches share brick sweeps and brick queues.  (Cartesian grids: the per-launch INT batches below; the intensity file,
+        # region-of-interest records and a Healpix sky keep the block-by-block loop.)
+        if (self.with_int and FABSORBED is not None and c.LEVELS > 1 and U.SAVE_INTENSITY == 0 and not U.WITH_ROI_SAVE
+                and not U.WITH_ROI_LOAD and len(self.HPBG) == 0 and hasattr(e, "batch_begin_shared_int") and U.ITERATIONS >= 1
+                and (shares is None or owned)):
+            return self._simulate_by_frequency(CTABS, FABSORBED, shares, owned, rng)
         if one_batch:
             e.zero(0)
             e.batch_begin(0)
@@ -490,6 +498,82 @@ class AbsorptionRun:
             e.set_roi_load(None, 0, None)
         if isinstance(self.ROI_SAVE, np.memmap):
             self.ROI_SAVE.flush()
+        return CTABS, FABSORBED
+
+    def _simulate_by_frequency(self, CTABS, FABSORBED, shares, owned, rng):
+        """for IFREQ: for II in (point sources, background, diffuse): launch -- the loop of ASOC.py:1028-1545 with the frequency
+        outside, for runs that keep the per-frequency absorptions: the launches of one frequency are one batch with one INT
+        tally.  TABS integrates over everything on the device and is read once (CTABS is the sum over the blocks anyway)."""
+        U, e, c = self.U, self.eng, self.cloud
+        CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
+        blocks = [(II, self._constant_launch(II)) for II in range(3)]
+        blocks = [(II, L) for II, L in blocks if L is not None]
+        for II, L in blocks:
+            self.log("=== %s  GLOBAL %d x BATCH %d = %d" % (['PS', 'BG', 'DE'][II], L["GLOBAL"], L["BATCH"], L["PACKETS"]))
+        e.zero(0)
+        for IFREQ in range(NFREQ):
+            FREQ = float(FFREQ[IFREQ])
+            if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
+                continue
+            t0 = time.time()
+            ABS, SCA = self._optical_for(IFREQ)
+            self._scatter_tables_for(IFREQ)
+            FF = np.float32(launch.trapezoid_weight(FFREQ, IFREQ))
+            if U.SEED > 0:
+                seed = launch.launch_seed(U.SEED, IFREQ, 1, 0)
+            else:
+                seed = float(rng.random())
+                if self.comm and self.world > 1:          # every rank must use the same streams
+                    seed = self._bcast_seed(seed)
+            mine = [(II, L) + ((0, L["GLOBAL"]) if shares is None else shares.get((II, IFREQ), (0, 0))) for II, L in blocks]
+            if shares is None and self.comm:
+                mine = [(II, L) + self.comm.shard(L["GLOBAL"]) for II, L in blocks]
+            mine = [m for m in mine if m[3] > 0]
+            if not mine:
+                continue                                  # another rank's frequency
+            e.zero(1)
+            e.batch_begin_shared_int(len(mine))
+            self.timers["Tpush"] += time.time() - t0
+            for II, L, first, count in mine:
+                t0 = time.time()
+                if II == 2:
+                    dr_ind = IFREQ + (self.DIFFUSERAD.shape[1] - NFREQ)
+                    if dr_ind < 0 or dr_ind >= self.DIFFUSERAD.shape[1]:
+                        continue
+                    EMIT = np.zeros(CELLS, np.float32)
+                    for level in range(c.LEVELS):
+                        coeff = U.GL * PARSEC / (8.0 ** level) * U.K_DIFFUSE
+                        a, b = int(c.OFF[level]), int(c.OFF[level] + c.LCELLS[level])
+                        EMIT[a:b] = self.DIFFUSERAD[a:b, dr_ind] * coeff
+                    e.set_emission(EMIT, None)
+                self.timers["Tpush"] += time.time() - t0
+                t0 = time.time()
+                if II == 2:
+                    e.sim_cl(II, L["PACKETS"], L["BATCH"], seed, FF, L["GLOBAL"], gid_first=first, gid_count=count)
+                else:
+                    PS = (self.LPS[:, IFREQ] * np.float32(L["WPS"])) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
+                    BG = np.float32(float(self.IBG[IFREQ]) * L["WBG"] / FREQ) if (II == 1 and len(self.IBG) == NFREQ) else np.float32(0.0)
+                    e.sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, FF, PSPOS=U.PSPOS[:max(U.NO_PS, 1), :3], PS=PS, XPS=self.XPS,
+                             GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
+                self.timers["Tkernel"] += time.time() - t0
+                self.packets += L["PACKETS"]
+            t0 = time.time()
+            e.batch_end()
+            e.sync()
+            if self.comm and not owned:
+                self.comm.all_reduce_tally(e, 1)          # one all-reduce of the per-cell buffer per frequency
+            self.timers["Tkernel"] += time.time() - t0
+            t0 = time.time()
+            FABSORBED[:, IFREQ] += e.read_tally(1)[0::self.absthin]
+            self.timers["Tpull"] += time.time() - t0
+            if self.verbose and self.rank == 0:
+                print("  FREQ %3d/%3d  %10.3e   TW %10.3e" % (IFREQ + 1, NFREQ, FREQ, FF))
+        if self.comm:
+            self.comm.all_reduce_tally(e, 0)              # TABS: integrated over frequency and source blocks on the device
+        t0 = time.time()
+        CTABS += e.read_tally(0)
+        self.timers["Tpull"] += time.time() - t0
+        self.log("******  CONSTANT   all source blocks   CTABS -> %12.4e" % float(np.mean(CTABS)))
         return CTABS, FABSORBED
 
     # ---------------------------------------------------------------------------------

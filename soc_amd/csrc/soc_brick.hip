@@ -1655,7 +1655,10 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             if ((long long)(K.S[l].OPT - K.S[0].OPT) != l * A.opt_stride) return hipErrorInvalidValue;
     }
     // launches with the INT tally: brick queues per launch, so that a workgroup's LDS tallies belong to one launch
-    A.NBQ = (V.wint && K.n > 1) ? A.NB * K.n : A.NB;
+    // (launches that tally into ONE INT array -- the source blocks of one frequency, soc_batch_begin_shared_int -- share the queues)
+    bool own_int = false;
+    for (int l = 1; l < K.n; l++) own_int = own_int || (K.S[l].INT != K.S[0].INT);
+    A.NBQ = (V.wint && K.n > 1 && own_int) ? A.NB * K.n : A.NB;
     if ((long long)A.NB * K.n > (1 << 20)) return hipErrorNotSupported;
     const int NQ = A.NBQ + A.EQ * K.n + 1;
     // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in

@@ -86,6 +86,7 @@ struct soc_ctx {
     int    emit_slot_last = -1;
     int    int_slots_done = 0;                    // launches of the last executed sweep whose INT can be read
     bool   batch_keep_int = false;                // soc_batch_begin_int: deferred launches keep their own INT tally
+    bool   batch_share_int = false;               // soc_batch_begin_shared_int: deferred launches tally into the handle's INT together
     size_t emitslot_cells = 0;
     size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
@@ -167,7 +168,7 @@ static int flush_pending(soc_ctx *c)
     SocVariant V;
     V.octree = c->G.LEVELS > 1;  V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
     V.abu = todo[0].OPT != nullptr;                          // what makes a launch deferrable (see soc_sim_pb)
-    V.wint = (c->batch_keep_int && c->with_int) ? 1 : 0;
+    V.wint = ((c->batch_keep_int || c->batch_share_int) && c->with_int) ? 1 : 0;
     HIPCHK(c, hipSetDevice(c->device));
     if (V.octree && todo.size() == 1 && c->exec_mode < 0 && !(lt_capable(c, V.abu != 0) && todo[0].gid_count >= SOC_LT_LONE_LAUNCH)) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
@@ -801,12 +802,12 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
-                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, with_int 2, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOURCE, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_pb: a batch with the INT tally holds launches of one kind");
@@ -845,6 +846,7 @@ int soc_batch_begin(soc_ctx *c, int max_launches)
     FLUSH(c);
     c->batching = true;
     c->batch_keep_int = false;
+    c->batch_share_int = false;
     c->int_slots_done = 0;
     // default: as many as one sweep takes (the packets in flight are limited separately, see flush_pending)
     c->batch_max = max_launches ? max_launches : SOC_MAXLAUNCH;
@@ -856,6 +858,14 @@ int soc_batch_begin_int(soc_ctx *c, int max_launches)
     int r = soc_batch_begin(c, max_launches);
     if (r) return r;
     c->batch_keep_int = true;
+    return SOC_OK;
+}
+
+int soc_batch_begin_shared_int(soc_ctx *c, int max_launches)
+{
+    int r = soc_batch_begin(c, max_launches);
+    if (r) return r;
+    c->batch_share_int = true;
     return SOC_OK;
 }
 
@@ -1041,10 +1051,10 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2;
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
-                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, with_int 2, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_hp: a batch with the INT tally holds launches of one kind");
@@ -1101,10 +1111,10 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
-                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
+                                   && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, with_int 2, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_cl: a batch with the INT tally holds launches of one kind");

@@ -50,6 +50,7 @@ API = {
     "soc_batch_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_batch_end": (C.c_int, [C.c_void_p]),
     "soc_batch_begin_int": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_batch_begin_shared_int": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_batch_read_int": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_long]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
@@ -218,6 +219,11 @@ class Engine:
         """like batch_begin, for launches that keep the per-frequency INT tally: each deferred launch gets its own;
         read them with batch_read_int(k) after batch_end"""
         self._chk(self.lib.soc_batch_begin_int(self.h, int(max_launches)))
+
+    def batch_begin_shared_int(self, max_launches=0):
+        """Launches until batch_end() that keep the INT tally are deferred too and tally into the handle's INT buffer together:
+        the source blocks of one frequency (zero(1) before, read_tally(1) after)."""
+        self._chk(self.lib.soc_batch_begin_shared_int(self.h, int(max_launches)))
 
     def batch_read_int(self, k):
         out = np.zeros(self.CELLS, np.float32)

@@ -121,6 +121,9 @@ class OracleEngine:
     def batch_begin(self, max_launches=0):
         self._int_batch = None
 
+    def batch_begin_shared_int(self, max_launches=0):
+        self._int_batch = None                     # the launches tally into the shared INT array, as immediate ones do
+
     def batch_begin_int(self, max_launches=0):
         self._int_batch = []
         self._int_max = max_launches or 16

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--global0", type=int, default=4194304)
     ap.add_argument("--freq", type=int, default=30)
     ap.add_argument("--fstride", type=int, default=1, help="frequency of launch k: freq + k * fstride (mod 50)")
-    ap.add_argument("--int", dest="with_int", type=int, default=0, help="1: launches keep the per-frequency INT tally and run one at a time (read after each)")
+    ap.add_argument("--int", dest="with_int", type=int, default=0, help="1: launches keep the per-frequency INT tally and run one at a time (read after each); 2: the same in batches of 16 (soc_batch_begin_int: brick queues per launch, every launch its own INT tally, read after the batch)")
     ap.add_argument("tunes", nargs="*")
     a = ap.parse_args()
     t0 = time.time()
@@ -50,7 +50,7 @@ def main():
     buf = (C.c_ulonglong * 24)()
     eng = Engine(0)
     eng.set_cloud(cloud)
-    eng.set_features(a.with_int, 0, 0)
+    eng.set_features(1 if a.with_int else 0, 0, 0)
     eng.set_emission(work["step"](1)["EMIT"], None)
     for ts in (a.tunes or ["{}"]):
         tune = json.loads(ts)
@@ -64,9 +64,12 @@ def main():
             eng.timer_start()
             if not a.with_int:
                 eng.batch_begin(min(128, a.launches))
+            nint = 0
             for k in range(a.launches):
-                if a.with_int:
+                if a.with_int == 1:
                     eng.zero(1)
+                if a.with_int == 2 and nint == 0:
+                    eng.batch_begin_int(16)
                 kind = a.kind if a.kind != "mix" else ("ps", "cl")[k % 2]      # mix: point-source and diffuse launches share the sweep
                 f = (a.freq + (k // 2 if a.kind == "mix" else k) * a.fstride) % 50
                 s = work["step_for"](f, "ps" if kind == "ps" else "cl")
@@ -83,8 +86,15 @@ def main():
                 else:
                     Lb = launch.bg_launch(int(a.packets), cloud.AREA)
                     eng.sim_pb(1, Lb["PACKETS"], Lb["BATCH"], seed, 1e-3, s["TW"], GLOBAL=Lb["GLOBAL"])
-                if a.with_int:
+                if a.with_int == 1:
                     eng.read_tally(1)
+                if a.with_int == 2:
+                    nint += 1
+                    if nint == 16 or k == a.launches - 1:
+                        eng.batch_end()
+                        for q in range(nint):
+                            eng.batch_read_int(q)
+                        nint = 0
             if not a.with_int:
                 eng.batch_end()
             ms = eng.timer_stop()
