@@ -203,6 +203,9 @@ def main():
                          "every rank a contiguous share of the launch sequence (whole launches + a work-item range at either end); "
                          "weak = replicas with per-rank seeds")
     ap.add_argument("--separate-kinds", action="store_true", help="point-source and diffuse launches in sweeps of their own (as in round 2)")
+    ap.add_argument("--first-step", type=int, default=-1,
+                    help="index of the first timed step (default: the number of warm-up steps, i.e. the steps follow the warm-up); "
+                         "tools/profile_bench.sh profiles the driver's timed steps without running its warm-up: --warmup 0 --first-step 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-shape", action="store_true")
     ap.add_argument("--no-per-kind", action="store_true", help="skip the per-kind sweeps after the timed region")
@@ -345,7 +348,8 @@ def main():
     eng.stats(reset=True)
     fence()
     t0 = time.perf_counter()
-    kernel_ms = run_steps(args.warmup, args.steps, args.in_flight)
+    first_step = args.first_step if args.first_step >= 0 else args.warmup
+    kernel_ms = run_steps(first_step, args.steps, args.in_flight)
     fence()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
@@ -355,7 +359,7 @@ def main():
     packets_rank = st["packets"]
     events_rank = st["tally_events"]
     scat_rank = st["scatterings"]
-    freqs = sorted({int(work["step"](i)["IFREQ"]) for i in range(args.warmup, args.warmup + args.steps)})
+    freqs = sorted({int(work["step"](i)["IFREQ"]) for i in range(first_step, first_step + args.steps)})
     # per-kind rates: the kinds share the timed sweep, so each kind's launches of the first 8 timed steps are run again in a
     # sweep of their own (outside the timed region; fewer launches per sweep than the timed one)
     per_kind = None
@@ -363,7 +367,7 @@ def main():
         per_kind = {}
         for kd in work["kinds"]:
             eng.stats(reset=True)
-            ms = run_steps(args.warmup, min(args.steps, 8), 0, kinds=(kd,))
+            ms = run_steps(first_step, min(args.steps, 8), 0, kinds=(kd,))
             eng.sync()
             sk = eng.stats()
             if sk["packets"]:

@@ -954,20 +954,42 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             w.ind = -1;
             if (!create) w.ind = soc_cell_index(G, w.level, ccx, ccy, ccz, w.dens);      // the cell the packet is in (or stepped from)
         }
+        // Reflecting faces (the `mirror` key; Mirror, kernel_ASOC_aux.c:1054-1083, called where a step has taken the packet out of the
+        // model: kernel_ASOC.c:686-688, :1064, :1540).  Brick-local hierarchies: such a packet arrives in its launch's creation
+        // queue with its old cell and the advanced position; the root-grid position Index() leaves behind (:238-241) follows
+        // from them, Mirror works on that.  A packet that comes back inside goes on in the brick of its new cell.
+        bool mirrored = false;
+        if (LT && create && (S.MIRROR > 0)) {
+            const bool started = CL ? (((int)cl_cell >= 0) && (III > 0)) : (III > 0);      // (a work item that has sent no packet yet holds none)
+            if (started) {
+                if (w.level > 0) {
+                    const float sc = soc_lt_pow2(-w.level);
+                    w.px = SOC_FMA(w.px, sc, (float)(ccx & ~1) * sc);  w.py = SOC_FMA(w.py, sc, (float)(ccy & ~1) * sc);  w.pz = SOC_FMA(w.pz, sc, (float)(ccz & ~1) * sc);
+                }
+                soc_mirror<true>(G, sOFF, S.MIRROR, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
+                mirrored = (w.ind >= 0);
+            }
+        }
         if (LT && (evk == 2)) {
             // slow step: Index() itself, in double, for a step that exact geometry does not decide (soc_ltree.h).  The
             // packet holds its old cell and the advanced position; tallies of the step are done.
             const int ind0 = w.ind, level0 = w.level;
             soc_index<true, double>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+            if (!CL && (w.ind >= 0) && (w.level == level0) && (w.ind == ind0)) {   // failed step: nudge (SimRAM_PB / HP only), before Mirror as in the step
+                w.px += SOC_PEPS * w.ux;  w.py += SOC_PEPS * w.uy;  w.pz += SOC_PEPS * w.uz;
+            }
+            if ((w.ind < 0) && (S.MIRROR > 0)) soc_mirror<true>(G, sOFF, S.MIRROR, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
             if (w.ind < 0) {
                 create = true;                                                  // left the model: the work item's next packet
             } else {
-                if (!CL && (w.level == level0) && (w.ind == ind0)) {            // failed step: nudge (SimRAM_PB / HP only)
-                    w.px += SOC_PEPS * w.ux;  w.py += SOC_PEPS * w.uy;  w.pz += SOC_PEPS * w.uz;
-                }
                 soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);
                 key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
             }
+        } else
+        if (mirrored) {
+            create = false;
+            soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);
+            key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
         } else
         if (!create) {
             // scattering block (kernel_ASOC.c:700-804); the packet is at the start of the step
@@ -1729,6 +1751,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         all_bg = all_bg && (K.S[l].SOURCE == 1);
     }
     if (kind != 4 && all_bg && !tune.nolean) kind = 3;  // background packets only: the lean kernel
+    if (!A.LT) for (int l = 0; l < K.n; l++) if (K.S[l].MIRROR) return hipErrorNotSupported;      // reflecting faces: the event workgroups of brick-local hierarchies only
     const int slices = (A.P + A.T - 1) / A.T;
     const int nev = ((int)((live + A.P - 1) / A.P) + (A.EQ + 1) * K.n) * slices;
 

@@ -799,7 +799,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
@@ -1049,7 +1049,7 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     // the brick sweep as for soc_sim_pb: the walk is SimRAM_PB's, only the creation of a packet differs
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2;
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
@@ -1108,7 +1108,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && c->mirror == 0 && c->with_int != 2
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));

@@ -89,9 +89,9 @@ def test_brick_sweep_octree_double_index(engine, oracle_soc):
     engine.set_exec(-1, 4)
 
 
-def test_brick_sweep_refuses_mirror(engine):
-    """reflecting faces are handled by the direct kernel only: forcing the brick sweep is an error,
-    automatic mode falls back"""
+def test_brick_sweep_refuses_mirror_off_brick_local_hierarchies(engine):
+    """reflecting faces in the sweep: the event workgroups of brick-local hierarchies handle them (tests/test_gpu_ltree.py); on
+    Cartesian grids and hierarchies walked in global memory forcing the brick sweep is an error, automatic mode falls back"""
     from soc_amd.lib import SocError
     ref, kind, mk = cases.CASES["bg_c8_mirror"]
     with pytest.raises(SocError):

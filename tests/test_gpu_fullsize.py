@@ -195,6 +195,40 @@ def test_c3_point_source_and_diffuse_launches_direct_equals_sweep(step, first, c
     engine.set_exec(-1, 4)
 
 
+def test_c3_source_cell_against_fp64_partial_sums(engine, c3):
+    """Which execution mode is right where they differ by percents: the cell of the point source, into which every packet of a
+    launch makes its first deposit (1.7e7 fp32 additions into ONE number in the direct kernel).  Reference: the same launch in 128
+    work-item ranges through the direct kernel, the tally read after each range (<= 1.3e5 additions into a zeroed cell: accurate to
+    ~1e-6) and added up on the host in fp64.  The brick sweep adds workgroup partial sums (<= 16384 packets each, in LDS) and must
+    agree with that reference to 1e-5 in the hot cells; the one-launch direct kernel is the one that is off (a float cannot take
+    1.7e7 increments of its own 2^-24: they fall below half an ulp)."""
+    cloud = c3["cloud"]
+    engine.set_cloud(cloud)
+    engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_opt(None)
+    step, G, batch = 60, 4194304, 4
+    out = {}
+    for mode in (0, 1):
+        engine.set_exec(mode, 4)
+        engine.zero(0)
+        _c3_launch(engine, c3, step, 0, G, batch)
+        out[mode] = np.asarray(engine.read_tally(0), np.float64)
+    hot = np.argsort(out[1])[-8:]                                  # the source cell and the cells around it
+    ref = np.zeros(hot.size, np.float64)
+    engine.set_exec(0, 4)
+    nr = 128
+    for r in range(nr):
+        engine.zero(0)
+        _c3_launch(engine, c3, step, r * (G // nr), G // nr, batch)
+        ref += np.asarray(engine.read_tally(0), np.float64)[hot]
+    err_sweep = np.abs(out[1][hot] - ref) / ref
+    err_direct = np.abs(out[0][hot] - ref) / ref
+    assert err_sweep.max() < 1e-5, (err_sweep, err_direct)
+    assert err_direct.max() > 10 * err_sweep.max()                 # the direct kernel's single accumulator is where the percents come from
+    engine.set_exec(-1, 4)
+
+
 def test_c3_lone_launches_with_int_use_the_sweep_in_automatic_mode(engine, c3):
     """automatic mode: on this hierarchy a lone launch of >= 1e6 work items goes through the brick sweep, with the INT tally"""
     cloud = c3["cloud"]

@@ -164,3 +164,23 @@ def test_deferred_launches_with_and_without_int(engine, oracle_soc):
             for k, I in enumerate(ints):
                 assert_tally_close(e.batch_read_int(k), I, rtol=1e-5)
     engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("mask,kind", [(25, 0), (6, 0), (63, 1)], ids=["xYZ_bg", "Xy_bg", "all_faces_cl"])
+def test_reflecting_faces_in_the_sweep(mask, kind, engine, oracle_soc):
+    """`mirror`: a packet whose step took it out of the model arrives in its launch's creation queue; the event workgroups
+    reflect it there (Mirror, kernel_ASOC_aux.c:1054-1083, on the root-grid position Index() leaves behind) and send it on to the
+    brick of the cell it re-enters.  Same trajectories as the oracle: event counts equal."""
+    cl = cloud104()
+    if kind == 0:
+        job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=3, SEED=0.4177, MIRROR=mask)
+        g0, g1 = 200000, 204000
+    else:
+        emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 0).astype(np.float32)
+        job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=2, BATCH=1, SEED=0.913, GLOBAL=1 << 20, EMIT=emit, MIRROR=mask)
+        g0, g1 = 300000, 303000
+    T, _, n = oracle_soc.sim(job, kind, gid0=g0, gid1=g1, nthreads=8)
+    Tg, _, st = _sweep(engine, job, kind, gid_first=g0, gid_count=g1 - g0)
+    assert st["tally_events"] == n, "trajectories diverged from the oracle"
+    assert_tally_close(Tg, T, rtol=1e-5)
+    engine.set_exec(-1, 4)

@@ -15,7 +15,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--workload $WORK --steps $STEPS --warmup 0 --no-cpu-baseline --no-reference-shape $@"
+# the driver runs --steps 20 --warmup 5: its timed steps are 5 .. 24; profiled here without the warm-up launches
+ARGS="--workload $WORK --steps $STEPS --warmup 0 --first-step 5 --no-cpu-baseline --no-reference-shape --no-per-kind $@"
 timeout -k 10 1000 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOT/bench.py $ARGS > $OUT/bench_stats.log 2>&1
 timeout -k 10 1000 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 timeout -k 10 1000 rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.log 2>&1

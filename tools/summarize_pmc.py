@@ -35,7 +35,7 @@ def main():
     atom = b.get('TCC_EA0_ATOMIC_sum', 0.0) / steps
     with open(os.path.join(REPO, 'profiles', tag + '_pmc_summary.csv'), 'w') as fp:
         fp.write('# rocprofv3 --pmc passes (separate runs: FETCH_SIZE | WRITE_SIZE TCC_EA0_ATOMIC_sum), '
-                 'python bench.py --workload %s --steps %d --warmup 0 --no-cpu-baseline\n' % (workload, steps))
+                 'python bench.py --workload %s --steps %d --warmup 0 --first-step 5 --no-cpu-baseline --no-reference-shape --no-per-kind\n' % (workload, steps))
         fp.write('# sums over all soc_* dispatches of the run / %d steps; dispatch counts: %s\n' % (steps, json.dumps(nka)))
         fp.write('counter,per_step\n')
         fp.write('FETCH_SIZE_KiB,%.6g\nWRITE_SIZE_KiB,%.6g\nTCC_EA0_ATOMIC_sum,%.6g\n' % (fetch / 1024, write / 1024, atom))
