@@ -235,6 +235,9 @@ int soc_read_par(soc_ctx *ctx, int32_t *out, int64_t n);
 /* counters accumulated by the kernels since the last reset:
  * out[0] tally events, out[1] packets created, out[2] scattering events */
 int soc_stats(soc_ctx *ctx, uint64_t out[3], int reset);
+/* cell steps of all rays (look-ahead, packet, peel-off) of the scattered-light launches that ran as sweeps of rays on brick-local
+ * hierarchies, as of the last soc_stats call (what the read-only roofline of SURVEY 8(d) counts: 4 B per step); -1: no handle */
+int64_t soc_sca_ray_steps(soc_ctx *ctx);
 
 /* number of brick-sweep passes of the last launch (0 if it ran in direct mode) */
 int soc_last_passes(soc_ctx *ctx);

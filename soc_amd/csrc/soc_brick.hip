@@ -138,6 +138,9 @@ struct SocBrickArgs {
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
     int kexp;                    // k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_move
+    // scattered-light images on brick-local hierarchies (soc_sca_events): the view, and the parked packet of every work item
+    SocPk2 *park;
+    SocSca sca;
 };
 
 #include "soc_octbricks.h"     // SOC_SLOT_BITS, SocOctBuilder
@@ -264,6 +267,7 @@ __global__ void soc_brick2_init(const SocSimPack *Kp, SocBrickArgs A, uint32_t c
         p.D = make_uint4(r.x, r.c, 0u, cell0);
         pk[t] = p;
         idq0[t] = t;
+        if (A.park) { p.C = p.A;  p.D = make_uint4(0u, 0u, 0u, 0u);  A.park[t] = p; }      // no ray yet (SOC_RM_NONE)
     }
     // every launch starts in its own creation queue NB + 2l; the first A.target work items at once
     const uint32_t active = min(count, (uint32_t)A.target);
@@ -616,7 +620,10 @@ __device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int c
     return ind;
 }
 
-template <bool WINT>
+// RAY: the read-only rays of the scattered-light kernels (soc_sca_events below): no tallies (the LDS holds the cells only), the optical
+// depth grows with the factor the record carries in place of the photons (kappa_sca for the look-ahead and the packet, kappa_abs + kappa_sca
+// for a peel-off ray: kernel_ASOC_sca.c:895-897, :975-990, :1035-1040), no nudge after a failed step (GetStep alone moves these rays).
+template <bool WINT, bool RAY = false>
 __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
     if (bid >= *A.ndesc) return;
@@ -630,8 +637,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
-    float *sI   = sT + BV;                                 // [BV] INT (WINT)
-    float *sD   = sI + (WINT ? BV : 0);                    // [BV] density | link of every cell of the brick
+    float *sI   = sT + (RAY ? 0 : BV);                     // [BV] INT (WINT)
+    float *sD   = sI + (WINT ? BV : 0);                    // [BV] density | link of every cell of the brick (RAY: nothing else)
     const int NQ = A.NBQ + A.EQ * A.nl + 1;
     int   *sH   = (int *)(sD + BV);                        // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));   // [0] next packet, [1] tally events
@@ -651,7 +658,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
     if (!parked) {
         const float *src = A.btree + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
+        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  if (!RAY) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
     }
     soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
@@ -751,7 +758,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         lq = n_lq;                                                // the launch of the work item
                         evq = A.NBQ + A.EQ * n_lq;
                         level = (int)(dz >> 29);
-                        kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = (__float_as_int(l4.w) & 1) != 0;
+                        kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = RAY || ((__float_as_int(l4.w) & 1) != 0);
                         nvisit = 0;
                         mode = SOC_BM_STEP;
                         slot = -1;  obase = -1;
@@ -804,7 +811,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 pz += ds * uz;
                 ds = ds * soc_lt_pow2(-level);                                    // ldexp(ds, -level)
                 tauA = ds * dens * kabs;
-                dtau = ds * dens * ksca;
+                dtau = ds * dens * (RAY ? photons : ksca);
                 if (free_path < (tau + dtau)) {
                     px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
                     mode = SOC_BM_SWAP;  key = evq + 1;                           // -> scattering queue of its launch
@@ -825,6 +832,9 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 }
             }
             // ---- the tally of the step (the LDS read above is in flight meanwhile) ----
+            if (RAY) {
+                if (move && (what == SOC_LTM_STEP)) { tau += dtau;  n_tally++; }
+            } else
             if (move && (what == SOC_LTM_STEP)) {
                 const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                 const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
@@ -864,7 +874,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     SOC_PROF_FLUSH;
     atomicAdd(&sCtl[1], (int)n_tally);
     __syncthreads();
-    if (!parked) {
+    if (!parked && !RAY) {
         const int *cells = A.bcell + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
             const float v = sT[i];
@@ -887,7 +897,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     soc_qh_bases(sH, A.HS, NQ, A.hist);
     __syncthreads();
     for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, A.posq[D.start + j]);
-    if (threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
+    if (!RAY && threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
+    if (RAY && threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 3, (unsigned long long)(unsigned int)sCtl[1]);      // cell steps of all rays
 }
 
 
@@ -1212,6 +1223,382 @@ __global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const S
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Scattered-light images (kernel_ASOC_sca.c) on brick-local hierarchies.
+//
+// A work item of the reference alternates between read-only walks -- the look-ahead of forced first scattering (:888-906), the
+// packet's free walk (:967-990), one walk to the surface per observer at every scattering (:1019-1047) -- and short blocks in
+// between.  Here every such walk is a RAY: a record of the same 64 bytes as an absorption packet, queued per brick and stepped by
+// soc_lbrick_walk<false, true> on the brick's cells in LDS (4 B per cell: no tallies).  What a ray does not need while it walks
+// stays behind in a second record per work item that never moves (`park`): the packet's position and direction at the scattering
+// (or at its creation), its photons, its cell, the observer the current ray looks at.  The blocks in between run here, one lane
+// per ray that has ended: it left the model (queue 0 of its launch), the packet's free path ends in the cell (queue 1), or the
+// step was one that exact geometry does not decide (queue 2, soc_ltree.h).  The chain of blocks a lane runs through is the one
+// of soc_sca_kernel's service arm (soc_sca.hip), whose order of operations and of RNG draws is the reference's; it ends when the
+// lane has a ray to walk again or the work item is finished.
+//   ray record:  A = position, kappa factor | B = direction, free path (+inf for look-ahead and peel-off rays) | C = optical
+//                depth so far, cell coordinates | D = RNG state, III | scatterings << 24 | level << 29, SimRAM_CL: emitting cell
+//   park record: A = packet position, photons | B = packet direction | C = its cell coordinates, level | D = kind of the current
+//                ray (SOC_RM_*), observer index
+// Not on this path (the caller falls back to soc_sca_kernel): Healpix images, SimRAM_HP, per-cell opacities, WITH_MSF.
+// ---------------------------------------------------------------------------------------
+enum { SOC_RM_NONE = 0, SOC_RM_FFS = 1, SOC_RM_MAIN = 2, SOC_RM_PEEL = 3 };
+enum { SOC_RE_SCAT = 4, SOC_RE_PEEL_END = 5, SOC_RE_FFS_END = 6, SOC_RE_CREATE = 7, SOC_RE_DONE = 8 };     // blocks between rays
+#define SOC_SCA_MAX_SCATTERINGS 30                                    /* kernel_ASOC_sca.c:5 */
+
+struct SocRayLane {                                                   // what soc_pb_create fills in
+    float px, py, pz, ux, uy, uz, photons, dens;
+    int   level, ind;
+    soc_rng_t rng;
+};
+
+template <int KIND>
+__device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
+{
+    constexpr bool CLW = (KIND == SOC_SCA_CL);
+    const SocSca &V = A.sca;
+    const int di = A.ndesc[2] + ebid;
+    if (di >= *A.ndesc) return;
+    SocDesc D = A.desc[di];
+    if (D.brick < A.NBQ) return;
+    {
+        const int first = (int)(slice * blockDim.x);
+        if (first >= D.count) return;
+        D.start += first;
+        D.count = min((int)blockDim.x, D.count - first);
+    }
+    SocPk2 *pk = A.pk, *park = A.park;
+    const int NQ = A.NBQ + A.EQ * K.n + 1;
+    const int lq = (D.brick - A.NBQ) / A.EQ;
+    const int evk = (D.brick - A.NBQ) % A.EQ;                 // 0 left the model (or not started), 1 scattering, 2 slow step
+    const SocSim &S = K.S[lq];
+    const int qbase = 0;                                      // rays of all launches share the brick queues (no tallies in LDS)
+    extern __shared__ float lds[];
+    int   *sH   = (int *)lds;
+    int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);
+    int   *sOFF = sCtl + 4;
+    soc_qh_init(sH, A.HS, NQ);
+    if (threadIdx.x < 4) sCtl[threadIdx.x] = 0;
+    if (threadIdx.x < SOC_MAXL) sOFF[threadIdx.x] = G.OFF[threadIdx.x];
+    __syncthreads();
+    unsigned int n_add = 0, n_pkt = 0, n_scat = 0;
+    uint32_t mypack = 0;
+    const float kabs = S.ABS, ksca = S.SCA;
+    const int   NDIRS = V.NDIR;
+
+    for (int j = threadIdx.x; j < D.count; j += blockDim.x) {
+        const uint32_t wid = A.idq[D.start + j];
+        const SocPk2 p = pk[wid];
+        const SocPk2 q = park[wid];
+        SocRayLane w;
+        w.px = p.A.x;  w.py = p.A.y;  w.pz = p.A.z;
+        w.ux = p.B.x;  w.uy = p.B.y;  w.uz = p.B.z;
+        float free_path = p.B.w, tau = p.C.x;
+        int   ccx = __float_as_int(p.C.y), ccy = __float_as_int(p.C.z), ccz = __float_as_int(p.C.w) & ((1 << SOC_LQ_SHIFT) - 1);
+        w.level = (int)(p.D.z >> 29);
+        int   scat = (int)((p.D.z >> 24) & 31u), III = (int)(p.D.z & 0xffffffu);
+        w.rng.x = p.D.x;  w.rng.c = p.D.y;
+        uint32_t cl_cell = p.D.w & ~SOC_LT_ARRIVE;
+        if ((evk == 0) && (q.D.x == SOC_RM_NONE)) cl_cell = p.D.w;       // (a work item that has not started holds a negative cell)
+        float mx = q.A.x, my = q.A.y, mz = q.A.z;
+        w.photons = q.A.w;
+        float dx_ = q.B.x, dy_ = q.B.y, dz_ = q.B.z;
+        int   mcx = __float_as_int(q.C.x), mcy = __float_as_int(q.C.y), mcz = __float_as_int(q.C.z), mlevel = __float_as_int(q.C.w);
+        int   rmode = (int)q.D.x, idir = (int)q.D.y;
+        w.ind = -1;  w.dens = 0.0f;
+        int   lvl_post = 0, mode;
+        bool  cc_ok = true;                                   // (ccx, ccy, ccz) are the coordinates of cell (w.level, w.ind)
+
+        if (rmode == SOC_RM_NONE) {
+            mode = SOC_RE_CREATE;
+        } else if (evk == 1) {
+            // the packet's free path ends in this step (:1000-1015 PB, :1295-1310 CL, :1789-1805 PS); the record holds the start of the step.
+            // The offset of the scattering is scaled with the level AFTER the step: GetStep once more, on the global hierarchy.
+            w.ind = soc_cell_index(G, w.level, ccx, ccy, ccz, w.dens);
+            float tx = w.px, ty = w.py, tz = w.pz, td = w.dens;
+            int   tl = w.level, ti = w.ind;
+            (void)soc_getstep_rcp<true, true>(G, sOFF, tx, ty, tz, w.ux, w.uy, w.uz, 1.0f / w.ux, 1.0f / w.uy, 1.0f / w.uz, tl, ti, td);
+            lvl_post = tl;
+            mode = SOC_RE_SCAT;
+        } else {
+            if (evk == 2) {
+                // slow step: Index() itself, in double; the record holds the old cell and the advanced position, the optical depth of the step is added
+                w.ind = soc_cell_index(G, w.level, ccx, ccy, ccz, w.dens);
+                soc_index<true, double>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+                cc_ok = false;
+            } else {
+                // the ray has left the model: the root-grid position Index() leaves behind (kernel_ASOC_aux.c:238-241)
+                if (w.level > 0) {
+                    const float sc = soc_lt_pow2(-w.level);
+                    w.px = SOC_FMA(w.px, sc, (float)(ccx & ~1) * sc);  w.py = SOC_FMA(w.py, sc, (float)(ccy & ~1) * sc);  w.pz = SOC_FMA(w.pz, sc, (float)(ccz & ~1) * sc);
+                }
+                w.level = 0;  w.ind = -1;
+            }
+            if (w.ind >= 0) {
+                mode = rmode;                                 // the slow step stayed inside: the ray goes on
+            } else if (rmode == SOC_RM_FFS) {
+                mode = SOC_RE_FFS_END;
+            } else if (rmode == SOC_RM_PEEL) {
+                mode = SOC_RE_PEEL_END;
+            } else {
+                if (S.MIRROR > 0) {                           // kernel_ASOC_sca.c:983, :1283, :1781
+                    soc_mirror<true>(G, sOFF, S.MIRROR, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.dens);
+                    cc_ok = false;
+                }
+                mode = (w.ind >= 0) ? SOC_RM_MAIN : SOC_RE_CREATE;
+            }
+        }
+
+        const int id = (int)(S.gid0 + (wid - K.first[lq]));
+        SocSurfElem E;
+        if (KIND != SOC_SCA_CL) E = soc_surface_element(G, S, id);
+        while (mode > SOC_RM_PEEL && mode != SOC_RE_DONE) {
+            // ---- start of a scattering event
+            if (mode == SOC_RE_SCAT) {
+                scat++;
+                n_scat++;
+                float dx = (free_path - tau) / (ksca * w.dens);
+                dx = soc_scale_up(dx, lvl_post);
+                w.px = w.px + dx * w.ux;
+                w.py = w.py + dx * w.uy;
+                w.pz = w.pz + dx * w.uz;
+                w.photons *= soc_expf(-free_path * kabs / ksca);
+                mx = w.px;  my = w.py;  mz = w.pz;  dx_ = w.ux;  dy_ = w.uy;  dz_ = w.uz;
+                mlevel = w.level;  mcx = ccx;  mcy = ccy;  mcz = ccz;
+                idir = 0;
+                if (NDIRS > 0) {
+                    const float4 o = V.ODIRS[0];
+                    w.ux = o.x;  w.uy = o.y;  w.uz = o.z;
+                    tau = 0.0f;
+                    mode = SOC_RM_PEEL;
+                } else {
+                    mode = SOC_RE_PEEL_END;                   // no observers: straight to the deflection
+                    idir = -1;
+                }
+            }
+            // ---- a peel-off ray has reached the surface: image contribution, next observer or deflection
+            if (mode == SOC_RE_PEEL_END) {
+                if (idir >= 0) {
+                    const float taup = tau;
+                    const float CL = CLW ? 0.9999f : 0.999f;
+                    const float cos_theta = soc_clampf(dx_ * w.ux + dy_ * w.uy + dz_ * w.uz, -CL, +CL);
+                    float delta;
+                    if (CLW) {
+                        const float g = 0.65f;
+                        const float fraction = (1.0f / (4.0f * SOC_PI)) * (1.0f - g * g) / soc_pow15f(1.0f + g * g - 2.0f * g * cos_theta);
+                        delta = w.photons * fraction * ((taup > SOC_TAULIM) ? (1.0f - soc_expf(-taup)) : (taup * (1.0f - 0.5f * taup)));
+                    } else {
+                        int b = (int)(S.BINS * (1.0f + cos_theta) * 0.5f);
+                        b = b < 0 ? 0 : (b > S.BINS - 1 ? S.BINS - 1 : b);
+                        delta = w.photons * soc_expf(-taup) * V.DSC[b];
+                    }
+                    const float qx = w.px - V.CX, qy = w.py - V.CY, qz = w.pz - V.CZ;
+                    const float4 ra = V.ORA[idir], de = V.ODE[idir];
+                    int i = (int)((0.5f * V.NPIX_X - 0.00005f) + (qx * ra.x + qy * ra.y + qz * ra.z) / V.MAP_DX);
+                    int jj = (int)((0.5f * V.NPIX_Y - 0.00005f) + (qx * de.x + qy * de.y + qz * de.z) / V.MAP_DX);
+                    if ((i >= 0) && (jj >= 0) && (i < V.NPIX_X) && (jj < V.NPIX_Y)) {
+                        i += idir * V.NPIX_X * V.NPIX_Y + jj * V.NPIX_X;
+                        soc_tally(V.OUT, i, delta);
+                        n_add++;
+                    }
+                    idir++;
+                }
+                // back to the packet at the scattering position
+                w.px = mx;  w.py = my;  w.pz = mz;  w.level = mlevel;  ccx = mcx;  ccy = mcy;  ccz = mcz;  cc_ok = true;  w.ind = 0;
+                tau = 0.0f;
+                if ((idir >= 0) && (idir < NDIRS)) {
+                    const float4 o = V.ODIRS[idir];
+                    w.ux = o.x;  w.uy = o.y;  w.uz = o.z;
+                    mode = SOC_RM_PEEL;
+                } else {
+                    // new direction, new free path
+                    w.ux = dx_;  w.uy = dy_;  w.uz = dz_;
+                    soc_scatter(w.ux, w.uy, w.uz, S.CSC, S.BINS, &w.rng);
+                    free_path = -soc_logf(soc_rand(&w.rng));
+                    mode = (scat == SOC_SCA_MAX_SCATTERINGS) ? SOC_RE_CREATE : SOC_RM_MAIN;
+                }
+            }
+            // ---- the FFS look-ahead has left the cloud (:899-909 PB, :1249-1258 CL, :1733-1745 PS); tau = optical depth of scattering along the line of sight
+            if (mode == SOC_RE_FFS_END) {
+                w.px = mx;  w.py = my;  w.pz = mz;  w.level = mlevel;  ccx = mcx;  ccy = mcy;  ccz = mcz;  cc_ok = true;
+                bool inside = (rmode != SOC_RM_NONE);         // (a packet created outside the cloud comes here without a look-ahead)
+                bool alive = true;
+                if (tau < 1.0e-22f) {
+                    inside = false;
+                    if (CLW) alive = false;                   // no random number drawn
+                }
+                if (alive) {
+                    float W;
+                    if (KIND == SOC_SCA_PS) {
+                        W = -soc_expm1f(-tau);
+                        free_path = -soc_logf(1.0f - W * soc_rand(&w.rng));
+                    } else {
+                        W = 1.0f - soc_expf(-tau);
+                        free_path = -(float)soc_logd(1.0 - (double)(W * soc_rand(&w.rng)));
+                    }
+                    w.photons *= W;
+                }
+                tau  = 0.0f;
+                scat = 0;
+                w.ind = inside ? 0 : -1;
+                mode = inside ? SOC_RM_MAIN : SOC_RE_CREATE;
+            }
+            // ---- next packet of this work item
+            if (mode == SOC_RE_CREATE) {
+                bool have = false;
+                rmode = SOC_RM_NONE;
+                if (KIND == SOC_SCA_CL) {
+                    // :1158-1222; the work item's place is kept in the record: D.w = cell, III = packets sent from it
+                    int ICELL = (int)cl_cell, IRAY = III, batch = -1;
+                    float PWEI = 1.0f;
+                    if (ICELL >= 0) {
+                        if (S.USE_EMWEIGHT > 0) {
+                            PWEI  = S.EMWEI[ICELL];
+                            batch = (int)soc_floorf(PWEI);
+                            if (batch < 1) { batch = 1;  PWEI = (float)(1.0 / (double)(PWEI + 1.0e-30f)); }
+                            else           { PWEI = (float)(1.0 / (double)((float)batch + 1.0e-9f)); }
+                        } else {
+                            batch = S.BATCH;
+                            PWEI  = 1.0f / ((float)batch + 1.0e-9f);
+                        }
+                    }
+                    bool more = true;
+                    if (IRAY >= batch) {
+                        IRAY = 0;
+                        PWEI = 1.0f;
+                        long long IC = ICELL;
+                        while (true) {
+                            IC += S.GLOBAL;
+                            if (IC >= G.CELLS) { more = false; break; }
+                            if (S.USE_EMWEIGHT > 0) {
+                                PWEI = S.EMWEI[IC];
+                                if ((PWEI < 1e-10f) || (G.DENS[IC] <= 0.0f)) continue;
+                                batch = (int)soc_floorf(PWEI);
+                                if (batch < 1) { batch = 1;  PWEI = (float)(1.0 / (double)(PWEI + 1.0e-30f)); }
+                                else           { PWEI = (float)(1.0 / (double)((float)batch + 1.0e-9f)); }
+                            } else {
+                                batch = S.BATCH;
+                                PWEI  = 1.0f / ((float)batch + 1.0e-9f);
+                            }
+                            break;
+                        }
+                        ICELL = (int)IC;
+                    }
+                    if (!more) {
+                        mode = SOC_RE_DONE;
+                    } else {
+                        int ind = ICELL, level;
+                        IRAY += 1;
+                        for (level = 0; level < G.LEVELS - 1; level++) {
+                            if (ind < sOFF[level + 1] - sOFF[level]) break;
+                            ind -= sOFF[level + 1] - sOFF[level];
+                        }
+                        float X0, Y0, Z0;
+                        if (level == 0) {
+                            X0 = (float)(ind % G.NX);  Y0 = (float)((ind / G.NX) % G.NY);  Z0 = (float)(ind / (G.NX * G.NY));
+                        } else {
+                            const int sid = ind % 8;
+                            X0 = (float)(sid % 2);  Y0 = ((sid % 4) > 1) ? 1.0f : 0.0f;  Z0 = (float)(sid / 4);
+                        }
+                        w.level = level;  w.ind = ind;
+                        w.dens = G.DENS[sOFF[level] + ind];
+                        w.photons = S.EMIT[sOFF[level] + ind] * PWEI;
+                        w.px = X0 + soc_rand(&w.rng);
+                        w.py = Y0 + soc_rand(&w.rng);
+                        w.pz = Z0 + soc_rand(&w.rng);
+                        const float phi       = SOC_TWOPI * soc_rand(&w.rng);
+                        const float cos_theta = 0.999997f - 1.999995f * soc_rand(&w.rng);
+                        const float sin_theta = soc_sqrtf(1.0f - cos_theta * cos_theta);
+                        float sp, cp;
+                        soc_sincosf(phi, &sp, &cp);
+                        w.ux = sin_theta * cp;
+                        w.uy = sin_theta * sp;
+                        w.uz = cos_theta;
+                        have = true;
+                    }
+                    III = IRAY;
+                    cl_cell = (uint32_t)ICELL;
+                } else {
+                    if (III >= S.BATCH) {
+                        mode = SOC_RE_DONE;
+                    } else {
+                        soc_pb_create<true>(G, S, sOFF, E, III, w);
+                        III++;
+                        have = true;
+                    }
+                }
+                if (have) {
+                    n_pkt++;
+                    if (soc_fabsf(w.ux) < SOC_DEPS) w.ux = SOC_DEPS;
+                    if (soc_fabsf(w.uy) < SOC_DEPS) w.uy = SOC_DEPS;
+                    if (soc_fabsf(w.uz) < SOC_DEPS) w.uz = SOC_DEPS;
+                    soc_normalize(w.ux, w.uy, w.uz);
+                    tau  = 0.0f;
+                    scat = 0;
+                    cc_ok = false;
+                    if (w.ind >= 0) { soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);  cc_ok = true; }
+                    if (V.FFS > 0) {
+                        mx = w.px;  my = w.py;  mz = w.pz;  mlevel = w.level;  mcx = ccx;  mcy = ccy;  mcz = ccz;
+                        if (w.ind >= 0) { mode = SOC_RM_FFS;  rmode = SOC_RM_FFS; }
+                        else            { mode = SOC_RE_FFS_END; }                  // (rmode NONE: see there)
+                    } else {
+                        free_path = -soc_logf(soc_rand(&w.rng));
+                        mode = (w.ind >= 0) ? SOC_RM_MAIN : SOC_RE_CREATE;
+                    }
+                }
+            }
+        }
+
+        int key = NQ - 1;                                     // work item finished
+        SocPk2 o, r;
+        if (mode != SOC_RE_DONE) {
+            if (!cc_ok) soc_cell_coords(G, sOFF, w.level, w.ind, ccx, ccy, ccz);
+            key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
+            rmode = mode;
+        }
+        const float kk = (mode == SOC_RM_PEEL) ? (kabs + ksca) : ksca;
+        const float fp = (mode == SOC_RM_MAIN) ? free_path : __builtin_inff();
+        o.A = make_float4(w.px, w.py, w.pz, kk);
+        o.B = make_float4(w.ux, w.uy, w.uz, fp);
+        o.C = make_float4(tau, __int_as_float(ccx), __int_as_float(ccy), __int_as_float(ccz | (lq << SOC_LQ_SHIFT)));
+        o.D = make_uint4(w.rng.x, w.rng.c, (uint32_t)III | ((uint32_t)scat << 24) | ((uint32_t)w.level << 29), CLW ? cl_cell : 0u);
+        r.A = make_float4(mx, my, mz, w.photons);
+        r.B = make_float4(dx_, dy_, dz_, 0.0f);
+        r.C = make_float4(__int_as_float(mcx), __int_as_float(mcy), __int_as_float(mcz), __int_as_float(mlevel));
+        r.D = make_uint4((uint32_t)rmode, (uint32_t)idir, 0u, 0u);
+        pk[wid] = o;
+        park[wid] = r;
+        A.keyq[D.start + j] = (uint32_t)key;
+        mypack = soc_qh_rank(sH, A.HS, key, A.hist);
+    }
+    atomicAdd(&sCtl[0], (int)n_add);
+    atomicAdd(&sCtl[1], (int)n_pkt);
+    atomicAdd(&sCtl[2], (int)n_scat);
+    __syncthreads();
+    soc_qh_bases(sH, A.HS, NQ, A.hist);
+    __syncthreads();
+    if ((int)threadIdx.x < D.count) A.posq[D.start + threadIdx.x] = soc_qh_place(sH, A.HS, mypack);
+    if (threadIdx.x == 0 && S.stats) {
+        atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[0]);
+        atomicAdd(S.stats + 1, (unsigned long long)(unsigned int)sCtl[1]);
+        atomicAdd(S.stats + 2, (unsigned long long)(unsigned int)sCtl[2]);
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void soc_lray_pass(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
+{
+    const SocSimPack &K = *Kp;
+    const int b = (int)blockIdx.x;
+    if (b < nwalk) {
+        soc_lbrick_walk<false, true>(G, K, A, b);
+    } else {
+        const int e = b - nwalk;
+        soc_sca_events<KIND>(G, K, A, e / slices, e % slices);
+    }
+}
+
 // one workgroup: hist -> offsets of the next queues + descriptors of the next pass
 __global__ __launch_bounds__(1024) void soc_brick_scan(SocBrickArgs A)
 {
@@ -1346,7 +1733,8 @@ __global__ __launch_bounds__(SOC_BRICK_T) void soc_brick_scatter(SocBrickArgs A,
 struct SocBrickBuffers {
     size_t cap_items = 0;
     int    cap_nq = 0, cap_desc = 0;
-    SocPk2 *pk = nullptr;
+    size_t cap_park = 0;
+    SocPk2 *pk = nullptr, *park = nullptr;
     uint32_t *idq[2] = { nullptr, nullptr }, *keyq = nullptr, *posq = nullptr;
     SocSimPack *pack = nullptr;
     int *hist = nullptr, *off = nullptr, *ndesc = nullptr, *total = nullptr, *admit = nullptr;
@@ -1374,7 +1762,7 @@ void soc_brick_release(int device)
 {
     if (device < 0 || device >= 16) return;
     SocBrickBuffers &b = g_bb[device];
-    void *ptrs[] = { b.pack, b.pk, b.idq[0], b.idq[1], b.keyq, b.posq, b.hist, b.off, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
+    void *ptrs[] = { b.pack, b.pk, b.park, b.idq[0], b.idq[1], b.keyq, b.posq, b.hist, b.off, b.ndesc, b.total, b.admit, b.desc[0], b.desc[1] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     b = SocBrickBuffers();
     soc_oct_release(device);
@@ -1523,6 +1911,19 @@ static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_
 #undef SOC_LB_CASE
 }
 
+static hipError_t soc_lray_launch_pass(int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
+                                       const SocBrickArgs &A, int nwalk, int slices)
+{
+#define SOC_LR_CASE(KD) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)soc_lray_pass<KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                             soc_lray_pass<KD><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); } while (0)
+    if (kind == SOC_SCA_PB) SOC_LR_CASE(SOC_SCA_PB);
+    else if (kind == SOC_SCA_PS) SOC_LR_CASE(SOC_SCA_PS);
+    else if (kind == SOC_SCA_CL) SOC_LR_CASE(SOC_SCA_CL);
+    else return hipErrorNotSupported;
+#undef SOC_LR_CASE
+    return hipSuccess;
+}
+
 // LB: log2 of the brick edge (Cartesian grids; hierarchies use bricks of <= CAP leaves).  nlaunch launches
 // (same geometry, same tallies; no INT tally when nlaunch > 1) share one sweep: more
 // packets in flight per pass, and the passes in which one launch's last work items finish are filled by the
@@ -1563,9 +1964,11 @@ static void soc_brick_launch_pass(int vkey, int kind, int nblocks, int T, size_t
 }
 
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int nlaunch, const SocVariant &V, int LB,
-                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out)
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out, const SocSca *sca)
 {
     if (form_out) *form_out = 0;
+    // rays of the scattered-light kernels (soc_sca_events): flat images of SimRAM_PB / PS / CL with scalar opacities and one scattering function
+    if (sca && (sca->NDIR < 0 || sca->kind == SOC_SCA_HP || V.abu || V.wint || nlaunch != 1 || Sin[0].NDUST > 1 || Sin[0].BINS < 1)) return hipErrorNotSupported;
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
@@ -1595,7 +1998,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         && ((long long)std::max(G.NX, std::max(G.NY, G.NZ)) << (G.LEVELS - 1)) < (1LL << 24)
         && std::max(G.NX, std::max(G.NY, G.NZ)) < 4096) {        // (root-cell numbers from 24-bit multiplies: SOC_MAD24)
         // cells per brick: what lets two workgroups share a CU's 160 KB of LDS (8 B per cell, 12 B with the INT tally, + 9 KB)
-        const int capl = (tune.CAP > 0) ? tune.CAP : (V.wint ? 5888 : 8704);
+        // (rays: 4 B per cell, twice the cells in the same LDS)
+        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (V.wint ? 5888 : 8704));
         if (capl < 8 || capl > 36864) return hipErrorInvalidValue;
         const hipError_t e = soc_lb_build(device, G, capl, st, tune.verbose != 0);
         if (e == hipSuccess) {
@@ -1622,6 +2026,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             return e;
         }
     }
+    if (sca && !A.LT) return hipErrorNotSupported;
     if (!A.LT && (A.T > 512 || A.P > SOC_BRICK_PMAX || A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS))) return hipErrorInvalidValue;
     if (A.LT) {
         // set above
@@ -1724,6 +2129,13 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         BCHK(brick_alloc(&bb.desc[1], maxdesc));
         bb.cap_desc = maxdesc;
     }
+    if (sca && bb.cap_park < count) {
+        BCHK(hipStreamSynchronize(st));
+        BCHK(brick_alloc(&bb.park, count));
+        bb.cap_park = count;
+    }
+    A.park = sca ? bb.park : nullptr;
+    if (sca) A.sca = *sca;
     if (!bb.pack) BCHK(brick_alloc(&bb.pack, 1));
     if (!bb.ndesc) { BCHK(brick_alloc(&bb.ndesc, 4));  BCHK(brick_alloc(&bb.total, 1));  BCHK(brick_alloc(&bb.admit, 1 + 3 * SOC_MAXLAUNCH)); }
     A.pk = bb.pk;  A.keyq = bb.keyq;  A.posq = bb.posq;  A.hist = bb.hist;  A.off = bb.off;  A.total = bb.total;
@@ -1733,7 +2145,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = A.LT ? (size_t)(BV * (2 + (V.wint ? 1 : 0)) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint ? 1 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
@@ -1768,7 +2180,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (A.LT)        soc_lbrick_launch_pass(V.wint, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            if (sca)         BCHK(soc_lray_launch_pass(sca->kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices));
+            else if (A.LT)   soc_lbrick_launch_pass(V.wint, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);

@@ -93,6 +93,7 @@ struct soc_ctx {
     // rng
     uint64_t *dSeedTab = nullptr;
     unsigned long long *dStats = nullptr;
+    unsigned long long ray_steps = 0;                        // cell steps of the rays of the scattered-light sweeps, as of the last soc_stats
     // features
     int with_int = 0, ps_method = 0, use_emweight = 0, mirror = 0;
     // execution
@@ -157,6 +158,7 @@ static bool lt_capable(const soc_ctx *c, bool abu)
     return G.LEVELS > 1 && G.LEVELS <= 8 && G.NX > ((G.LEVELS < 3) ? 399 : 100) && !abu && !c->tune.global_tree
            && (((long long)n << (G.LEVELS - 1)) < (1LL << 24)) && n < 4096;
 }
+#define SOC_SCA_RAYS_LAUNCH 500000                           // ... a launch of the scattered-light kernels goes to the ray sweep
 #define SOC_LT_LONE_LAUNCH 1000000                           // work items from which a lone launch goes to the sweep there
 
 // Execute the launches deferred since soc_batch_begin: one brick sweep for all of them.
@@ -253,8 +255,8 @@ int soc_create(int device, soc_ctx **out)
     soc_build_seed_table(tab.data());
     if ((e = hipMalloc((void **)&c->dSeedTab, 1024 * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMemcpy(c->dSeedTab, tab.data(), 1024 * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->dStats, 3 * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemsetAsync(c->dStats, 0, 3 * sizeof(unsigned long long), c->stream)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->dStats, 4 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemsetAsync(c->dStats, 0, 4 * sizeof(unsigned long long), c->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         int r = fail(nullptr, SOC_ERR_HIP, "soc_create: %s", hipGetErrorString(e));
         soc_destroy(c);
@@ -1268,6 +1270,21 @@ static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVaria
     X.DSC = c->dDSC;
     X.OUT = c->dOUT;
     S.TABS = nullptr;  S.INT = nullptr;
+    c->last_passes = 0;  c->last_form = 0;
+    // Rays on brick-local hierarchies (soc_brick.hip: soc_sca_events): flat images, scalar opacities, one scattering function, and a
+    // launch large enough to fill the brick queues; soc_set_exec(1) asks for it, (0) for the direct kernel
+    const bool rays_ok = lt_capable(c, V.abu != 0) && !V.abu && X.NDIR > 0 && kind != SOC_SCA_HP && c->msf_ndust <= 1 && c->device < 16;
+    if (c->exec_mode == 1 && !rays_ok)
+        return fail(c, SOC_ERR_ARG, "%s: brick sweep requested but not applicable (needs a hierarchy walked in double, a flat image, scalar opacities, one scattering function)", who);
+    if (rays_ok && (c->exec_mode == 1 || (c->exec_mode < 0 && S.gid_count >= SOC_SCA_RAYS_LAUNCH))) {
+        SocSim R = S;
+        if (kind == SOC_SCA_CL) R.SOURCE = SOC_SOURCE_CL;
+        SocVariant W = V;
+        W.wint = 0;
+        hipError_t e = soc_brick_run_pb(c->device, c->G, &R, 1, W, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form, &X);
+        if (e == hipSuccess) return SOC_OK;
+        if (e != hipErrorNotSupported || c->exec_mode == 1) return fail(c, SOC_ERR_HIP, "%s: brick sweep failed: %s", who, hipGetErrorString(e));
+    }
     HIPCHK(c, soc_launch_sca(c->G, S, X, V, c->stream));
     return SOC_OK;
 }
@@ -1462,12 +1479,15 @@ int soc_stats(soc_ctx *c, uint64_t out[3], int reset)
     FLUSH(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    unsigned long long h[3];
+    unsigned long long h[4];
     HIPCHK(c, hipMemcpy(h, c->dStats, sizeof h, hipMemcpyDeviceToHost));
     if (out) for (int i = 0; i < 3; i++) out[i] = h[i];
+    c->ray_steps = h[3];
     if (reset) HIPCHK(c, hipMemsetAsync(c->dStats, 0, sizeof h, c->stream));
     return SOC_OK;
 }
+
+int64_t soc_sca_ray_steps(soc_ctx *c) { return c ? (int64_t)c->ray_steps : -1; }
 
 int soc_timer_start(soc_ctx *c)
 {

@@ -179,7 +179,8 @@ struct SocBrickTune {
 // population: packets in flight (0 = all work items at once, -1 = chosen from the number of bricks): the other work
 // items are admitted as earlier ones finish
 hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *S, int nlaunch, const SocVariant &V, int LB,
-                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out);
+                            int population, const SocBrickTune &tune, hipStream_t st, int *passes_out, int *form_out,
+                            const struct SocSca *sca = nullptr);      // sca: the launch is one of the scattered-light kernels (rays, soc_sca_events)
 void soc_brick_release(int device);
 void soc_brick_invalidate(int device);      // the grid changed: bricks of a hierarchy are rebuilt at the next sweep
 

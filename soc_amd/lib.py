@@ -81,6 +81,7 @@ API = {
     "soc_bind_tally": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "soc_read_par": (C.c_int, [C.c_void_p, _I, C.c_int64]),
     "soc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "soc_sca_ray_steps": (C.c_int64, [C.c_void_p]),
     "soc_timer_start": (C.c_int, [C.c_void_p]),
     "soc_timer_stop": (C.c_int, [C.c_void_p, _F]),
     "soc_solve_temperature": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _F, C.c_float, C.c_float, _F, _F]),
@@ -581,6 +582,10 @@ class Engine:
         out = (C.c_uint64 * 3)()
         self._chk(self.lib.soc_stats(self.h, out, int(reset)))
         return dict(tally_events=int(out[0]), packets=int(out[1]), scatterings=int(out[2]))
+
+    def sca_ray_steps(self):
+        """cell steps of the rays of the scattered-light sweeps, as of the last stats() call"""
+        return int(self.lib.soc_sca_ray_steps(self.h))
 
     def timer_start(self):
         self._chk(self.lib.soc_timer_start(self.h))
