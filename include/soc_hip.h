@@ -296,6 +296,18 @@ int soc_sca_read_out(soc_ctx *ctx, float *out, int64_t n);
 /* device address of the image, or bind caller-owned device memory as the image (for an RCCL
  * all-reduce over the GPUs that shared a launch); NULL gives the image back to memory of the library */
 void *soc_sca_out_ptr(soc_ctx *ctx);
+
+/* Scattered-light launches in batches.  The reference runs one kernel after the other per frequency and source (ASOCS.py:655-708)
+ * and reads the image after each frequency (:710-716).  Between soc_batch_begin and soc_batch_end (above) the soc_sca_sim_ps / _pb /
+ * _cl launches that can run as rays on brick-local hierarchies (flat image, scalar opacities, one scattering function, a hierarchy
+ * whose Index() the reference evaluates in double) are deferred, each with a snapshot of its inputs, and run together in one sweep
+ * -- more rays per brick and pass than any single launch has; every other launch runs at once, as without the batch.
+ * soc_sca_batch_images(n) gives the batch n zeroed images (n = 0: the one image of soc_sca_set_view again); the launches that
+ * follow soc_sca_batch_select(k) add to image k -- one image per frequency -- and soc_sca_batch_read(k, ...) replaces the
+ * enqueue_copy of that frequency's image after soc_batch_end. */
+int soc_sca_batch_images(soc_ctx *ctx, int n);
+int soc_sca_batch_select(soc_ctx *ctx, int k);
+int soc_sca_batch_read(soc_ctx *ctx, int k, float *out, int64_t n);
 int   soc_sca_bind_out(soc_ctx *ctx, void *device_ptr);
 
 /* ---- equilibrium dust temperature and emission (ASOC.py `CLT`/`CLE` paths) ---- */

@@ -86,7 +86,11 @@ class ScatteringRun(AbsorptionRun):
         else:
             e.sca_set_view(self.ODIR, self.RA, self.DE, U.NPIX, U.MAP_DX, U.MAPCENTRE, U.FFS)
             npix = self.NDIR * U.NPIX[0] * U.NPIX[1]
-        if self.comm:
+        # The frequencies of a source block are ONE batch with an image each (soc_sca_batch_images): the launches that can run as rays on
+        # brick-local hierarchies are deferred and share sweeps (many more rays per brick and pass than one launch has), the others run
+        # at once into their frequency's image.  Several ranks then add the images up once per block, on the host.
+        self.batched = hasattr(e, "sca_batch_images")
+        if self.comm and not self.batched:
             self.comm.attach_image(e, npix)
 
     def _update_emwei(self, IFREQ):
@@ -118,9 +122,42 @@ class ScatteringRun(AbsorptionRun):
         return seed
 
     def _collect(self, OUTCOMING, IFREQ):
+        if self.batched:
+            self._launched.append(IFREQ)                          # read after the batch (_end_block)
+            return
         t0 = time.time()
         OUT = self.comm.all_reduce_image(self.eng) if self.comm else self.eng.sca_read_out()
         OUTCOMING[IFREQ] += OUT
+        self.timers["Tpull"] += time.time() - t0
+
+    def _begin_block(self, max_launches=0):
+        """max_launches: cell-emission launches keep a copy of the emission each (8 B per cell), so their batches are shorter"""
+        self._launched = []
+        if self.batched:
+            self.eng.batch_begin(max_launches)
+            self.eng.sca_batch_images(self.NFREQ)
+
+    def _begin_frequency(self, IFREQ):
+        if self.batched:
+            self.eng.sca_batch_select(IFREQ)
+        else:
+            self.eng.sca_zero()
+
+    def _end_block(self, OUTCOMING):
+        if not self.batched:
+            return
+        t0 = time.time()
+        self.eng.batch_end()
+        self.eng.sync()
+        self.timers["Tkernel"] += time.time() - t0
+        t0 = time.time()
+        if self._launched:
+            imgs = np.stack([self.eng.sca_batch_read(k) for k in self._launched])
+            if self.comm and self.world > 1:
+                imgs = self.comm.all_reduce_host(imgs)
+            for i, k in enumerate(self._launched):
+                OUTCOMING[k] += imgs[i].reshape(OUTCOMING[k].shape)
+        self.eng.sca_batch_images(0)
         self.timers["Tpull"] += time.time() - t0
 
     # ---------------------------------------------------------------------------------
@@ -151,12 +188,13 @@ class ScatteringRun(AbsorptionRun):
             self.log("=== II=%d  GLOBAL %d, BATCH %d, PACKETS %d" % (II, L["GLOBAL"], L["BATCH"], L["PACKETS"]))
             first, count = self.comm.shard(L["GLOBAL"]) if self.comm else (0, L["GLOBAL"])
             self._skip = 2
+            self._begin_block(16 if II == 2 else 0)
             for IFREQ in range(NFREQ):
                 FREQ = float(FFREQ[IFREQ])
                 if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
                     continue
                 t0 = time.time()
-                e.sca_zero()
+                self._begin_frequency(IFREQ)
                 self._optical_for(IFREQ)
                 BG = np.float32(float(self.IBG[IFREQ]) * WBG / FREQ) if len(self.IBG) == NFREQ else np.float32(0.0)
                 PS = (self.LPS[:, IFREQ] * np.float32(WPS)) / np.float32(FREQ) if II == 0 else np.zeros(1, np.float32)
@@ -188,12 +226,14 @@ class ScatteringRun(AbsorptionRun):
                     e.sca_sim_pb(II, L["PACKETS"], L["BATCH"], seed, BG, GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
                 else:
                     e.sca_sim_cl(II, L["PACKETS"], L["BATCH"], seed, L["GLOBAL"], gid_first=first, gid_count=count)
-                e.sync()
+                if not self.batched:
+                    e.sync()
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
                 self._collect(OUTCOMING, IFREQ)
                 if self.verbose and self.rank == 0:
                     print("  FREQ %3d/%3d  %10.3e --  BG %10.3e  PS %10.3e" % (IFREQ + 1, NFREQ, FREQ, BG, PS[0]))
+            self._end_block(OUTCOMING)
 
         # dust emission from the emitted file, ASOCS.py:733-881
         if self.CLPAC > 0:
@@ -201,9 +241,10 @@ class ScatteringRun(AbsorptionRun):
             first, count = self.comm.shard(GLOBAL) if self.comm else (0, GLOBAL)
             self.log("=== CLPAC %d, GLOBAL %d, BATCH %d" % (CELLS * BATCH, GLOBAL, BATCH))
             self._skip = 2
+            self._begin_block(16)
             for IFREQ in range(NFREQ):
                 FREQ = float(FFREQ[IFREQ])
-                e.sca_zero()
+                self._begin_frequency(IFREQ)
                 if (FREQ < U.SIM_F[0]) or (FREQ > U.SIM_F[1]):
                     continue
                 if IFREQ < self.REMIT_I1 or IFREQ > self.REMIT_I2:
@@ -224,10 +265,12 @@ class ScatteringRun(AbsorptionRun):
                 self.timers["Tpush"] += time.time() - t0
                 t0 = time.time()
                 e.sca_sim_cl(2, self.CLPAC, BATCH, seed, GLOBAL, gid_first=first, gid_count=count)
-                e.sync()
+                if not self.batched:
+                    e.sync()
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += CELLS * BATCH
                 self._collect(OUTCOMING, IFREQ)
+            self._end_block(OUTCOMING)
         return OUTCOMING
 
     def run(self):

@@ -1253,10 +1253,8 @@ struct SocRayLane {                                                   // what so
     soc_rng_t rng;
 };
 
-template <int KIND>
 __device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
-    constexpr bool CLW = (KIND == SOC_SCA_CL);
     const SocSca &V = A.sca;
     const int di = A.ndesc[2] + ebid;
     if (di >= *A.ndesc) return;
@@ -1273,6 +1271,8 @@ __device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPac
     const int lq = (D.brick - A.NBQ) / A.EQ;
     const int evk = (D.brick - A.NBQ) % A.EQ;                 // 0 left the model (or not started), 1 scattering, 2 slow step
     const SocSim &S = K.S[lq];
+    const int  KIND = S.SCAKIND - 1;                          // the kernel of this queue's launch (uniform in the workgroup)
+    const bool CLW = (KIND == SOC_SCA_CL);
     const int qbase = 0;                                      // rays of all launches share the brick queues (no tallies in LDS)
     extern __shared__ float lds[];
     int   *sH   = (int *)lds;
@@ -1391,7 +1391,7 @@ __device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPac
                     } else {
                         int b = (int)(S.BINS * (1.0f + cos_theta) * 0.5f);
                         b = b < 0 ? 0 : (b > S.BINS - 1 ? S.BINS - 1 : b);
-                        delta = w.photons * soc_expf(-taup) * V.DSC[b];
+                        delta = w.photons * soc_expf(-taup) * S.DSC[b];
                     }
                     const float qx = w.px - V.CX, qy = w.py - V.CY, qz = w.pz - V.CZ;
                     const float4 ra = V.ORA[idir], de = V.ODE[idir];
@@ -1399,7 +1399,7 @@ __device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPac
                     int jj = (int)((0.5f * V.NPIX_Y - 0.00005f) + (qx * de.x + qy * de.y + qz * de.z) / V.MAP_DX);
                     if ((i >= 0) && (jj >= 0) && (i < V.NPIX_X) && (jj < V.NPIX_Y)) {
                         i += idir * V.NPIX_X * V.NPIX_Y + jj * V.NPIX_X;
-                        soc_tally(V.OUT, i, delta);
+                        soc_tally(S.OUT, i, delta);
                         n_add++;
                     }
                     idir++;
@@ -1586,7 +1586,6 @@ __device__ __forceinline__ void soc_sca_events(const SocGrid &G, const SocSimPac
     }
 }
 
-template <int KIND>
 __global__ __launch_bounds__(1024) void soc_lray_pass(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
 {
     const SocSimPack &K = *Kp;
@@ -1595,7 +1594,7 @@ __global__ __launch_bounds__(1024) void soc_lray_pass(const SocGrid G, const Soc
         soc_lbrick_walk<false, true>(G, K, A, b);
     } else {
         const int e = b - nwalk;
-        soc_sca_events<KIND>(G, K, A, e / slices, e % slices);
+        soc_sca_events(G, K, A, e / slices, e % slices);
     }
 }
 
@@ -1911,16 +1910,11 @@ static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_
 #undef SOC_LB_CASE
 }
 
-static hipError_t soc_lray_launch_pass(int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
+static hipError_t soc_lray_launch_pass(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                        const SocBrickArgs &A, int nwalk, int slices)
 {
-#define SOC_LR_CASE(KD) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)soc_lray_pass<KD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                             soc_lray_pass<KD><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); } while (0)
-    if (kind == SOC_SCA_PB) SOC_LR_CASE(SOC_SCA_PB);
-    else if (kind == SOC_SCA_PS) SOC_LR_CASE(SOC_SCA_PS);
-    else if (kind == SOC_SCA_CL) SOC_LR_CASE(SOC_SCA_CL);
-    else return hipErrorNotSupported;
-#undef SOC_LR_CASE
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)soc_lray_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    soc_lray_pass<<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices);
     return hipSuccess;
 }
 
@@ -1968,7 +1962,15 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 {
     if (form_out) *form_out = 0;
     // rays of the scattered-light kernels (soc_sca_events): flat images of SimRAM_PB / PS / CL with scalar opacities and one scattering function
-    if (sca && (sca->NDIR < 0 || sca->kind == SOC_SCA_HP || V.abu || V.wint || nlaunch != 1 || Sin[0].NDUST > 1 || Sin[0].BINS < 1)) return hipErrorNotSupported;
+    if (sca) {
+        if (sca->NDIR < 0 || V.abu || V.wint) return hipErrorNotSupported;
+        for (int l = 0; l < nlaunch; l++) {
+            const int k = Sin[l].SCAKIND - 1;
+            if ((k != SOC_SCA_PB && k != SOC_SCA_PS && k != SOC_SCA_CL) || Sin[l].NDUST > 1 || Sin[l].BINS < 1 || !Sin[l].OUT) return hipErrorNotSupported;
+            if ((k != SOC_SCA_CL) && !Sin[l].DSC) return hipErrorNotSupported;
+            if ((k == SOC_SCA_CL) != (Sin[l].SOURCE == SOC_SOURCE_CL)) return hipErrorInvalidValue;
+        }
+    }
     if (device < 0 || device >= 16 || nlaunch < 1 || nlaunch > SOC_MAXLAUNCH) return hipErrorNotSupported;
     const int B = 1 << LB;
     SocBrickArgs A{};
@@ -2180,7 +2182,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (sca)         BCHK(soc_lray_launch_pass(sca->kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices));
+            if (sca)         BCHK(soc_lray_launch_pass(maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices));
             else if (A.LT)   soc_lbrick_launch_pass(V.wint, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
             else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);

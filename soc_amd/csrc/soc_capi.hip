@@ -73,6 +73,12 @@ struct soc_ctx {
     bool   batching = false;
     int    batch_max = 4;
     std::vector<SocSim> pending;
+    bool   pending_sca = false;                               // the deferred launches are scattered-light ones (rays; soc_sca_sim_*)
+    float *dDSCslot[SOC_MAXLAUNCH] = {};                      // their discrete scattering functions
+    int    dsc_slot_bins = 0;
+    float *dOUTslots = nullptr;                               // soc_sca_batch_images: several images, one per frequency of a batch
+    int    out_slots = 0, out_slot_cur = 0;
+    size_t out_slot_pixels = 0;
     float *dCSCslot[SOC_MAXLAUNCH] = {};
     float2 *dOPTslots = nullptr;                  // [SOC_OPT_SLOTS][CELLS] per-cell opacities of deferred launches (one buffer: the sweep strides through it)
     float *dHPslots = nullptr;                    // [SOC_MAXLAUNCH][2][49152] Healpix skies of deferred SimRAM_HP launches
@@ -169,6 +175,26 @@ static int flush_pending(soc_ctx *c)
     todo.swap(c->pending);
     SocVariant V;
     V.octree = c->G.LEVELS > 1;  V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);
+    if (c->pending_sca) {
+        // deferred launches of the scattered-light kernels: one sweep of rays for all of them; where the sweep does not apply
+        // (it did when they were deferred: the grid has not changed since) each runs through the direct kernel
+        c->pending_sca = false;
+        V.abu = 0;  V.wint = 0;
+        HIPCHK(c, hipSetDevice(c->device));
+        SocSca X = c->view;
+        X.kind = todo[0].SCAKIND - 1;  X.DSC = todo[0].DSC;  X.OUT = todo[0].OUT;
+        hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form, &X);
+        if (e == hipErrorNotSupported) {
+            for (SocSim &S1 : todo) {
+                X.kind = S1.SCAKIND - 1;  X.DSC = S1.DSC;  X.OUT = S1.OUT;
+                if (S1.SOURCE == SOC_SOURCE_CL) S1.SOURCE = 2;
+                HIPCHK(c, soc_launch_sca(c->G, S1, X, V, c->stream));
+            }
+            return SOC_OK;
+        }
+        if (e != hipSuccess) return fail(c, SOC_ERR_HIP, "sweep of the rays of %d deferred scattered-light launches failed: %s", (int)todo.size(), hipGetErrorString(e));
+        return SOC_OK;
+    }
     V.abu = todo[0].OPT != nullptr;                          // what makes a launch deferrable (see soc_sim_pb)
     V.wint = ((c->batch_keep_int || c->batch_share_int) && c->with_int) ? 1 : 0;
     HIPCHK(c, hipSetDevice(c->device));
@@ -277,6 +303,8 @@ void soc_destroy(soc_ctx *c)
         for (void *q : sb) if (q) (void)hipFree(q);
     }
     for (float *q : c->dCSCslot) if (q) (void)hipFree(q);
+    for (float *q : c->dDSCslot) if (q) (void)hipFree(q);
+    if (c->dOUTslots) (void)hipFree(c->dOUTslots);
     for (float *q : c->dEMITslot) if (q) (void)hipFree(q);
     for (float *q : c->dINTslot) if (q) (void)hipFree(q);
     void *bufs[] = { c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dINTV, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
@@ -767,6 +795,7 @@ static int take_int_slot(soc_ctx *c, const char *who, SocSim &S)
 static bool same_sweep(const soc_ctx *c, int source, bool abu)
 {
     if (c->pending.empty()) return true;
+    if (c->pending_sca) return false;                        // deferred scattered-light launches: another kind of sweep
     const SocSim &P = c->pending[0];
     const int kp = (P.SOURCE == SOC_SOURCE_CL) ? 2 : (P.SOURCE == SOC_SOURCE_HP) ? 1 : 0;
     const int kn = (source == SOC_SOURCE_CL) ? 2 : (source == SOC_SOURCE_HP) ? 1 : 0;
@@ -1087,6 +1116,31 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     return SOC_OK;
 }
 
+// a deferred cell-emission launch keeps its own copy of the emission (and of the packet weights): the caller uploads the next frequency's
+static int snapshot_emission(soc_ctx *c, SocSim &S, int slot)
+{
+    const size_t cells = (size_t)c->G.CELLS;
+    if (c->emitslot_cells != cells) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (float *&q : c->dEMITslot) if (q) { (void)hipFree(q);  q = nullptr; }
+        c->emitslot_cells = cells;
+        c->emit_slot_last = -1;
+    }
+    // (the copy of an earlier launch of this batch serves when soc_set_emission has not been called since)
+    int es = slot;
+    if (c->emit_slot_last >= 0 && c->emit_slot_last < slot && c->emit_slot_gen == c->emit_gen) {
+        es = c->emit_slot_last;
+    } else {
+        if (!c->dEMITslot[slot]) HIPCHK(c, dev_alloc(&c->dEMITslot[slot], cells * 2));
+        HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot], c->dEMIT, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot] + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
+        c->emit_slot_last = slot;  c->emit_slot_gen = c->emit_gen;
+    }
+    float *em = c->dEMITslot[es];
+    S.EMIT = em;  S.EMWEI = em + cells;
+    return SOC_OK;
+}
+
 int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float TW,
                int GLOBAL, int gid_first, int gid_count)
 {
@@ -1129,26 +1183,8 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         const int slot = (int)c->pending.size();
         r = snapshot_inputs(c, S, V, slot);
         if (r) return r;
-        // its own copy of the emission (and of the packet weights): the caller uploads the next frequency's
-        const size_t cells = (size_t)c->G.CELLS;
-        if (c->emitslot_cells != cells) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (float *&q : c->dEMITslot) if (q) { (void)hipFree(q);  q = nullptr; }
-            c->emitslot_cells = cells;
-            c->emit_slot_last = -1;
-        }
-        // (the copy of an earlier launch of this batch serves when soc_set_emission has not been called since)
-        int es = slot;
-        if (c->emit_slot_last >= 0 && c->emit_slot_last < slot && c->emit_slot_gen == c->emit_gen) {
-            es = c->emit_slot_last;
-        } else {
-            if (!c->dEMITslot[slot]) HIPCHK(c, dev_alloc(&c->dEMITslot[slot], cells * 2));
-            HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot], c->dEMIT, cells * 4, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->dEMITslot[slot] + cells, c->dEMWEI, cells * 4, hipMemcpyDeviceToDevice, c->stream));
-            c->emit_slot_last = slot;  c->emit_slot_gen = c->emit_gen;
-        }
-        float *em = c->dEMITslot[es];
-        S.EMIT = em;  S.EMWEI = em + cells;
+        r = snapshot_emission(c, S, slot);
+        if (r) return r;
         c->pending.push_back(S);
         if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
         return SOC_OK;
@@ -1211,6 +1247,7 @@ int soc_sca_set_view(soc_ctx *c, int NDIR, const float *ODIR, const float *RA, c
     c->view.MAP_DX = MAP_DX;  c->view.CX = CENTRE[0];  c->view.CY = CENTRE[1];  c->view.CZ = CENTRE[2];
     c->view.ODIRS = c->dODIR;  c->view.ORA = c->dORA;  c->view.ODE = c->dODE;
     c->have_view = true;
+    c->out_slots = 0;                                        // (images of soc_sca_batch_images belonged to the old view)
     return SOC_OK;
 }
 
@@ -1247,6 +1284,7 @@ int soc_sca_set_healpix(soc_ctx *c, int NSIDE, const float *OBSERVER, int FFS)
     c->view.MAP_DX = 1.0f;  c->view.CX = c->view.CY = c->view.CZ = 0.0f;
     c->view.ODIRS = c->dODIR;  c->view.ORA = c->dORA;  c->view.ODE = c->dODE;
     c->have_view = true;
+    c->out_slots = 0;                                        // (images of soc_sca_batch_images belonged to the old view)
     return SOC_OK;
 }
 
@@ -1260,7 +1298,24 @@ int soc_sca_zero(soc_ctx *c)
     return SOC_OK;
 }
 
-static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVariant &V)
+// Rays on brick-local hierarchies (soc_brick.hip: soc_sca_events) take flat images, scalar opacities and one scattering function
+static bool sca_rays_ok(const soc_ctx *c, int kind)
+{
+    return c->have_view && c->view.NDIR > 0 && kind != SOC_SCA_HP && lt_capable(c, c->dOPT != nullptr) && c->msf_ndust <= 1 && c->device < 16;
+}
+
+// Start of a soc_sca_sim_* call: inside soc_batch_begin/end a launch that can run as rays is deferred -- the slot its inputs are
+// kept in is returned -- and runs with the others of the batch in one sweep; otherwise (-1) what is pending runs first.
+static int sca_begin(soc_ctx *c, int kind, int *slot)
+{
+    *slot = -1;
+    const bool defer = c->batching && c->exec_mode != 0 && sca_rays_ok(c, kind);
+    if (!defer || !c->pending_sca || (int)c->pending.size() >= c->batch_max) FLUSH(c);
+    if (defer) *slot = (int)c->pending.size();
+    return SOC_OK;
+}
+
+static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVariant &V, int slot)
 {
     if (!c->have_view) return fail(c, SOC_ERR_STATE, "%s: call soc_sca_set_view first", who);
     if (kind != SOC_SCA_CL && kind != SOC_SCA_HP && !c->have_dsc) return fail(c, SOC_ERR_STATE, "%s: soc_set_scatter_table was called without DSC", who);
@@ -1268,14 +1323,36 @@ static int sca_launch(soc_ctx *c, const char *who, int kind, SocSim &S, SocVaria
     SocSca X = c->view;
     X.kind = kind;
     X.DSC = c->dDSC;
-    X.OUT = c->dOUT;
+    X.OUT = c->out_slots ? c->dOUTslots + (size_t)c->out_slot_cur * c->out_slot_pixels : c->dOUT;
     S.TABS = nullptr;  S.INT = nullptr;
+    S.SCAKIND = kind + 1;  S.DSC = X.DSC;  S.OUT = X.OUT;
     c->last_passes = 0;  c->last_form = 0;
-    // Rays on brick-local hierarchies (soc_brick.hip: soc_sca_events): flat images, scalar opacities, one scattering function, and a
-    // launch large enough to fill the brick queues; soc_set_exec(1) asks for it, (0) for the direct kernel
-    const bool rays_ok = lt_capable(c, V.abu != 0) && !V.abu && X.NDIR > 0 && kind != SOC_SCA_HP && c->msf_ndust <= 1 && c->device < 16;
+    const bool rays_ok = sca_rays_ok(c, kind);
     if (c->exec_mode == 1 && !rays_ok)
         return fail(c, SOC_ERR_ARG, "%s: brick sweep requested but not applicable (needs a hierarchy walked in double, a flat image, scalar opacities, one scattering function)", who);
+    if (slot >= 0) {
+        // deferred: the launch keeps its own copies of the scattering functions (and of the emission; the point sources are in their slot already)
+        SocVariant W = V;
+        W.abu = 0;
+        int r = snapshot_inputs(c, S, W, slot);
+        if (r) return r;
+        if (c->dsc_slot_bins != c->BINS) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int k = 0; k < SOC_MAXLAUNCH; k++) HIPCHK(c, dev_alloc(&c->dDSCslot[k], (size_t)c->BINS));
+            c->dsc_slot_bins = c->BINS;
+        }
+        if (c->have_dsc) HIPCHK(c, hipMemcpyAsync(c->dDSCslot[slot], c->dDSC, (size_t)c->BINS * 4, hipMemcpyDeviceToDevice, c->stream));
+        S.DSC = c->dDSCslot[slot];
+        if (kind == SOC_SCA_CL) {
+            r = snapshot_emission(c, S, slot);
+            if (r) return r;
+            S.SOURCE = SOC_SOURCE_CL;
+        }
+        c->pending.push_back(S);
+        c->pending_sca = true;
+        return SOC_OK;
+    }
+    // a lone launch: as rays when it is large enough to fill the brick queues; soc_set_exec(1) asks for it, (0) for the direct kernel
     if (rays_ok && (c->exec_mode == 1 || (c->exec_mode < 0 && S.gid_count >= SOC_SCA_RAYS_LAUNCH))) {
         SocSim R = S;
         if (kind == SOC_SCA_CL) R.SOURCE = SOC_SOURCE_CL;
@@ -1295,16 +1372,18 @@ int soc_sca_sim_ps(soc_ctx *c, int PACKETS, int BATCH, float SEED, float BG, con
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
-    int r = check_launch(c, "soc_sca_sim_ps", BATCH, GLOBAL, gid_first, gid_count);
+    int slot = -1;
+    int r = sca_begin(c, SOC_SCA_PS, &slot);
+    if (r) return r;
+    r = check_launch(c, "soc_sca_sim_ps", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     HIPCHK(c, hipSetDevice(c->device));
     SocSim S;
     SocVariant V;
     fill_sim(c, S, V, 0, BATCH, SEED, BG, 0.0f, GLOBAL, gid_first, gid_count);
-    r = upload_sources(c, "soc_sca_sim_ps", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true);
+    r = upload_sources(c, "soc_sca_sim_ps", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true, slot < 0 ? 0 : slot);
     if (r) return r;
-    return sca_launch(c, "soc_sca_sim_ps", SOC_SCA_PS, S, V);
+    return sca_launch(c, "soc_sca_sim_ps", SOC_SCA_PS, S, V, slot);
 }
 
 int soc_sca_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, const float *PSPOS, const float *PS,
@@ -1313,8 +1392,10 @@ int soc_sca_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, f
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
-    int r = check_launch(c, "soc_sca_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
+    int slot = -1;
+    int r = sca_begin(c, SOC_SCA_PB, &slot);
+    if (r) return r;
+    r = check_launch(c, "soc_sca_sim_pb", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (SOURCE != 0 && SOURCE != 1)
         return fail(c, SOC_ERR_ARG, "soc_sca_sim_pb: SOURCE=%d (0 point sources, 1 background; ROI_LOAD is not supported)", SOURCE);
@@ -1323,20 +1404,22 @@ int soc_sca_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, f
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, 0.0f, GLOBAL, gid_first, gid_count);
     if (SOURCE == 0) {
-        r = upload_sources(c, "soc_sca_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true);
+        r = upload_sources(c, "soc_sca_sim_pb", S, PSPOS, PS, NO_PS, XPS_NSIDE, XPS_SIDE, XPS_AREA, true, slot < 0 ? 0 : slot);
         if (r) return r;
     } else {
         S.NO_PS = 1;
     }
-    return sca_launch(c, "soc_sca_sim_pb", SOC_SCA_PB, S, V);
+    return sca_launch(c, "soc_sca_sim_pb", SOC_SCA_PB, S, V, slot);
 }
 
 int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count)
 {
     (void)PACKETS;  (void)SOURCE;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
-    int r = check_launch(c, "soc_sca_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
+    int slot = -1;
+    int r = sca_begin(c, SOC_SCA_CL, &slot);
+    if (r) return r;
+    r = check_launch(c, "soc_sca_sim_cl", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_emit) return fail(c, SOC_ERR_STATE, "soc_sca_sim_cl: call soc_set_emission first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1344,15 +1427,17 @@ int soc_sca_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, i
     SocVariant V;
     fill_sim(c, S, V, 2, BATCH, SEED, 0.0f, 0.0f, GLOBAL, gid_first, gid_count);
     S.NO_PS = 1;
-    return sca_launch(c, "soc_sca_sim_cl", SOC_SCA_CL, S, V);
+    return sca_launch(c, "soc_sca_sim_cl", SOC_SCA_CL, S, V, slot);
 }
 
 int soc_sca_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, int GLOBAL, int gid_first, int gid_count)
 {
     (void)PACKETS;
     if (!c) return SOC_ERR_ARG;
-    FLUSH(c);
-    int r = check_launch(c, "soc_sca_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
+    int slot = -1;
+    int r = sca_begin(c, SOC_SCA_HP, &slot);
+    if (r) return r;
+    r = check_launch(c, "soc_sca_sim_hp", BATCH, GLOBAL, gid_first, gid_count);
     if (r) return r;
     if (!c->have_hpbg) return fail(c, SOC_ERR_STATE, "soc_sca_sim_hp: call soc_set_hpbg first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1360,7 +1445,7 @@ int soc_sca_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, int GLOBAL, i
     SocVariant V;
     fill_sim(c, S, V, 1, BATCH, SEED, 0.0f, 0.0f, GLOBAL, gid_first, gid_count);
     S.NO_PS = 1;
-    return sca_launch(c, "soc_sca_sim_hp", SOC_SCA_HP, S, V);
+    return sca_launch(c, "soc_sca_sim_hp", SOC_SCA_HP, S, V, slot);
 }
 
 int soc_sca_read_out(soc_ctx *c, float *out, int64_t n)
@@ -1377,6 +1462,45 @@ int soc_sca_read_out(soc_ctx *c, float *out, int64_t n)
 }
 
 void *soc_sca_out_ptr(soc_ctx *c) { return (c && c->have_view) ? (void *)c->dOUT : nullptr; }
+
+int soc_sca_batch_images(soc_ctx *c, int n)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (n < 0 || n > 4096) return fail(c, SOC_ERR_ARG, "soc_sca_batch_images: n=%d (0 = the image of soc_sca_set_view again, at most 4096)", n);
+    if (n > 0 && !c->have_view) return fail(c, SOC_ERR_STATE, "soc_sca_batch_images: call soc_sca_set_view first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t pix = view_pixels(c);
+    if (n > 0) {
+        if ((size_t)n * pix > (size_t)c->out_slots * c->out_slot_pixels || !c->dOUTslots) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_alloc(&c->dOUTslots, (size_t)n * pix));
+        }
+        HIPCHK(c, hipMemsetAsync(c->dOUTslots, 0, (size_t)n * pix * 4, c->stream));
+    }
+    c->out_slots = n;  c->out_slot_pixels = pix;  c->out_slot_cur = 0;
+    return SOC_OK;
+}
+
+int soc_sca_batch_select(soc_ctx *c, int k)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (k < 0 || k >= c->out_slots) return fail(c, SOC_ERR_ARG, "soc_sca_batch_select: image %d of %d (soc_sca_batch_images)", k, c->out_slots);
+    c->out_slot_cur = k;                                     // (launches already deferred keep the image they were given)
+    return SOC_OK;
+}
+
+int soc_sca_batch_read(soc_ctx *c, int k, float *out, int64_t n)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (k < 0 || k >= c->out_slots) return fail(c, SOC_ERR_ARG, "soc_sca_batch_read: image %d of %d (soc_sca_batch_images)", k, c->out_slots);
+    if (!out || n < 0 || (size_t)n > c->out_slot_pixels) return fail(c, SOC_ERR_ARG, "soc_sca_batch_read: n=%lld (an image has %lld values)", (long long)n, (long long)c->out_slot_pixels);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->dOUTslots + (size_t)k * c->out_slot_pixels, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
 
 int soc_sca_bind_out(soc_ctx *c, void *device_ptr)
 {

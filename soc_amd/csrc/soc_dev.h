@@ -58,6 +58,11 @@ struct SocSim {
     const float  *ABU;         /* [CELLS][NDUST] abundances                                                  */
     float  *INTV;              /* -D SAVE_INTENSITY=2: INTX | INTY | INTZ (CELLS each), else NULL; direct kernels only */
     int     CELLS;             /* stride of INTV                                                             */
+    /* a launch of the scattered-light kernels run as a sweep of rays (soc_brick.hip: soc_sca_events): which kernel, its
+     * discrete scattering function and the image it adds to (launches of one sweep may belong to several frequencies) */
+    int          SCAKIND;      /* SOC_SCA_* + 1; 0: an absorption launch                                     */
+    const float *DSC;          /* [BINS]                                                                     */
+    float       *OUT;          /* [NDIR*NPIX_Y*NPIX_X]                                                       */
 };
 
 #define SOC_SOURCE_HP 4        /* brick sweep only: the launch is a SimRAM_HP one (Healpix sky instead of BG) */

@@ -73,6 +73,9 @@ API = {
     "soc_sca_sim_cl": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
     "soc_sca_read_out": (C.c_int, [C.c_void_p, _F, C.c_int64]),
     "soc_sca_out_ptr": (C.c_void_p, [C.c_void_p]),
+    "soc_sca_batch_images": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_sca_batch_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_sca_batch_read": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
     "soc_sca_bind_out": (C.c_int, [C.c_void_p, C.c_void_p]),
     "soc_sync": (C.c_int, [C.c_void_p]),
     "soc_read_tally": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_int64]),
@@ -546,6 +549,18 @@ class Engine:
 
     def sca_out_ptr(self):
         return self.lib.soc_sca_out_ptr(self.h)
+
+    def sca_batch_images(self, n):
+        """n zeroed images for the scattered-light launches of a batch (batch_begin ... batch_end), 0 = the one image again"""
+        self._chk(self.lib.soc_sca_batch_images(self.h, int(n)))
+
+    def sca_batch_select(self, k):
+        self._chk(self.lib.soc_sca_batch_select(self.h, int(k)))
+
+    def sca_batch_read(self, k):
+        out = np.zeros(self.sca_shape, np.float32)
+        self._chk(self.lib.soc_sca_batch_read(self.h, int(k), _f(out), out.size))
+        return out
 
     def sca_bind_out(self, device_ptr):
         self._chk(self.lib.soc_sca_bind_out(self.h, C.c_void_p(device_ptr) if device_ptr else None))

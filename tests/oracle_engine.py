@@ -270,6 +270,21 @@ class OracleEngine:
     def sca_read_out(self):
         return self.OUT.reshape(self.sca_shape).copy()
 
+    # images of a batch (soc_sca_batch_images / _select / _read): the oracle runs every launch at once, into the selected image
+    def sca_batch_images(self, n):
+        if getattr(self, "_one", None) is None:
+            self._one = self.OUT
+        self._imgs = [np.zeros_like(self._one) for _ in range(n)]
+        self.OUT = self._imgs[0] if n else self._one
+        if not n:
+            self._one = None
+
+    def sca_batch_select(self, k):
+        self.OUT = self._imgs[k]
+
+    def sca_batch_read(self, k):
+        return self._imgs[k].reshape(self.sca_shape).copy()
+
     def sca_bind_out(self, ptr):
         raise NotImplementedError
 

@@ -107,3 +107,68 @@ def test_reflecting_faces_and_the_direct_kernel_as_second_witness(engine, parkin
         assert sa == sb
         assert_image_close(b, a)
     engine.set_mirror(0)
+
+
+def test_a_batch_of_launches_with_an_image_per_frequency(engine, parking):
+    """soc_batch_begin ... soc_batch_end around scattered-light launches: point-source, background and cell-emission launches of several
+    'frequencies' (own opacities, scattering functions, emission, seeds) deferred into ONE sweep of rays, each frequency adding to its own
+    image (soc_sca_batch_images / _select / _read).  Every image equals the one the same launches give one at a time."""
+    from soc_amd import synth
+    cl = cloud104()
+    k = 2.0 / (104 * float(cl.DENS[:104 ** 3][cl.DENS[:104 ** 3] > 0].mean()))
+    view = view104(angles=((60.0, 200.0), (10.0, 80.0)))
+    ps = np.array([[52.3, 51.7, 50.2]], np.float32)
+    emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+    tabs = [synth.hg_scattering_table(g) for g in (0.6, 0.2, 0.4)]                # (DSC, CSC)
+    freqs = []
+    for f in range(3):
+        kw = dict(ABS=(0.2 + 0.1 * f) * k, SCA=(1.0 - 0.2 * f) * k, DSC=tabs[f][0])
+        freqs.append([(2, Job(cl, tabs[f][1], SOURCE=0, BATCH=6, SEED=0.2 + 0.1 * f, GLOBAL=4096, PSPOS=ps, PS=[1.0 + f], **kw), 0, 4096),
+                      (0, Job(cl, tabs[f][1], SOURCE=1, BATCH=2, SEED=0.3 + 0.1 * f, BG=1.0 + f, **kw), 1000, 21000),
+                      (1, Job(cl, tabs[f][1], SOURCE=2, BATCH=1, SEED=0.4 + 0.1 * f, GLOBAL=16384, EMIT=emit * (1 + f), **kw), 0, 16384)])
+    # one at a time (rays too), one image
+    single, stats = [], []
+    for launches in freqs:
+        img = None
+        tot = dict(tally_events=0, packets=0, scatterings=0)
+        for kind, job, g0, g1 in launches:
+            engine.set_exec(1, 4)
+            a, st = run_sca(engine, job, view, kind, g0, g1 - g0)
+            img = a.astype(np.float64) if img is None else img + a
+            for key in tot:
+                tot[key] += st[key]
+        single.append(img)
+        stats.append(tot)
+    # the same launches in one batch
+    engine.set_exec(-1, 4)
+    engine.stats(reset=True)
+    engine.batch_begin(0)
+    engine.sca_batch_images(3)
+    for f, launches in enumerate(freqs):
+        engine.sca_batch_select(f)
+        for kind, job, g0, g1 in launches:
+            _defer(engine, job, view, kind, g0, g1 - g0)
+    assert engine.last_passes() == 0                              # nothing has run yet (a launch run at once as rays would have left its passes) ...
+    engine.batch_end()
+    st = engine.stats()
+    assert engine.last_form() == 3 and engine.last_passes() > 0   # ... and all of it ran as one sweep
+    for key in ("tally_events", "packets", "scatterings"):
+        assert st[key] == sum(s[key] for s in stats)
+    for f in range(3):
+        assert_image_close(engine.sca_batch_read(f), single[f], rtol=2e-5)
+    engine.sca_batch_images(0)
+    engine.set_exec(-1, 4)
+
+
+def _defer(eng, job, view, kind, gid_first, gid_count):
+    """the calls of run_sca without the ones that would run what is pending (zero, stats, sync, read)"""
+    eng.set_optical(job.ABS, job.SCA)
+    eng.set_scatter_table(job.DSC, job.CSC)
+    xps = (job.XPS_NSIDE, job.XPS_SIDE, job.XPS_AREA)
+    if kind == 2:
+        eng.sca_sim_ps(job.PACKETS, job.BATCH, job.SEED, job.BG, job.PSPOS[:, :3], job.PS, XPS=xps, GLOBAL=job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
+    elif kind == 0:
+        eng.sca_sim_pb(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.BG, job.PSPOS[:, :3], job.PS, XPS=xps, GLOBAL=job.GLOBAL, gid_first=gid_first, gid_count=gid_count)
+    else:
+        eng.set_emission(job.EMIT, job.EMWEI)
+        eng.sca_sim_cl(job.SOURCE, job.PACKETS, job.BATCH, job.SEED, job.GLOBAL, gid_first=gid_first, gid_count=gid_count)

@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--ndir", type=int, default=3)
+    ap.add_argument("--exec", dest="exec_mode", type=int, default=-1, help="-1 automatic, 0 the direct kernel (soc_sca_kernel), 1 the sweep of rays on brick-local hierarchies")
+    ap.add_argument("--cl-global", type=int, default=1048576, help="work items of the cell-emission launch")
+    ap.add_argument("--ps-global", type=int, default=1048576)
+    ap.add_argument("--tune", default="{}", help="soc_set_tuning settings as JSON")
+    ap.add_argument("--launches", type=int, default=1, help="launches (seeds) per measurement, deferred into one batch: soc_batch_begin ... soc_batch_end, as soc_amd.asocs runs the frequencies of a source block")
     a = ap.parse_args()
     N = a.n
     cloud = synth.octree_cloud(N, levels=a.levels, frac=0.10, seed=1234) if a.levels > 1 else synth.cartesian_cloud(N, seed=1234)
@@ -32,6 +37,8 @@ def main():
     eng = Engine(0)
     eng.set_cloud(cloud)
     eng.set_features(0, 0, 0)
+    eng.set_exec(a.exec_mode, 4)
+    eng.set_tuning(**json.loads(a.tune))
     eng.set_scatter_table(dsc, csc)
     k = 2.0 / (N * float(cloud.DENS[cloud.DENS > 0][:N ** 3].mean()))          # optical depth ~2 across the cloud
     eng.set_optical(0.5 * k, k)
@@ -46,21 +53,35 @@ def main():
     emit = np.where(cloud.DENS > 0, cloud.DENS * 1e-3, 0).astype(np.float32)
     eng.set_emission(emit)
     runs = (("SimRAM_PB background", lambda s: eng.sca_sim_pb(1, 8 * AREA * a.batch, a.batch, s, 1.0, GLOBAL=GLOBAL)),
-            ("SimRAM_PS point source", lambda s: eng.sca_sim_ps(1048576 * 8, 8, s, 0.0, ps, [1.0], GLOBAL=1048576)),
-            ("SimRAM_CL cell emission", lambda s: eng.sca_sim_cl(2, cloud.CELLS, 1, s, 1048576)))
+            ("SimRAM_PS point source", lambda s: eng.sca_sim_ps(a.ps_global * 8, 8, s, 0.0, ps, [1.0], GLOBAL=a.ps_global)),
+            ("SimRAM_CL cell emission", lambda s: eng.sca_sim_cl(2, cloud.CELLS, 1, s, a.cl_global)))
     for name, fn in runs:
         best = None
         for rep in range(2):
             eng.sca_zero()
             eng.stats(reset=True)
             eng.timer_start()
-            fn(0.3 + 0.1 * rep)
+            if a.launches > 1:
+                eng.batch_begin(0)
+                for k in range(a.launches):
+                    fn(0.3 + 0.1 * rep + 0.01 * k)
+                eng.batch_end()
+            else:
+                fn(0.3 + 0.1 * rep)
             ms = eng.timer_stop()
             st = eng.stats()
+            st["ray_steps"] = eng.sca_ray_steps()
+            st["passes"], st["form"] = eng.last_passes(), eng.last_form()
             if best is None or ms < best[0]:
                 best = (ms, st)
         ms, st = best
-        print(json.dumps({"kernel": "soc_sca_kernel", "launch": name, "cells": cloud.CELLS, "ndir": a.ndir, "kernel_ms": ms,
+        rays = st["form"] == 3
+        roof = {}
+        if rays:                  # read-only roofline of SURVEY 8(d): 4 B (density) per cell step of a ray
+            roof = {"ray_steps": st["ray_steps"], "steps_per_s": st["ray_steps"] / ms * 1e3, "passes": st["passes"],
+                    "roofline": {"bound": "hbm", "achieved": 4.0 * st["ray_steps"] / ms * 1e-6, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": 4.0 * st["ray_steps"] / ms * 1e-6 / 8000.0}}
+        print(json.dumps({"kernel": "soc_lray_pass (rays on brick-local hierarchies)" if rays else "soc_sca_kernel", **roof, "launch": name, "launches_in_the_batch": a.launches, "cells": cloud.CELLS, "ndir": a.ndir, "kernel_ms": ms,
                           "packets": st["packets"], "packets_per_s": st["packets"] / ms * 1e3,
                           "image_contributions": st["tally_events"], "scatterings": st["scatterings"]}), flush=True)
     eng.close()
