@@ -164,7 +164,10 @@ static bool lt_capable(const soc_ctx *c, bool abu)
     return G.LEVELS > 1 && G.LEVELS <= 8 && G.NX > ((G.LEVELS < 3) ? 399 : 100) && !abu && !c->tune.global_tree
            && (((long long)n << (G.LEVELS - 1)) < (1LL << 24)) && n < 4096;
 }
-#define SOC_SCA_RAYS_LAUNCH 500000                           // ... a launch of the scattered-light kernels goes to the ray sweep
+// ... the launches of the scattered-light kernels (alone, or those of a batch together) go to the sweep of rays.  Measured on the 256^3-root
+// hierarchy (tools/exp_sca.py): 1.0e6 work items 0.47x the direct kernel, 3.1e6 0.92x, 8.4e6 1.3x, 5.0e7 1.6x (best direct launch shape), 32
+// launches of 3.1e6 in one batch 4.4x
+#define SOC_SCA_RAYS_LAUNCH 4000000
 #define SOC_LT_LONE_LAUNCH 1000000                           // work items from which a lone launch goes to the sweep there
 
 // Execute the launches deferred since soc_batch_begin: one brick sweep for all of them.
@@ -183,7 +186,11 @@ static int flush_pending(soc_ctx *c)
         HIPCHK(c, hipSetDevice(c->device));
         SocSca X = c->view;
         X.kind = todo[0].SCAKIND - 1;  X.DSC = todo[0].DSC;  X.OUT = todo[0].OUT;
-        hipError_t e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form, &X);
+        unsigned long long items = 0;
+        for (const SocSim &S1 : todo) items += S1.gid_count;
+        hipError_t e = hipErrorNotSupported;
+        if (c->exec_mode == 1 || items >= SOC_SCA_RAYS_LAUNCH)     // (too few rays to fill the brick queues: the direct kernel, launch by launch)
+            e = soc_brick_run_pb(c->device, c->G, todo.data(), (int)todo.size(), V, c->brick_log2, -1, c->tune, c->stream, &c->last_passes, &c->last_form, &X);
         if (e == hipErrorNotSupported) {
             for (SocSim &S1 : todo) {
                 X.kind = S1.SCAKIND - 1;  X.DSC = S1.DSC;  X.OUT = S1.OUT;

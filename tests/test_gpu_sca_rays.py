@@ -139,8 +139,8 @@ def test_a_batch_of_launches_with_an_image_per_frequency(engine, parking):
                 tot[key] += st[key]
         single.append(img)
         stats.append(tot)
-    # the same launches in one batch
-    engine.set_exec(-1, 4)
+    # the same launches in one batch (soc_set_exec(1): in automatic mode a batch this small would go through the direct kernel)
+    engine.set_exec(1, 4)
     engine.stats(reset=True)
     engine.batch_begin(0)
     engine.sca_batch_images(3)
