@@ -623,7 +623,8 @@ __device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int c
 // RAY: the read-only rays of the scattered-light kernels (soc_sca_events below): no tallies (the LDS holds the cells only), the optical
 // depth grows with the factor the record carries in place of the photons (kappa_sca for the look-ahead and the packet, kappa_abs + kappa_sca
 // for a peel-off ray: kernel_ASOC_sca.c:895-897, :975-990, :1035-1040), no nudge after a failed step (GetStep alone moves these rays).
-template <bool WINT, bool RAY = false>
+// WINT: 0 TABS only, 1 the INT tally beside it, 2 INT and the vector sums INTX, INTY, INTZ (-D SAVE_INTENSITY=2, kernel_ASOC.c:604-612).
+template <int WINT, bool RAY = false>
 __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
     if (bid >= *A.ndesc) return;
@@ -638,7 +639,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + (RAY ? 0 : BV);                     // [BV] INT (WINT)
-    float *sD   = sI + (WINT ? BV : 0);                    // [BV] density | link of every cell of the brick (RAY: nothing else)
+    float *sV   = sI + (WINT ? BV : 0);                    // [3 BV] INTX | INTY | INTZ (WINT == 2)
+    float *sD   = sV + ((WINT == 2) ? 3 * BV : 0);         // [BV] density | link of every cell of the brick (RAY: nothing else)
     const int NQ = A.NBQ + A.EQ * A.nl + 1;
     int   *sH   = (int *)(sD + BV);                        // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));   // [0] next packet, [1] tally events
@@ -658,7 +660,10 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     KB.base = __builtin_amdgcn_readfirstlane(KB.base);  KB.nslot = __builtin_amdgcn_readfirstlane(KB.nslot);
     if (!parked) {
         const float *src = A.btree + KB.base;
-        for (int i = threadIdx.x; i < KB.nslot; i += nthr) { sD[i] = src[i];  if (!RAY) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f; }
+        for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
+            sD[i] = src[i];  if (!RAY) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f;
+            if (WINT == 2) { sV[i] = 0.0f;  sV[BV + i] = 0.0f;  sV[2 * BV + i] = 0.0f; }
+        }
     }
     soc_qh_init(sH, A.HS, NQ);
     if (threadIdx.x < 2) sCtl[threadIdx.x] = 0;
@@ -840,6 +845,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
                 atomicAdd(&sT[slot0], delta * tw);
                 if (WINT) atomicAdd(&sI[slot0], delta);
+                if (WINT == 2) { atomicAdd(&sV[slot0], delta * ux);  atomicAdd(&sV[BV + slot0], delta * uy);  atomicAdd(&sV[2 * BV + slot0], delta * uz); }
                 n_tally++;
                 photons *= e;
                 tau += dtau;
@@ -883,6 +889,11 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
                 if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
+                if (WINT == 2) {
+                    float *IV = K.S[qbase / A.NB].INTV;
+                    const long C = K.S[0].CELLS;
+                    soc_tally(IV, cell, sV[i]);  soc_tally(IV + C, cell, sV[BV + i]);  soc_tally(IV + 2 * C, cell, sV[2 * BV + i]);
+                }
             }
         }
     }
@@ -903,7 +914,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 
 
 // creation and scattering, one lane per queued packet
-template <bool OCT, bool ABU, bool WINT, int KIND, bool LT>
+template <bool OCT, bool ABU, int WINT, int KIND, bool LT>
 __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int ebid, const int slice)
 {
     constexpr int  SRC = (KIND == 3) ? 1 : -1;             // KIND 3: SimRAM_PB with SOURCE == 1 (background) only
@@ -1020,6 +1031,9 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
             soc_tally(S.TABS, oind, delta * S.TW);
             if (WINT) soc_tally(S.INT, oind, delta);
+            if (WINT == 2) {                                                  // -D SAVE_INTENSITY=2 (kernel_ASOC.c:724-732)
+                soc_tally(S.INTV, oind, delta * w.ux);  soc_tally(S.INTV + S.CELLS, oind, delta * w.uy);  soc_tally(S.INTV + 2 * (long)S.CELLS, oind, delta * w.uz);
+            }
             n_tally++;
             n_scat++;
             dx = soc_scale_up(dx, w.level);
@@ -1210,7 +1224,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void s
 
 // the same for brick-local hierarchies (soc_lbrick_walk).  The brick's cells take 8 bytes of LDS each, which is what
 // bounds the waves per SIMD here, not the registers.
-template <bool WINT, int KIND>
+template <int WINT, int KIND>
 __global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
 {
     const SocSimPack &K = *Kp;
@@ -1892,7 +1906,7 @@ static hipError_t soc_lb_build(int device, const SocGrid &G, int cap, hipStream_
     return hipSuccess;
 }
 
-template <bool WINT, int KIND>
+template <int WINT, int KIND>
 static void soc_lbrick_launch_one(int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                   const SocBrickArgs &A, int nwalk, int slices)
 {
@@ -1905,7 +1919,8 @@ static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_
                                    const SocBrickArgs &A, int nwalk, int slices)
 {
 #define SOC_LB_CASE(W, KD) soc_lbrick_launch_one<W, KD>(nblocks, T, lds, st, G, K, A, nwalk, slices)
-    if (wint) { if (kind == 4) SOC_LB_CASE(true, 4);  else if (kind == 3) SOC_LB_CASE(true, 3);  else if (kind == 2) SOC_LB_CASE(true, 2);  else if (kind == 1) SOC_LB_CASE(true, 1);  else SOC_LB_CASE(true, 0); }
+    if (wint == 2) { if (kind == 4) SOC_LB_CASE(2, 4);  else if (kind == 3) SOC_LB_CASE(2, 3);  else if (kind == 2) SOC_LB_CASE(2, 2);  else if (kind == 1) SOC_LB_CASE(2, 1);  else SOC_LB_CASE(2, 0); }
+    else if (wint) { if (kind == 4) SOC_LB_CASE(1, 4);  else if (kind == 3) SOC_LB_CASE(1, 3);  else if (kind == 2) SOC_LB_CASE(1, 2);  else if (kind == 1) SOC_LB_CASE(1, 1);  else SOC_LB_CASE(1, 0); }
     else      { if (kind == 4) SOC_LB_CASE(false, 4); else if (kind == 3) SOC_LB_CASE(false, 3); else if (kind == 2) SOC_LB_CASE(false, 2); else if (kind == 1) SOC_LB_CASE(false, 1); else SOC_LB_CASE(false, 0); }
 #undef SOC_LB_CASE
 }
@@ -2001,7 +2016,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         && std::max(G.NX, std::max(G.NY, G.NZ)) < 4096) {        // (root-cell numbers from 24-bit multiplies: SOC_MAD24)
         // cells per brick: what lets two workgroups share a CU's 160 KB of LDS (8 B per cell, 12 B with the INT tally, + 9 KB)
         // (rays: 4 B per cell, twice the cells in the same LDS)
-        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (V.wint ? 5888 : 8704));
+        // (the vector sums of SAVE_INTENSITY 2: 24 B per cell)
+        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (V.wint == 2 ? 2944 : V.wint ? 5888 : 8704));
         if (capl < 8 || capl > 36864) return hipErrorInvalidValue;
         const hipError_t e = soc_lb_build(device, G, capl, st, tune.verbose != 0);
         if (e == hipSuccess) {
@@ -2028,7 +2044,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             return e;
         }
     }
-    if (sca && !A.LT) return hipErrorNotSupported;
+    if ((sca || V.wint == 2) && !A.LT) return hipErrorNotSupported;
     if (!A.LT && (A.T > 512 || A.P > SOC_BRICK_PMAX || A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS))) return hipErrorInvalidValue;
     if (A.LT) {
         // set above
@@ -2147,7 +2163,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint ? 1 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint == 2 ? 4 : V.wint ? 1 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;

@@ -203,7 +203,7 @@ static int flush_pending(soc_ctx *c)
         return SOC_OK;
     }
     V.abu = todo[0].OPT != nullptr;                          // what makes a launch deferrable (see soc_sim_pb)
-    V.wint = ((c->batch_keep_int || c->batch_share_int) && c->with_int) ? 1 : 0;
+    V.wint = ((c->batch_keep_int || c->batch_share_int) && c->with_int) ? c->with_int : 0;
     HIPCHK(c, hipSetDevice(c->device));
     if (V.octree && todo.size() == 1 && c->exec_mode < 0 && !(lt_capable(c, V.abu != 0) && todo[0].gid_count >= SOC_LT_LONE_LAUNCH)) {
         // a single launch on a hierarchy: the direct kernel is as fast (1.9e10 vs 2.0e10 steps/s at 256^3, 4 levels)
@@ -722,7 +722,7 @@ static void fill_sim(soc_ctx *c, SocSim &S, SocVariant &V, int SOURCE, int BATCH
     V.octree = c->G.LEVELS > 1;
     V.dbl = c->G.NX > ((c->G.LEVELS < 3) ? 399 : 100);   // DIMLIM, kernel_ASOC_aux.c:25-37
     V.abu = c->dOPT != nullptr;
-    V.wint = c->with_int ? 1 : 0;
+    V.wint = c->with_int;                                  // 0, 1, or 2: INT and the vector sums (the brick-local sweep and the direct kernels)
 }
 
 // Point sources of one launch -> device.  xps_as_float: the scattered-light kernels declare
@@ -837,7 +837,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0))
                   && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
@@ -845,7 +845,7 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         return fail(c, SOC_ERR_ARG, "soc_sim_pb: brick sweep requested but not applicable (mirror, with_int 2, roisave/roiload, > 15 levels or > 2^18 bricks)");
     // inside soc_batch_begin/end a brick launch with scalar opacities and no INT tally is deferred:
     // its per-launch inputs are snapshotted (scattering table, sources) and it runs with the others
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || (c->batch_keep_int && V.wint != 2) || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOURCE, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_pb: a batch with the INT tally holds launches of one kind");
@@ -1087,12 +1087,12 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
     // the brick sweep as for soc_sim_pb: the walk is SimRAM_PB's, only the creation of a packet differs
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2;
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0));
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_hp: brick sweep requested but not applicable (mirror, with_int 2, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || (c->batch_keep_int && V.wint != 2) || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_HP, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_hp: a batch with the INT tally holds launches of one kind");
@@ -1171,13 +1171,13 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
-    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && c->with_int != 2
+    bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0))
                   && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
         return fail(c, SOC_ERR_ARG, "soc_sim_cl: brick sweep requested but not applicable (mirror, with_int 2, USE_EMWEIGHT 2, ALI, roisave, > 15 levels or > 2^18 bricks)");
-    const bool defer = c->batching && bricks && (!V.wint || c->batch_keep_int || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
+    const bool defer = c->batching && bricks && (!V.wint || (c->batch_keep_int && V.wint != 2) || c->batch_share_int) && c->msf_ndust <= 1;   // WITH_MSF: per-species tables are not snapshotted
     if (!defer) FLUSH(c);
     if (defer && c->batch_keep_int && !same_sweep(c, SOC_SOURCE_CL, V.abu != 0))
         return fail(c, SOC_ERR_STATE, "soc_sim_cl: a batch with the INT tally holds launches of one kind");

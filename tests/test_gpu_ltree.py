@@ -186,3 +186,30 @@ def test_reflecting_faces_in_the_sweep(mask, kind, engine, oracle_soc):
     assert st["tally_events"] == n, "trajectories diverged from the oracle"
     assert_tally_close(Tg, T, rtol=1e-5)
     engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_intensity_vectors_in_the_sweep(kind, engine, oracle_soc):
+    """-D SAVE_INTENSITY=2 (kernel_ASOC.c:604-612, :724-732): INT and the vector sums INTX, INTY, INTZ beside TABS in the LDS of the
+    walk (24 B per cell: smaller bricks), the scattering block's deposits from the event workgroups; background and cell emission"""
+    cl = cloud104()
+    if kind == 0:
+        job = Job(cl, cases._CSC, ABS=3e-5, SCA=6e-5, SOURCE=1, BATCH=3, SEED=0.377, WITH_INT=2, TW=1.7)
+        g0, g1 = 100000, 106000
+    else:
+        emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+        job = Job(cl, cases._CSC, ABS=3e-5, SCA=6e-5, SOURCE=2, BATCH=1, SEED=0.9, GLOBAL=8192, EMIT=emit, WITH_INT=2)
+        g0, g1 = 4000, 4064
+    T, I, n = oracle_soc.sim(job, kind, gid0=g0, gid1=g1, nthreads=8)
+    want = np.array(job.INTV, np.float32).copy()
+    Tg, Ig, st = _sweep(engine, job, kind, gid_first=g0, gid_count=g1 - g0)
+    assert st["tally_events"] == n and st["scatterings"] > 100
+    assert_tally_close(Tg, T, rtol=1e-5)
+    assert_tally_close(Ig, I, rtol=1e-5)
+    assert np.abs(want).sum() > 0
+    for k in range(3):      # signed sums: the error is measured against the sum of the absolute terms, INT (as tests/test_gpu_parity.py)
+        got = engine.read_tally(3 + k)
+        assert np.abs(got - want[k]).max() <= 2e-6 * np.abs(I).max()
+        assert np.all(np.abs(got - want[k]) <= 1e-5 * np.maximum(I, 1e-3 * I.max()))
+    engine.set_features(0, 0, 0)
+    engine.set_exec(-1, 4)
