@@ -136,6 +136,15 @@ class Pipeline:
         U.file_optical = [d if k != 'gsetdust' else simple_name(d) for d, k in zip(self.dusts, self.kinds)]
         self.want_maps = not U.NOMAP
         self.want_solve = True
+        # what stage 2 needs, checked before any GPU work (the transfer run of a large model takes minutes): a solver file per
+        # stochastically heated dust -- soc_amd.a2e_pre writes them (ASOC_driver.py:196-228 calls A2E_pre.py there) -- and no dust
+        # re-emission iterations, which this in-memory pipeline does not do
+        if U.ITERATIONS > 0 and U.CLPAC > 0:
+            raise UnsupportedOption("cellpackets (dust re-emission iterations) inside the pipeline: run soc_amd.asoc per iteration")
+        for d, k in zip(self.dusts, self.kinds):
+            if k == 'gsetdust' and not os.path.exists(solver_name(d)):
+                raise FileNotFoundError("%s: the solver file of %s is missing; write it with python -m soc_amd.a2e_pre %s <frequency file> %s"
+                                        % (solver_name(d), d, d, solver_name(d)))
         U.NOABSORBED, U.NOMAP, U.NOSOLVE = 0, 1, 1            # rt_simple.ini: absorptions per frequency, nomap, nosolve
         self.verbose = U.VERBOSE if verbose is None else verbose
         self.timers = {}

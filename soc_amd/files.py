@@ -23,8 +23,16 @@ def read_cloud(filename, kdensity=1.0, max_levels=999):
         NX, NY, NZ, LEVELS, CELLS = [int(v) for v in hdr]
         if LEVELS > max_levels:
             # keyword `levels`: the hierarchy is cut, the new cloud written beside the old one and used (ASOC_aux.py:748-761)
+            # Every rank of a torch.distributed run comes here at the same time: each writes the (identical) cut cloud under a name
+            # of its own and moves it into place -- os.replace is atomic, so no reader ever sees a truncated file.
             newname = '%s.MAX%d' % (filename, max_levels)
-            cut_levels(filename, newname, max_levels - 1)
+            tmpname = '%s.tmp.%d' % (newname, os.getpid())
+            try:
+                cut_levels(filename, tmpname, max_levels - 1)
+                os.replace(tmpname, newname)
+            finally:
+                if os.path.exists(tmpname):
+                    os.remove(tmpname)
             return read_cloud(newname, kdensity, max_levels)
         H = []
         for level in range(LEVELS):
