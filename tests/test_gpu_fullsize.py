@@ -335,6 +335,58 @@ def test_c4_scattered_light_on_the_c3_geometry(engine, c3):
     engine.set_emission(emit)
 
 
+def test_c4_rays_in_one_batch_equal_the_direct_kernel(engine, c3):
+    """Config 4 as soc_amd.asocs runs it on this geometry: the launches of a source block deferred into ONE sweep of rays on the
+    brick-local hierarchies (soc_batch_begin ... soc_batch_end, an image per frequency).  No oracle at this size; the direct kernel
+    (held to the oracle at oracle sizes, tests/test_gpu_sca.py) is the witness: integer counts equal, every image to summation order."""
+    import math
+    from soc_amd import launch
+    cloud = c3["cloud"]
+    N = cloud.NX
+    engine.set_cloud(cloud)
+    engine.set_features(0, 0, 0)
+    engine.set_mirror(0)
+    engine.set_opt(None)
+    th = [math.radians(30 + 25 * i) for i in range(3)]
+    ph = [math.radians(40 * i) for i in range(3)]
+    _, OD, RA, DE = launch.set_observer_directions(th, ph)
+    engine.sca_set_view(OD, RA, DE, (256, 256), 1.5, (N / 2, N / 2, N / 2), 1)
+    AREA = 6 * N * N
+    GLOBAL = launch.Fix(8 * AREA, 64)
+    emit = np.where(cloud.DENS > 0, 1.0e-3 * cloud.DENS, 0).astype(np.float32)
+    steps = [c3["step"](k) for k in (40, 60, 90)]                 # three frequencies: own opacities and scattering functions
+
+    def launches(f, s):
+        engine.set_optical(s["ABS"], s["SCA"])
+        engine.set_scatter_table(s["DSC"], s["CSC"])
+        engine.sca_sim_pb(1, 8 * AREA, 1, 0.31 + 0.1 * f, 1.0 + f, GLOBAL=GLOBAL)
+        engine.sca_sim_ps(1048576 * 2, 2, 0.32 + 0.1 * f, 0.0, s["PSPOS"], [float(s["PS"][0])], GLOBAL=1048576)
+        engine.set_emission(emit * np.float32(1 + f))
+        engine.sca_sim_cl(2, cloud.CELLS, 1, 0.33 + 0.1 * f, 4194304)
+
+    res = {}
+    for mode in (0, 1):
+        engine.set_exec(mode, 4)
+        engine.stats(reset=True)
+        engine.batch_begin(0)
+        engine.sca_batch_images(len(steps))
+        for f, s in enumerate(steps):
+            engine.sca_batch_select(f)
+            launches(f, s)
+        engine.batch_end()
+        st = engine.stats()
+        assert (engine.last_form() == 3) == (mode == 1)
+        res[mode] = (st, [engine.sca_batch_read(f) for f in range(len(steps))])
+        engine.sca_batch_images(0)
+    engine.set_exec(-1, 4)
+    assert res[0][0] == res[1][0] and res[0][0]["packets"] == 3 * (8 * AREA + 2 * 1048576 + cloud.CELLS)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.isfinite(b).all() and b.sum() > 0
+        tol = 2e-5 * np.abs(a) + 1e-9 * a.max()
+        assert (np.abs(b - a) <= tol).mean() > 0.9999 and abs(b.sum(dtype=np.float64) / a.sum(dtype=np.float64) - 1) < 1e-6
+    engine.set_emission(emit)
+
+
 def test_c5_stochastic_heating_at_its_stated_size(engine, c3, oracle_soc):
     """BASELINE configs[4] at its stated size: 128 enthalpy bins x 50 frequencies, absorptions of 65536 cells taken from a
     point-source launch on the config-3 geometry (so that the dynamic range is the real one: cells next to the source
