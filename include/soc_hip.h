@@ -382,6 +382,18 @@ int soc_a2e_upload(soc_ctx *ctx, int batch, const float *AABS);
 int soc_a2e_run(soc_ctx *ctx, int batch);
 int soc_a2e_download(soc_ctx *ctx, int batch, float *AEMIT);
 
+/* The same with the cells RESIDENT in device memory.  The reference uploads every batch of cells once per grain size and adds the
+ * sizes' emission up on the host (A2E.py:520-600: NSIZE x (absorptions in + emission out) over PCIe); a model's absorptions are
+ * 4*NFREQ bytes per cell (config 3: 9.9 GB) and fit the device many times over.  soc_a2e_resident_begin(cells, NFREQ) allocates them
+ * and a zeroed emission sum; _upload(c0, n, ABS) fills rows [c0, c0+n) (any chunking, e.g. from a memory-mapped absorbed file);
+ * after every soc_a2e_set_size, _solve() runs DoSolve over all cells and ADDS the emission of that size to the sum -- the same fp32
+ * additions in the same order as the host's EMITTED += emit; _download(c0, n, EMIT) reads rows of the sum; _end() frees both. */
+int soc_a2e_resident_begin(soc_ctx *ctx, int64_t cells, int NFREQ);
+int soc_a2e_resident_upload(soc_ctx *ctx, int64_t c0, int64_t n, const float *AABS);
+int soc_a2e_resident_solve(soc_ctx *ctx);
+int soc_a2e_resident_download(soc_ctx *ctx, int64_t c0, int64_t n, float *AEMIT);
+int soc_a2e_resident_end(soc_ctx *ctx);
+
 /* replaces kernel_T(...) = EqTemperature for one batch (A2E.py:511-530 -> kernel_A2E.c:110-154);
  * TTT holds NIP temperatures, ABS is [batch*NFREQ] (already multiplied by AF on the host),
  * outputs T[batch] and EMIT[batch*NFREQ] */

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(A2E_T) void soc_a2e_dosolve_kernel(const SocA2EArgs
             const int ib = A.Ibeg[f];
 #pragma unroll 8
             for (int i = ib; i < NE; i++) I += ea[(size_t)i * NFREQ] * XL[i];
-            EMIT[f] = I;
+            EMIT[f] = A.accumulate ? (EMIT[f] + I) : I;       // (the host's EMITTED += emit of A2E.py:596-600, size after size: the same fp32 additions)
         }
     }
     A2E_PROF(4);                                         // emission

@@ -116,6 +116,8 @@ struct soc_ctx {
     // A2E
     int a2e_NE = 0, a2e_NFREQ = 0, a2e_npair = 0, a2e_cap = 0, a2e_noIw = 0;
     float *aIw = nullptr, *aTdown = nullptr, *aEA = nullptr, *aAF = nullptr, *aABS = nullptr, *aEMIT = nullptr;
+    float *aAll = nullptr, *aSum = nullptr;                  // soc_a2e_resident_*: absorptions of all cells, emission summed over the sizes
+    int64_t a2e_cells = 0;  int a2e_res_nfreq = 0;
     int   *aFirst = nullptr, *aLast = nullptr, *aIwOff = nullptr, *aDst = nullptr, *aIbeg = nullptr;
 };
 
@@ -315,7 +317,7 @@ void soc_destroy(soc_ctx *c)
     for (float *q : c->dEMITslot) if (q) (void)hipFree(q);
     for (float *q : c->dINTslot) if (q) (void)hipFree(q);
     void *bufs[] = { c->dHPslots, c->dOPTslots, c->dABU, c->dAF, c->dRoi, c->dRoiSave, c->dRoiLoad, c->dDENS, c->dPAR, c->dCSC, c->dDSC, c->dOPT, c->dEMIT, c->dEMWEI, c->dXAB, c->dINTV, c->dEMINDEX, c->dSeedTab, c->dStats, c->dODIR, c->dORA, c->dODE, c->dHPBG, c->dHPBGP, c->dT, c->dTTT, c->dEbuf, c->dEF, c->dMapEmit, c->dMap, c->dMapTau,
-                     c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
+                     c->aIw, c->aTdown, c->aEA, c->aAF, c->aABS, c->aEMIT, c->aAll, c->aSum, c->aFirst, c->aLast, c->aIwOff, c->aDst, c->aIbeg };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_TABS && c->dTABS) (void)hipFree(c->dTABS);
     if (c->own_INT && c->dINT) (void)hipFree(c->dINT);
@@ -1925,6 +1927,78 @@ int soc_a2e_download(soc_ctx *c, int batch, float *AEMIT)
     if (batch < 1 || batch > c->a2e_cap) return fail(c, SOC_ERR_ARG, "soc_a2e_download: batch = %d", batch);
     HIPCHK(c, hipMemcpyAsync(AEMIT, c->aEMIT, (size_t)batch * c->a2e_NFREQ * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+// ---- config 5 with the cells resident in HBM ----
+int soc_a2e_resident_begin(soc_ctx *c, int64_t cells, int NFREQ)
+{
+    if (!c) return SOC_ERR_ARG;
+    FLUSH(c);
+    if (cells < 1 || NFREQ < 2 || cells > (int64_t)2147483647) return fail(c, SOC_ERR_ARG, "soc_a2e_resident_begin: cells=%lld NFREQ=%d", (long long)cells, NFREQ);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)cells * NFREQ * 8;
+    if (need + ((size_t)1 << 30) > free_b + (c->aAll ? (size_t)c->a2e_cells * c->a2e_res_nfreq * 8 : 0))
+        return fail(c, SOC_ERR_STATE, "soc_a2e_resident_begin: %lld cells x %d frequencies need %.1f GB of device memory, %.1f GB are free (use soc_a2e_solve in batches)",
+                    (long long)cells, NFREQ, need * 1e-9, free_b * 1e-9);
+    HIPCHK(c, dev_alloc(&c->aAll, (size_t)cells * NFREQ));
+    HIPCHK(c, dev_alloc(&c->aSum, (size_t)cells * NFREQ));
+    HIPCHK(c, hipMemsetAsync(c->aSum, 0, (size_t)cells * NFREQ * 4, c->stream));
+    c->a2e_cells = cells;  c->a2e_res_nfreq = NFREQ;
+    return SOC_OK;
+}
+
+int soc_a2e_resident_upload(soc_ctx *c, int64_t c0, int64_t n, const float *AABS)
+{
+    if (!c || !AABS) return SOC_ERR_ARG;
+    if (!c->aAll || c0 < 0 || n < 1 || c0 + n > c->a2e_cells) return fail(c, SOC_ERR_ARG, "soc_a2e_resident_upload: cells [%lld, %lld) of %lld", (long long)c0, (long long)(c0 + n), (long long)c->a2e_cells);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->aAll + (size_t)c0 * c->a2e_res_nfreq, AABS, (size_t)n * c->a2e_res_nfreq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));             // (the host buffer may be a temporary)
+    return SOC_OK;
+}
+
+int soc_a2e_resident_solve(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!c->aAll) return fail(c, SOC_ERR_STATE, "soc_a2e_resident_solve: call soc_a2e_resident_begin first");
+    if (c->a2e_NE == 0 || c->a2e_NFREQ != c->a2e_res_nfreq) return fail(c, SOC_ERR_STATE, "soc_a2e_resident_solve: soc_a2e_set_size with NFREQ = %d first", c->a2e_res_nfreq);
+    HIPCHK(c, hipSetDevice(c->device));
+    SocA2EArgs A{};
+    A.NE = c->a2e_NE;  A.NFREQ = c->a2e_NFREQ;  A.npair = c->a2e_npair;
+    A.Iw = c->aIw;  A.pair_first = c->aFirst;  A.pair_last = c->aLast;  A.pair_iw = c->aIwOff;  A.pair_dst = c->aDst;
+    A.Tdown = c->aTdown;  A.EA = c->aEA;  A.Ibeg = c->aIbeg;  A.AF = c->aAF;
+    A.accumulate = 1;
+    const int64_t step = 1 << 20;                           // cells per launch (the grid is one workgroup per four cells)
+    for (int64_t c0 = 0; c0 < c->a2e_cells; c0 += step) {
+        A.batch = (int)std::min<int64_t>(step, c->a2e_cells - c0);
+        A.AABS = c->aAll + (size_t)c0 * A.NFREQ;  A.AEMIT = c->aSum + (size_t)c0 * A.NFREQ;
+        HIPCHK(c, soc_launch_a2e_dosolve(A, c->stream));
+    }
+    return SOC_OK;
+}
+
+int soc_a2e_resident_download(soc_ctx *c, int64_t c0, int64_t n, float *AEMIT)
+{
+    if (!c || !AEMIT) return SOC_ERR_ARG;
+    if (!c->aSum || c0 < 0 || n < 1 || c0 + n > c->a2e_cells) return fail(c, SOC_ERR_ARG, "soc_a2e_resident_download: cells [%lld, %lld) of %lld", (long long)c0, (long long)(c0 + n), (long long)c->a2e_cells);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(AEMIT, c->aSum + (size_t)c0 * c->a2e_res_nfreq, (size_t)n * c->a2e_res_nfreq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SOC_OK;
+}
+
+int soc_a2e_resident_end(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->aAll) { (void)hipFree(c->aAll);  c->aAll = nullptr; }
+    if (c->aSum) { (void)hipFree(c->aSum);  c->aSum = nullptr; }
+    c->a2e_cells = 0;
     return SOC_OK;
 }
 

@@ -155,6 +155,7 @@ struct SocA2EArgs {
     const float *AF;                 // [NFREQ]
     const float *AABS;               // [batch*NFREQ]
     float       *AEMIT;              // [batch*NFREQ]
+    int          accumulate;         // 1: AEMIT += the emission of this size (the sum over the sizes stays on the device: soc_a2e_resident_*)
 };
 
 struct SocEqTArgs {

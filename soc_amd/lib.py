@@ -103,6 +103,11 @@ API = {
     "soc_a2e_upload": (C.c_int, [C.c_void_p, C.c_int, _F]),
     "soc_a2e_run": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_a2e_download": (C.c_int, [C.c_void_p, C.c_int, _F]),
+    "soc_a2e_resident_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "soc_a2e_resident_upload": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _F]),
+    "soc_a2e_resident_solve": (C.c_int, [C.c_void_p]),
+    "soc_a2e_resident_download": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _F]),
+    "soc_a2e_resident_end": (C.c_int, [C.c_void_p]),
     "soc_a2e_eqtemp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, _F, _F, _F, _F, _F, _F]),
     "soc_eqsolver": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -649,6 +654,26 @@ class Engine:
     def a2e_upload(self, AABS):
         AABS = np.ascontiguousarray(AABS, np.float32)
         self._chk(self.lib.soc_a2e_upload(self.h, AABS.shape[0], _f(AABS)))
+
+    # the cells resident in device memory: absorptions up once, the sum over the sizes down once (soc_a2e_resident_*)
+    def a2e_resident_begin(self, cells, NFREQ):
+        self._chk(self.lib.soc_a2e_resident_begin(self.h, int(cells), int(NFREQ)))
+        self._a2e_res = (int(cells), int(NFREQ))
+
+    def a2e_resident_upload(self, c0, AABS):
+        AABS = np.ascontiguousarray(AABS, np.float32)
+        self._chk(self.lib.soc_a2e_resident_upload(self.h, int(c0), AABS.shape[0], _f(AABS)))
+
+    def a2e_resident_solve(self):
+        self._chk(self.lib.soc_a2e_resident_solve(self.h))
+
+    def a2e_resident_download(self, c0, n, out=None):
+        out = np.zeros((int(n), self._a2e_res[1]), np.float32) if out is None else out
+        self._chk(self.lib.soc_a2e_resident_download(self.h, int(c0), int(n), _f(out)))
+        return out
+
+    def a2e_resident_end(self):
+        self._chk(self.lib.soc_a2e_resident_end(self.h))
 
     def a2e_run(self, batch):
         self._chk(self.lib.soc_a2e_run(self.h, int(batch)))

@@ -155,6 +155,40 @@ def test_gpu_a2e_host_program(engine, oracle_soc, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_a2e_resident_cells_equal_the_batches_to_the_bit(engine):
+    """soc_a2e_resident_*: the absorptions of all cells in device memory, every size one launch that adds to the emission sum there
+    (what a2e.run does where the memory allows) against the reference's shape -- a batch up, a size, a batch down, the host adds."""
+    from soc_amd import a2e
+    sol = synth.synth_solver(NFREQ=12, NE=16, NSIZE=4, seed=7)
+    rng = np.random.default_rng(9)
+    ABS = (rng.lognormal(0, 1, (1000, 12)) * 1e-3).astype(np.float32)
+
+    class Batches:                                        # the engine without the resident calls
+        def __getattr__(self, name):
+            if name.startswith("a2e_resident"):
+                raise AttributeError(name)
+            return getattr(engine, name)
+    for ifreq in (-1, 5):
+        got, _ = a2e.run(engine, sol, ABS, NSTOCH=3, IFREQ=ifreq, batch=256, verbose=False)
+        want, _ = a2e.run(Batches(), sol, ABS, NSTOCH=3, IFREQ=ifreq, batch=256, verbose=False)
+        assert np.isfinite(got).all() and got.any()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # chunked upload / download at odd offsets, and the refusals
+    engine.a2e_resident_begin(1000, 12)
+    engine.a2e_resident_upload(0, ABS[:333])
+    engine.a2e_resident_upload(333, ABS[333:])
+    with pytest.raises(Exception):
+        engine.a2e_resident_upload(900, ABS[:200])
+    engine.a2e_set_size(16, 12, sol["sizes"][0], synth.a2e_absorption_fraction(sol, 0))
+    engine.a2e_resident_solve()
+    one = engine.a2e_solve(ABS)
+    assert np.array_equal(engine.a2e_resident_download(17, 500).view(np.uint32), one[17:517].view(np.uint32))
+    engine.a2e_resident_end()
+    with pytest.raises(Exception):
+        engine.a2e_resident_solve()
+
+
+@pytest.mark.gpu
 def test_gpu_a2e_sharded_program_equals_in_memory_run(engine, tmp_path):
     """python -m soc_amd.a2e: memory-mapped absorbed file, this rank's cell range, its part of the emitted file"""
     from soc_amd import a2e, files

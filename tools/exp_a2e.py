@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--nfreq", type=int, default=50)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--program", type=int, nargs=2, metavar=("CELLS", "NSIZE"), default=None,
+                    help="also time soc_amd.a2e.run end to end (host arrays in, host array out) for CELLS cells and NSIZE sizes: with the cells resident on the device, and in batches as the reference does")
     a = ap.parse_args()
     prof = None
     if os.environ.get("SOC_HIP_LIB"):                     # a -DSOC_A2E_PROF build (tools/build_prof.sh): cycles per phase
@@ -65,6 +67,27 @@ def main():
                                    "unit": "GB/s", "frac": alg / k * 1e-6 / 8000.0},
                       "note": "LDS/latency-bound: the transition matrix (NE^2/2 floats per cell) never leaves LDS",
                       "finite": bool(np.isfinite(out).all())}))
+    if a.program:
+        from soc_amd import a2e
+        cells, nsize = a.program
+        sol = synth.synth_solver(NFREQ=a.nfreq, NE=a.ne, NSIZE=nsize, seed=5)
+        ABS = (rng.lognormal(0, 1, (cells, a.nfreq)) * 1e-3 * (sol['FREQ'][None, :] / 1e13) ** -1.0).astype(np.float32)
+
+        class Batches:
+            def __getattr__(self, name):
+                if name.startswith("a2e_resident"):
+                    raise AttributeError(name)
+                return getattr(eng, name)
+        res = {}
+        for tag, e in (("resident", eng), ("batches", Batches())):
+            t0 = time.time()
+            E, _ = a2e.run(e, sol, ABS, verbose=False)
+            res[tag] = (time.time() - t0, E)
+        same = bool(np.array_equal(res["resident"][1].view(np.uint32), res["batches"][1].view(np.uint32)))
+        print(json.dumps({"program": "soc_amd.a2e.run, host arrays in and out", "NE": a.ne, "NFREQ": a.nfreq, "cells": cells, "sizes": nsize,
+                          "resident_s": res["resident"][0], "resident_cell_sizes_per_s": cells * nsize / res["resident"][0],
+                          "batches_s": res["batches"][0], "batches_cell_sizes_per_s": cells * nsize / res["batches"][0],
+                          "bit_identical": same}))
     eng.close()
 
 
