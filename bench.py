@@ -28,9 +28,11 @@ reference's simulation loop (source block II x frequency IFREQ, ASOC.py:1028-146
 The K steps are handed to the engine together (soc_batch_begin/end): on the config-3 hierarchy point-source and diffuse
 launches share one brick sweep (up to 128 launches: the two source blocks of a 50-frequency run, ASOC.py:1028-1545).
 
-Multi-GPU: --scaling strong (default for N > 1) splits the work items of every launch across the ranks
-(identical result to one GPU) with one RCCL all-reduce of the per-cell absorption buffer per
-sweep; --scaling weak runs one replica per rank with the reference's per-device seed term (ASOC.py:1247).
+Multi-GPU: photon packets are independent units, so the default (--scaling auto = weak) keeps the per-GPU work fixed: every rank
+runs the K steps with the reference's per-device seed term and the weight 1/N of its multi-device design (ASOC.py:180,1247,1501) -- N
+times the packets, the same per-rank population as one GPU -- and ONE RCCL all-reduce of the per-cell absorption buffer after the
+timed sweeps.  --scaling strong splits the work items of every launch across the ranks (identical result to one GPU),
+--scaling launches gives every rank a share of the launch (frequency) sequence; both fix the total work.
 
 Inputs are resident in HBM before the timed region.  Rank 0 prints one JSON line.
 """
@@ -199,9 +201,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong", "launches", "auto"], default="auto",
-                    help="auto = strong for N > 1 (work-item ranges of every launch: equal packets and events per rank); launches = "
-                         "every rank a contiguous share of the launch sequence (whole launches + a work-item range at either end); "
-                         "weak = replicas with per-rank seeds")
+                    help="auto = weak: per-GPU work fixed, every rank the K steps with per-rank seeds and weight 1/N (the reference's multi-device "
+                         "design); strong = work-item ranges of every launch (total work fixed, identical result to one GPU); launches = "
+                         "every rank a contiguous share of the launch sequence (whole launches + a work-item range at either end)")
     ap.add_argument("--separate-kinds", action="store_true", help="point-source and diffuse launches in sweeps of their own (as in round 2)")
     ap.add_argument("--first-step", type=int, default=-1,
                     help="index of the first timed step (default: the number of warm-up steps, i.e. the steps follow the warm-up); "
@@ -229,7 +231,7 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     if args.scaling == "auto":
-        args.scaling = "strong" if world > 1 else "weak"
+        args.scaling = "weak"
 
     dist = None
     torch = None
