@@ -204,6 +204,7 @@ def main():
                     help="auto = weak: per-GPU work fixed, every rank the K steps with per-rank seeds and weight 1/N (the reference's multi-device "
                          "design); strong = work-item ranges of every launch (total work fixed, identical result to one GPU); launches = "
                          "every rank a contiguous share of the launch sequence (whole launches + a work-item range at either end)")
+    ap.add_argument("--int-groups", type=int, default=1, help="C3INT: frequencies (each with its own INT tally) per sweep; soc_amd.asoc runs absorbed-file runs on hierarchies with 1 (more was measured slower: the brick queues are per frequency)")
     ap.add_argument("--separate-kinds", action="store_true", help="point-source and diffuse launches in sweeps of their own (as in round 2)")
     ap.add_argument("--first-step", type=int, default=-1,
                     help="index of the first timed step (default: the number of warm-up steps, i.e. the steps follow the warm-up); "
@@ -303,10 +304,14 @@ def main():
                 chunks.append([])
             chunks[-1].append(m)
         eng.timer_start()
-        for chunk in chunks:
+        open_groups = 0                                             # C3INT: frequencies (INT tallies) deferred into the current sweep
+        for ic, chunk in enumerate(chunks):
             if keep_int:
-                eng.zero(1)
-                eng.batch_begin_shared_int(len(chunk))
+                # the launches of one frequency share an INT tally; up to --int-groups frequencies share a sweep
+                if open_groups == 0:
+                    eng.batch_begin_int_groups(args.int_groups)
+                eng.batch_next_int()
+                open_groups += 1
             else:
                 eng.batch_begin(len(chunk))
             for i, first, count in chunk:
@@ -323,9 +328,14 @@ def main():
                 else:
                     eng.sim_pb(1, L["PACKETS"], L["BATCH"], seed, np.float32(s["BG"] * KDEV), s["TW"],
                                GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
-            eng.batch_end()
             if keep_int:
-                eng.read_tally(1)                                   # the frequency's column of the absorbed file (device -> host, as ASOC.py:1482)
+                if open_groups >= args.int_groups or ic == len(chunks) - 1:
+                    eng.batch_end()
+                    for k in range(open_groups):
+                        eng.batch_read_int(k)                       # a frequency's column of the absorbed file (device -> host, as ASOC.py:1482)
+                    open_groups = 0
+            else:
+                eng.batch_end()
         if world > 1:
             # TABS integrates over frequency on the device (ASOC.py:1533): one all-reduce per source block, here per call.
             # The local tally is the rank's share only, so the sum over ranks is the one-GPU tally (to summation order).
@@ -429,7 +439,7 @@ def main():
                        "cells": cloud.CELLS, "tally_events_per_packet": events_rank / max(packets_rank, 1),
                        "scatterings_per_packet": scat_rank / max(packets_rank, 1),
                        "frequencies_in_the_timed_steps": freqs,
-                       "launches_per_sweep": "the two launches of a frequency (one INT tally)" if keep_int else (
+                       "launches_per_sweep": ("the launches of %d frequenc%s, an INT tally per frequency (soc_batch_begin_int_groups)" % (args.int_groups, "y" if args.int_groups == 1 else "ies")) if keep_int else (
                            args.in_flight if args.in_flight else "all steps in one sweep (point-source and diffuse launches together; at most 128)"),
                        "work_items_in_flight_rank0": inflight[0],
                        "parallelism": "1 process per GPU; %s" % (

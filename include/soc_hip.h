@@ -184,6 +184,12 @@ int soc_batch_begin_int(soc_ctx *ctx, int max_launches);
  * in LDS per workgroup, the same brick queues.  Replaces the per-launch enqueue + finish() + enqueue_copy(INT) of ASOC.py:1360-1372,
  * :1461, :1482-1498 for the launches of one frequency. */
 int soc_batch_begin_shared_int(soc_ctx *ctx, int max_launches);
+/* Several frequencies in one sweep, each with its own INT tally: as soc_batch_begin_int, but the launches between two
+ * soc_batch_next_int calls -- the source blocks of ONE frequency -- share a tally (soc_batch_read_int(k) reads the k-th group's).
+ * On brick-local hierarchies the brick queues are per group, so a workgroup's LDS tallies belong to one frequency; point-source,
+ * background and cell-emission launches mix freely.  At most max_groups groups (0: 128) until soc_batch_end. */
+int soc_batch_begin_int_groups(soc_ctx *ctx, int max_groups);
+int soc_batch_next_int(soc_ctx *ctx);
 int soc_batch_read_int(soc_ctx *ctx, int k, float *out, long n);
 
 /* ---- region of interest of nested runs (ini keys roi, roisave, roiload, roipac, roinside) ---- */

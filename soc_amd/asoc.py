@@ -500,12 +500,36 @@ class AbsorptionRun:
             self.ROI_SAVE.flush()
         return CTABS, FABSORBED
 
+    # Frequencies of an absorbed-file run on a hierarchy that share a sweep (an INT tally and, for cell emission, a copy of the emission each).
+    # Measured on config 3 (bench.py --workload C3INT --int-groups 4): 2.00e8 packets/s against 2.09e8 with one frequency per sweep -- the
+    # brick queues are per frequency (a workgroup's LDS tallies belong to one INT array), so more frequencies mean more queues of the same
+    # length, not longer ones; the default stays 1.
+    FREQS_PER_SWEEP = 1
+
     def _simulate_by_frequency(self, CTABS, FABSORBED, shares, owned, rng):
         """for IFREQ: for II in (point sources, background, diffuse): launch -- the loop of ASOC.py:1028-1545 with the frequency
         outside, for runs that keep the per-frequency absorptions: the launches of one frequency are one batch with one INT
-        tally.  TABS integrates over everything on the device and is read once (CTABS is the sum over the blocks anyway)."""
+        tally.  TABS integrates over everything on the device and is read once (CTABS is the sum over the blocks anyway).
+        Where the engine has them, groups: up to FREQS_PER_SWEEP frequencies are deferred into one sweep, each with its own INT tally
+        (soc_batch_begin_int_groups / soc_batch_next_int) -- that many times the packets per brick and pass -- and read after it."""
         U, e, c = self.U, self.eng, self.cloud
         CELLS, NFREQ, FFREQ = c.CELLS, self.NFREQ, self.FFREQ
+        grouped = hasattr(e, "batch_begin_int_groups")
+        pend = []
+
+        def end_sweep():
+            t0 = time.time()
+            e.batch_end()
+            e.sync()
+            self.timers["Tkernel"] += time.time() - t0
+            t0 = time.time()
+            for k, f in enumerate(pend):
+                arr = e.batch_read_int(k)
+                if self.comm and self.world > 1 and not owned:
+                    arr = self.comm.all_reduce_host(arr)      # the per-cell buffer of one frequency, summed over the ranks
+                FABSORBED[:, f] += arr[0::self.absthin]
+            self.timers["Tpull"] += time.time() - t0
+            del pend[:]
         blocks = [(II, self._constant_launch(II)) for II in range(3)]
         blocks = [(II, L) for II, L in blocks if L is not None]
         for II, L in blocks:
@@ -531,8 +555,13 @@ class AbsorptionRun:
             mine = [m for m in mine if m[3] > 0]
             if not mine:
                 continue                                  # another rank's frequency
-            e.zero(1)
-            e.batch_begin_shared_int(len(mine))
+            if grouped:
+                if not pend:
+                    e.batch_begin_int_groups(self.FREQS_PER_SWEEP)
+                e.batch_next_int()
+            else:
+                e.zero(1)
+                e.batch_begin_shared_int(len(mine))
             self.timers["Tpush"] += time.time() - t0
             for II, L, first, count in mine:
                 t0 = time.time()
@@ -557,17 +586,24 @@ class AbsorptionRun:
                              GLOBAL=L["GLOBAL"], gid_first=first, gid_count=count)
                 self.timers["Tkernel"] += time.time() - t0
                 self.packets += L["PACKETS"]
-            t0 = time.time()
-            e.batch_end()
-            e.sync()
-            if self.comm and not owned:
-                self.comm.all_reduce_tally(e, 1)          # one all-reduce of the per-cell buffer per frequency
-            self.timers["Tkernel"] += time.time() - t0
-            t0 = time.time()
-            FABSORBED[:, IFREQ] += e.read_tally(1)[0::self.absthin]
-            self.timers["Tpull"] += time.time() - t0
+            if grouped:
+                pend.append(IFREQ)
+                if len(pend) >= self.FREQS_PER_SWEEP:
+                    end_sweep()
+            else:
+                t0 = time.time()
+                e.batch_end()
+                e.sync()
+                if self.comm and not owned:
+                    self.comm.all_reduce_tally(e, 1)          # one all-reduce of the per-cell buffer per frequency
+                self.timers["Tkernel"] += time.time() - t0
+                t0 = time.time()
+                FABSORBED[:, IFREQ] += e.read_tally(1)[0::self.absthin]
+                self.timers["Tpull"] += time.time() - t0
             if self.verbose and self.rank == 0:
                 print("  FREQ %3d/%3d  %10.3e   TW %10.3e" % (IFREQ + 1, NFREQ, FREQ, FF))
+        if pend:
+            end_sweep()
         if self.comm:
             self.comm.all_reduce_tally(e, 0)              # TABS: integrated over frequency and source blocks on the device
         t0 = time.time()

@@ -557,7 +557,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
             if (v != 0.0f || vi != 0.0f) {
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
+                if (WINT) soc_tally(K.S[K.gfirst[qbase / A.NB]].INT, cell, vi);      // the launches this workgroup's queue belongs to
             }
         }
     } else {
@@ -570,7 +570,7 @@ __device__ __forceinline__ void soc_brick_walk(const SocGrid &G, const SocSimPac
                 const int ix = bx * B + (i & M), iy = by * B + ((i >> A.LB) & M), iz = bz * B + (i >> (2 * A.LB));
                 const int cell = iz * NX * NY + iy * NX + ix;
                 soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
+                if (WINT) soc_tally(K.S[K.gfirst[qbase / A.NB]].INT, cell, vi);      // the launches this workgroup's queue belongs to
             }
         }
     }
@@ -888,9 +888,9 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
             if (v != 0.0f || vi != 0.0f) {
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
-                if (WINT) soc_tally(K.S[qbase / A.NB].INT, cell, vi);      // the launch this workgroup's queue belongs to
+                if (WINT) soc_tally(K.S[K.gfirst[qbase / A.NB]].INT, cell, vi);      // the launches this workgroup's queue belongs to
                 if (WINT == 2) {
-                    float *IV = K.S[qbase / A.NB].INTV;
+                    float *IV = K.S[K.gfirst[qbase / A.NB]].INTV;
                     const long C = K.S[0].CELLS;
                     soc_tally(IV, cell, sV[i]);  soc_tally(IV + C, cell, sV[BV + i]);  soc_tally(IV + 2 * C, cell, sV[2 * BV + i]);
                 }
@@ -937,7 +937,7 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
     // KIND 4: launches of several kinds share the sweep, the kind is the launch's (uniform in the workgroup: an event queue belongs to one launch)
     const int  skind = (KIND == 4) ? ((S.SOURCE == SOC_SOURCE_CL) ? 2 : (S.SOURCE == SOC_SOURCE_HP) ? 1 : 0) : KIND;
     const bool CL = (skind == 2), HP = (skind == 1);
-    const int qbase = (A.NBQ > A.NB) ? lq * A.NB : 0;      // first brick queue of this launch
+    const int qbase = (A.NBQ > A.NB) ? K.grp[lq] * A.NB : 0;      // first brick queue of this launch's group
     extern __shared__ float lds[];
     int   *sH   = (int *)lds;                              // arrivals per queue
     int   *sCtl = sH + (A.HS ? 2 * A.HS : NQ);             // [0..2] stats
@@ -2101,10 +2101,16 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     }
     // launches with the INT tally: brick queues per launch, so that a workgroup's LDS tallies belong to one launch
     // (launches that tally into ONE INT array -- the source blocks of one frequency, soc_batch_begin_shared_int -- share the queues)
-    bool own_int = false;
-    for (int l = 1; l < K.n; l++) own_int = own_int || (K.S[l].INT != K.S[0].INT);
-    A.NBQ = (V.wint && K.n > 1 && own_int) ? A.NB * K.n : A.NB;
-    if ((long long)A.NB * K.n > (1 << 20)) return hipErrorNotSupported;
+    int ngrp = 0;
+    for (int l = 0; l < K.n; l++) {
+        int g = 0;
+        while (g < ngrp && K.S[K.gfirst[g]].INT != K.S[l].INT) g++;
+        if (g == ngrp) K.gfirst[ngrp++] = l;
+        K.grp[l] = g;
+    }
+    if (!V.wint) { ngrp = 1;  for (int l = 0; l < K.n; l++) K.grp[l] = 0; }
+    A.NBQ = (ngrp > 1) ? A.NB * ngrp : A.NB;
+    if ((long long)A.NB * ngrp > (1 << 20)) return hipErrorNotSupported;
     const int NQ = A.NBQ + A.EQ * K.n + 1;
     // packets in flight: `population` of them (0: all work items at once); the other work items are admitted, in
     // order, as earlier ones finish.  Queues, descriptors and the grids of the passes are sized for that many.

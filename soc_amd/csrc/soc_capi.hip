@@ -93,6 +93,8 @@ struct soc_ctx {
     int    int_slots_done = 0;                    // launches of the last executed sweep whose INT can be read
     bool   batch_keep_int = false;                // soc_batch_begin_int: deferred launches keep their own INT tally
     bool   batch_share_int = false;               // soc_batch_begin_shared_int: deferred launches tally into the handle's INT together
+    bool   batch_group_int = false;               // soc_batch_begin_int_groups: the launches between two soc_batch_next_int calls share an INT tally
+    bool   int_group_open = false;                // ... and the current group has its tally
     size_t emitslot_cells = 0;
     size_t optslot_cells = 0;
     int    csc_slot_bins = 0;
@@ -784,6 +786,10 @@ static int snapshot_inputs(soc_ctx *c, SocSim &S, const SocVariant &V, int slot)
 static int take_int_slot(soc_ctx *c, const char *who, SocSim &S)
 {
     if (!(c->batching && c->batch_keep_int && c->with_int)) return SOC_OK;
+    if (c->batch_group_int && c->int_group_open) {           // a further launch of the current group: the group's tally
+        S.INT = c->dINTslot[c->int_slots_done - 1];
+        return SOC_OK;
+    }
     if (c->int_slots_done >= c->batch_max)
         return fail(c, SOC_ERR_STATE, "%s: %d launches of this batch hold an INT tally; soc_batch_end and soc_batch_read_int first", who, c->batch_max);
     const size_t cells = (size_t)c->G.CELLS;
@@ -794,6 +800,7 @@ static int take_int_slot(soc_ctx *c, const char *who, SocSim &S)
     }
     if (!c->dINTslot[c->int_slots_done]) HIPCHK(c, dev_alloc(&c->dINTslot[c->int_slots_done], cells));
     S.INT = c->dINTslot[c->int_slots_done];
+    c->int_group_open = true;
     HIPCHK(c, hipMemsetAsync(S.INT, 0, cells * 4, c->stream));
     c->int_slots_done++;
     return SOC_OK;
@@ -809,7 +816,7 @@ static bool same_sweep(const soc_ctx *c, int source, bool abu)
     const int kp = (P.SOURCE == SOC_SOURCE_CL) ? 2 : (P.SOURCE == SOC_SOURCE_HP) ? 1 : 0;
     const int kn = (source == SOC_SOURCE_CL) ? 2 : (source == SOC_SOURCE_HP) ? 1 : 0;
     if ((P.OPT != nullptr) != abu) return false;
-    return kp == kn || (lt_capable(c, abu) && !c->batch_keep_int);
+    return kp == kn || lt_capable(c, abu);      // (brick-local hierarchies: the kinds share sweeps, also with per-group INT tallies)
 }
 
 int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float BG, float TW,
@@ -866,7 +873,8 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         r = snapshot_inputs(c, S, V, slot);
         if (r) return r;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
+        if ((!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max))
+            || (int)c->pending.size() >= SOC_MAXLAUNCH) FLUSH(c);      // (with INT tallies per launch or group: a sweep's worth of launches)
         return SOC_OK;
     }
     if (bricks) {
@@ -887,6 +895,8 @@ int soc_batch_begin(soc_ctx *c, int max_launches)
     c->batching = true;
     c->batch_keep_int = false;
     c->batch_share_int = false;
+    c->batch_group_int = false;
+    c->int_group_open = false;
     c->int_slots_done = 0;
     // default: as many as one sweep takes (the packets in flight are limited separately, see flush_pending)
     c->batch_max = max_launches ? max_launches : SOC_MAXLAUNCH;
@@ -898,6 +908,23 @@ int soc_batch_begin_int(soc_ctx *c, int max_launches)
     int r = soc_batch_begin(c, max_launches);
     if (r) return r;
     c->batch_keep_int = true;
+    return SOC_OK;
+}
+
+int soc_batch_begin_int_groups(soc_ctx *c, int max_groups)
+{
+    int r = soc_batch_begin(c, max_groups);
+    if (r) return r;
+    c->batch_keep_int = true;
+    c->batch_group_int = true;
+    return SOC_OK;
+}
+
+int soc_batch_next_int(soc_ctx *c)
+{
+    if (!c) return SOC_ERR_ARG;
+    if (!(c->batching && c->batch_group_int)) return fail(c, SOC_ERR_STATE, "soc_batch_next_int: call soc_batch_begin_int_groups first");
+    c->int_group_open = false;                               // the next launch takes a new, zeroed INT tally
     return SOC_OK;
 }
 
@@ -1113,7 +1140,8 @@ int soc_sim_hp(soc_ctx *c, int PACKETS, int BATCH, float SEED, float TW, int GLO
         HIPCHK(c, hipMemcpyAsync(sky + 49152, c->dHPBGP, 49152 * 4, hipMemcpyDeviceToDevice, c->stream));
         S.HPBG = sky;  S.HPBGP = sky + 49152;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
+        if ((!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max))
+            || (int)c->pending.size() >= SOC_MAXLAUNCH) FLUSH(c);      // (with INT tallies per launch or group: a sweep's worth of launches)
         return SOC_OK;
     }
     if (bricks) {
@@ -1195,7 +1223,8 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
         r = snapshot_emission(c, S, slot);
         if (r) return r;
         c->pending.push_back(S);
-        if (!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max)) FLUSH(c);
+        if ((!c->batch_keep_int && (int)c->pending.size() >= (V.abu ? std::min(c->batch_max, SOC_OPT_SLOTS) : c->batch_max))
+            || (int)c->pending.size() >= SOC_MAXLAUNCH) FLUSH(c);      // (with INT tallies per launch or group: a sweep's worth of launches)
         return SOC_OK;
     }
     if (bricks) {

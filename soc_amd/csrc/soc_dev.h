@@ -74,6 +74,10 @@ struct SocSim {
 #define SOC_MAXLAUNCH 128
 struct SocSimPack {
     int      n;
+    // launches that tally into one INT array form a group (the source blocks of one frequency): with several groups in a sweep the
+    // brick queues are per group -- a workgroup's LDS tallies then belong to one INT array -- queue = group * NB + brick
+    int      grp[SOC_MAXLAUNCH];         // group of every launch
+    int      gfirst[SOC_MAXLAUNCH];      // a launch of every group (for its INT / INTV pointers)
     uint32_t first[SOC_MAXLAUNCH + 1];
     SocSim   S[SOC_MAXLAUNCH];
 };

@@ -51,6 +51,8 @@ API = {
     "soc_batch_end": (C.c_int, [C.c_void_p]),
     "soc_batch_begin_int": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_batch_begin_shared_int": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_batch_begin_int_groups": (C.c_int, [C.c_void_p, C.c_int]),
+    "soc_batch_next_int": (C.c_int, [C.c_void_p]),
     "soc_batch_read_int": (C.c_int, [C.c_void_p, C.c_int, _F, C.c_long]),
     "soc_set_mirror": (C.c_int, [C.c_void_p, C.c_int]),
     "soc_set_hpbg": (C.c_int, [C.c_void_p, _F, _F]),
@@ -233,6 +235,14 @@ class Engine:
         """Launches until batch_end() that keep the INT tally are deferred too and tally into the handle's INT buffer together:
         the source blocks of one frequency (zero(1) before, read_tally(1) after)."""
         self._chk(self.lib.soc_batch_begin_shared_int(self.h, int(max_launches)))
+
+    def batch_begin_int_groups(self, max_groups=0):
+        """As batch_begin_int, but the launches between two batch_next_int() calls -- the source blocks of one frequency -- share an
+        INT tally; batch_read_int(k) reads the k-th group's after batch_end()."""
+        self._chk(self.lib.soc_batch_begin_int_groups(self.h, int(max_groups)))
+
+    def batch_next_int(self):
+        self._chk(self.lib.soc_batch_next_int(self.h))
 
     def batch_read_int(self, k):
         out = np.zeros(self.CELLS, np.float32)

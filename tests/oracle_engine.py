@@ -127,21 +127,33 @@ class OracleEngine:
     def batch_begin_int(self, max_launches=0):
         self._int_batch = []
         self._int_max = max_launches or 16
+        self._int_groups = False
+
+    def batch_begin_int_groups(self, max_groups=0):
+        self.batch_begin_int(max_groups or 128)
+        self._int_groups, self._int_open = True, False
+
+    def batch_next_int(self):
+        self._int_open = False
 
     def batch_end(self):
-        pass
+        if getattr(self, "_int_batch", None) is not None:
+            self._int_done, self._int_batch = self._int_batch, None     # launches after the batch tally into the shared INT again
 
     def batch_read_int(self, k):
-        return self._int_batch[k].copy()
+        return self._int_done[k].copy()
 
     def _int_target(self):
         """the INT array of the next launch: its own inside batch_begin_int, else the shared one"""
         b = getattr(self, "_int_batch", None)
         if b is None or not self.feat["with_int"]:
             return self.T[1]
+        if getattr(self, "_int_groups", False) and self._int_open:
+            return b[-1]                                   # a further launch of the current group
         if len(b) >= self._int_max:
             raise RuntimeError("soc_batch_end and soc_batch_read_int first")
         b.append(np.zeros(self.cloud.CELLS, np.float32))
+        self._int_open = True
         return b[-1]
 
     def bind_tally(self, which, ptr, n=None):

@@ -213,3 +213,58 @@ def test_intensity_vectors_in_the_sweep(kind, engine, oracle_soc):
         assert np.all(np.abs(got - want[k]) <= 1e-5 * np.maximum(I, 1e-3 * I.max()))
     engine.set_features(0, 0, 0)
     engine.set_exec(-1, 4)
+
+
+def test_groups_of_launches_with_an_int_tally_each(engine, oracle_soc):
+    """soc_batch_begin_int_groups / soc_batch_next_int: several 'frequencies' in one sweep, the launches of a frequency -- a point-source
+    and a cell-emission launch here -- tallying into that frequency's INT array (brick queues per group); TABS integrates over all of them.
+    Every group's INT equals the one its launches give alone, and the oracle's for the first group."""
+    cl = cloud104()
+    ps = np.array([[52.3, 51.7, 50.2]], np.float32)
+    emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+    groups = []
+    for f in range(3):
+        kw = dict(ABS=(3 + f) * 1e-6, SCA=(3 - 0.5 * f) * 1e-5, WITH_INT=1, TW=1.0 + 0.5 * f)
+        groups.append([(0, Job(cl, cases._CSC, SOURCE=0, BATCH=20, SEED=0.2 + 0.1 * f, GLOBAL=512, PSPOS=ps, PS=[1.0 + f], PS_METHOD=0, **kw), 0, 512),
+                       (1, Job(cl, cases._CSC, SOURCE=2, BATCH=1, SEED=0.6 + 0.1 * f, GLOBAL=8192, EMIT=emit * (1 + f), **kw), 4000, 4048)])
+    alone, stats, tabs = [], dict(tally_events=0, packets=0, scatterings=0), None
+    for g in groups:
+        I = None
+        for kind, job, g0, g1 in g:
+            T, Ik, st = _sweep(engine, job, kind, gid_first=g0, gid_count=g1 - g0)
+            I = Ik.astype(np.float64) if I is None else I + Ik
+            tabs = T.astype(np.float64) if tabs is None else tabs + T
+            for key in stats:
+                stats[key] += st[key]
+        alone.append(I)
+    T0, I0, n0 = oracle_soc.sim(groups[0][0][1], 0, nthreads=8)
+    T1, I1, n1 = oracle_soc.sim(groups[0][1][1], 1, gid0=4000, gid1=4048, nthreads=8)
+    assert_tally_close(alone[0], I0.astype(np.float64) + I1, rtol=1e-5)
+    # the same launches in one sweep
+    e = engine
+    e.set_exec(1, 4)
+    e.set_features(1, 0, 0)
+    e.zero(0)
+    e.stats(reset=True)
+    e.batch_begin_int_groups(0)
+    for g in groups:
+        e.batch_next_int()
+        for kind, job, g0, g1 in g:
+            e.set_optical(job.ABS, job.SCA)
+            e.set_scatter_table(job.DSC, job.CSC)
+            if kind == 0:
+                e.sim_pb(0, job.PACKETS, job.BATCH, job.SEED, job.BG, job.TW, PSPOS=job.PSPOS[:, :3], PS=job.PS, GLOBAL=job.GLOBAL, gid_first=g0, gid_count=g1 - g0)
+            else:
+                e.set_emission(job.EMIT, None)
+                e.sim_cl(2, job.PACKETS, job.BATCH, job.SEED, job.TW, job.GLOBAL, gid_first=g0, gid_count=g1 - g0)
+    assert e.last_passes() == 0
+    e.batch_end()
+    st = e.stats()
+    assert e.last_form() == 3 and e.last_passes() > 0
+    for key in stats:
+        assert st[key] == stats[key]
+    assert_tally_close(e.read_tally(0), tabs, rtol=1e-5)
+    for k in range(3):
+        assert_tally_close(e.batch_read_int(k), alone[k], rtol=1e-5)
+    e.set_features(0, 0, 0)
+    e.set_exec(-1, 4)
