@@ -753,7 +753,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     // (4) the prefetched packet becomes the current one
                     have = nhave;
                     wid = nwid;  cslot = nslot;
-                    if (have) {
+                    {   // (all lanes of the arm: what a lane without a prefetched packet decodes here is never used)
                         dz = ndzw.x;  dw = ndzw.y & ~SOC_LT_ARRIVE;
                         px = na.x;  py = na.y;  pz = na.z;  photons = na.w;
                         ux = nb.x;  uy = nb.y;  uz = nb.z;  free_path = nb.w;
@@ -765,13 +765,15 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         level = (int)(dz >> 29);
                         kabs = l4.x;  ksca = l4.y;  tw = l4.z;  nonudge = RAY || ((__float_as_int(l4.w) & 1) != 0);
                         nvisit = 0;
-                        mode = SOC_BM_STEP;
+                        mode = have ? SOC_BM_STEP : mode;
                         slot = -1;  obase = -1;
                         // The first pass of the packet through the Index() part finds its cell in this brick: the second half of
                         // the step that brought it here (ARRIVE), or the cell its coordinates name.  A root-level packet in (or
                         // into) a root cell that is not refined -- the common case -- is settled here.
-                        what = n_arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE;
-                        if ((level == 0) && (!n_arrive || (n_rec > 0.0f))) { slot = n_s2;  dens = n_rec;  cx = n_ix;  cy = n_iy;  cz = n_iz;  what = SOC_LTM_STEP; }
+                        const bool settled = (level == 0) && (!n_arrive || (n_rec > 0.0f));
+                        what = settled ? SOC_LTM_STEP : (n_arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE);
+                        slot = settled ? n_s2 : slot;  dens = settled ? n_rec : dens;
+                        cx = settled ? n_ix : cx;  cy = settled ? n_iy : cy;  cz = settled ? n_iz : cz;
                     }
                     // (5) the record of the packet after it (its id has arrived), and the id of the one after that
                     nhave = nnhave;
@@ -817,60 +819,61 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 ds = ds * soc_lt_pow2(-level);                                    // ldexp(ds, -level)
                 tauA = ds * dens * kabs;
                 dtau = ds * dens * (RAY ? photons : ksca);
-                if (free_path < (tau + dtau)) {
-                    px = p0x;  py = p0y;  pz = p0z;                               // back to the start of the step
-                    mode = SOC_BM_SWAP;  key = evq + 1;                           // -> scattering queue of its launch
-                    move = false;
-                }
+                const bool scat = free_path < (tau + dtau);                       // the free path ends in this cell:
+                px = scat ? p0x : px;  py = scat ? p0y : py;  pz = scat ? p0z : pz;   // back to the start of the step
+                mode = scat ? SOC_BM_SWAP : mode;  key = scat ? (evq + 1) : key;  // -> scattering queue of its launch
+                move = !scat;
             }
-            // ---- Index (kernel_ASOC_aux.c:198-278), first half: where the point is, and the read of the slot the descent starts from ----
-            SocLtAim AM;
-            int   r = SOC_LT_LOST;
-            float rec = 1.0f;
+            // ---- Index (kernel_ASOC_aux.c:198-278), first half: where the point is, and the read of the slot the descent starts from;
+            // the tally of the step while that read is in flight; the descent to the leaf; the outcome.  ONE divergent region, and the
+            // outcome by selects: every `if` of a divergent wave costs scalar bookkeeping of the exec mask that the wave issues in order
+            // with its vector instructions (the walk is bound by instruction issue) ----
             if (move) {
+                SocLtAim AM;
+                int   r;
+                float rec = 1.0f;
                 if ((A.slow_every > 0) && (what == SOC_LTM_STEP) && (level > 0) && (((n_tally + 1u + wid) % (unsigned)A.slow_every) == 0u)) {
                     r = SOC_LT_SLOW;                                              // test knob: this step goes through the slow-step queue
+                    AM = SocLtAim{};
                 } else {
                     soc_lt_aim(KB, NX, NY, NZ, Lmax, kexp, what, px, py, pz, level, cx, cy, cz, obase, AM);
                     r = AM.r;
                     rec = sD[AM.s];
                 }
-            }
-            // ---- the tally of the step (the LDS read above is in flight meanwhile) ----
-            if (RAY) {
-                if (move && (what == SOC_LTM_STEP)) { tau += dtau;  n_tally++; }
-            } else
-            if (move && (what == SOC_LTM_STEP)) {
-                const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
-                const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
-                atomicAdd(&sT[slot0], delta * tw);
-                if (WINT) atomicAdd(&sI[slot0], delta);
-                if (WINT == 2) { atomicAdd(&sV[slot0], delta * ux);  atomicAdd(&sV[BV + slot0], delta * uy);  atomicAdd(&sV[2 * BV + slot0], delta * uz); }
-                n_tally++;
-                photons *= e;
-                tau += dtau;
-            }
-            SOC_PROF_T(1);                                 // GetStep + tally
-            // ---- Index, second half: the descent to the leaf, the packet's new place ----
-            if (move) {
-                if (r == SOC_LT_INSIDE) r = soc_lt_land(sD, AM, Lmax, what, rec, px, py, pz, level, cx, cy, cz, slot, obase, dens);
-                if (r == SOC_LT_INSIDE) {
-                    if (what != SOC_LTM_PLACE) {
-                        if (!nonudge && (slot == slot0)) {                        // failed step: nudge (SimRAM_PB / HP only)
-                            px += SOC_PEPS * ux;  py += SOC_PEPS * uy;  pz += SOC_PEPS * uz;
-                        }
-                        nvisit++;
-                        if (nvisit >= A.KCAP) { mode = SOC_BM_SWAP;  key = D.brick; }
+                // the tally of the step.  A lane that only places its packet (no GetStep: tauA = dtau = 0) adds zeros to slot 0
+                // and multiplies its photons by exp(-0) = 1: cheaper than a branch of its own
+                {
+                    const bool stepped = (what == SOC_LTM_STEP);
+                    n_tally += stepped ? 1u : 0u;
+                    tau += dtau;
+                    if (!RAY) {
+                        const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
+                        const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
+                        const int st = stepped ? slot0 : 0;
+                        atomicAdd(&sT[st], delta * tw);
+                        if (WINT) atomicAdd(&sI[st], delta);
+                        if (WINT == 2) { atomicAdd(&sV[st], delta * ux);  atomicAdd(&sV[BV + st], delta * uy);  atomicAdd(&sV[2 * BV + st], delta * uz); }
+                        photons *= e;
                     }
-                } else if (r == SOC_LT_LEAVE) {
-                    mode = SOC_BM_SWAP;  key = -1 - SOC_MAD24(SOC_MAD24(AM.Rz, NY, AM.Ry), NX, AM.Rx);  dw |= SOC_LT_ARRIVE;   // (the brick of that root cell: looked up after the walk; N < 4096)
-                } else if (r == SOC_LT_EXIT) {
-                    mode = SOC_BM_SWAP;  key = evq;                               // -> creation queue
-                } else if (r == SOC_LT_SLOW) {
-                    mode = SOC_BM_SWAP;  key = evq + 2;  dw |= SOC_LT_ARRIVE;     // -> slow-step queue: old cell, advanced position
-                } else {
-                    mode = SOC_BM_SWAP;  key = NQ - 1;                            // cannot happen (the sender looked the brick up): retire rather than walk off the tree
                 }
+                SOC_PROF_T(1);                                 // GetStep + tally
+                if (r == SOC_LT_INSIDE) r = soc_lt_land(sD, AM, Lmax, what, rec, px, py, pz, level, cx, cy, cz, slot, obase, dens);
+                const bool inside = (r == SOC_LT_INSIDE);
+                const bool moved  = inside & (what != SOC_LTM_PLACE);
+                // failed step: nudge (SimRAM_PB / HP only); + 0 * u leaves the position as it is
+                const float nz = (moved & !nonudge & (slot == slot0)) ? SOC_PEPS : 0.0f;
+                px += nz * ux;  py += nz * uy;  pz += nz * uz;
+                nvisit += moved ? 1 : 0;
+                const bool leave = (r == SOC_LT_LEAVE), slowq = (r == SOC_LT_SLOW);
+                // where the packet goes when it does not stay: its own queue again (step budget used), the brick of the root cell it
+                // steps into (looked up after the walk: -1 - root cell; N < 4096), the creation queue of its launch (outside the model),
+                // the slow-step queue (old cell, advanced position), or -- cannot happen, the sender looked the brick up -- retirement
+                const int kleave = -1 - SOC_MAD24(SOC_MAD24(AM.Rz, NY, AM.Ry), NX, AM.Rx);
+                const int kout = leave ? kleave : ((r == SOC_LT_EXIT) ? evq : (slowq ? (evq + 2) : (NQ - 1)));
+                const bool out = !inside | (moved & (nvisit >= A.KCAP));
+                key  = out ? (inside ? D.brick : kout) : key;
+                mode = out ? SOC_BM_SWAP : mode;
+                dw  |= (leave | slowq) ? SOC_LT_ARRIVE : 0u;
                 what = SOC_LTM_STEP;
             }
             SOC_PROF_T(2);                                 // Index

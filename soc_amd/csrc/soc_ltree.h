@@ -151,26 +151,25 @@ SOC_HD int soc_lt_land(const TREE tree, const SocLtAim &A, const int Lmax, const
         s = base + (((A.Fx >> sh) & 1) | (((A.Fy >> sh) & 1) << 1) | (((A.Fz >> sh) & 1) << 2));
         rec = tree[s];
     }
-    if (place) {
-        if (l != L) return SOC_LT_LOST;
-        slot = s;  obase = base;  dens = rec;
-        return SOC_LT_INSIDE;
-    }
+    // (a placement ends on the packet's own level, l == L, with the point F built from its own cell: the lines below then give the
+    //  coordinates and the level back as they were -- only the position, which a placement does not touch, is kept by a select)
+    const bool lost = place & (l != L);
     const int sh = Lmax - l;
     const int nx = A.Fx >> sh, ny = A.Fy >> sh, nz = A.Fz >> sh;            // the leaf, on its level
     const int qm = (l > 0) ? ~1 : 0;
     // pos' = RN(pos * 2^(l-L) + (O_old * 2^(l-L) - O_new)); the constant is a dyadic number of few bits: exact.  Same level and
     // same octet: pos * 1 + 0 = pos (pos is never a zero here: a coordinate on a cell face went to SOC_LT_SLOW or SOC_LT_EXIT).
     const float sc = soc_lt_pow2(l - L);
-    px = SOC_FMA(px, sc, SOC_FMA((float)A.ox, sc, -(float)(nx & qm)));
-    py = SOC_FMA(py, sc, SOC_FMA((float)A.oy, sc, -(float)(ny & qm)));
-    pz = SOC_FMA(pz, sc, SOC_FMA((float)A.oz, sc, -(float)(nz & qm)));
+    const float qx = SOC_FMA(px, sc, SOC_FMA((float)A.ox, sc, -(float)(nx & qm)));
+    const float qy = SOC_FMA(py, sc, SOC_FMA((float)A.oy, sc, -(float)(ny & qm)));
+    const float qz = SOC_FMA(pz, sc, SOC_FMA((float)A.oz, sc, -(float)(nz & qm)));
+    px = place ? px : qx;  py = place ? py : qy;  pz = place ? pz : qz;
     cx = nx;  cy = ny;  cz = nz;
     level = l;
     slot = s;
     obase = base;
     dens = rec;
-    return SOC_LT_INSIDE;
+    return lost ? SOC_LT_LOST : SOC_LT_INSIDE;
 }
 
 // both halves in one call (host harness, slow paths)
