@@ -83,10 +83,11 @@ int soc_set_mirror(soc_ctx *ctx, int mask);
 int soc_set_exec(soc_ctx *ctx, int mode, int brick_log2);
 
 /* Shape of the brick sweep (no counterpart in the reference; results are the same packets whatever the values).
- * value 0 = the built-in choice for the grid.  Names: "threads" (workgroup size of the walk, 64..512), "chunk" (packets
- * per workgroup, <= 4096), "steps_per_visit" (cell steps before a packet goes back to its queue), "swap_lanes" /
- * "climb_lanes" (lanes of a wave that must wait before the packet swap / the deferred Index() runs), "brick_cells"
- * (cells per brick on hierarchies, <= 16384), "tail_lanes", "park_below" (hierarchies: brick queues shorter than this and than the mean wait a pass; 1 = never), "population" (packets in flight), "hash_slots" (per-workgroup
+ * value 0 = the built-in choice for the grid.  Names: "threads" (workgroup size of the walk, 64..512; ..1024 on brick-local
+ * hierarchies), "chunk" (packets per workgroup, <= 4096; <= 32768 on brick-local hierarchies), "steps_per_visit" (cell steps
+ * before a packet goes back to its queue), "swap_lanes" (lanes of a wave that must wait before the packet swap runs),
+ * "climb_lanes" (the same for the deferred Index() of the global-tree form), "brick_cells" (cells per brick on hierarchies,
+ * <= 36864), "tail_lanes", "park_below" (hierarchies: brick queues shorter than this and than the mean wait a pass; 1 = never), "population" (packets in flight), "hash_slots" (per-workgroup
  * arrival table, power of two), "general_kernel" (1: no background-only kernel), "global_tree" (1: hierarchies are walked in
  * global memory also where the brick-local form applies), "slow_every" (test knob of that form),
  * "oversubscribe", "verbose". */
