@@ -138,6 +138,7 @@ struct SocBrickArgs {
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
     int kexp;                    // k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_move
+    int roi_on;                  // -D WITH_ROI_SAVE: a packet that steps into the region of interest goes through a fourth event queue of its launch
     // scattered-light images on brick-local hierarchies (soc_sca_events): the view, and the parked packet of every work item
     SocPk2 *park;
     SocSca sca;
@@ -676,6 +677,13 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     // lanes of a spill VGPR (v_readlane, no memory).
     int NX = G.NX, NY = G.NY, NZ = G.NZ, Lmax = G.LEVELS - 1, kexp = A.kexp;
     asm volatile("" : "+s"(NX), "+s"(NY), "+s"(NZ), "+s"(Lmax), "+s"(kexp));
+    // the region of interest (root cells, inclusive limits): InRoi of kernel_ASOC_aux.c:1031-1048 on the packet's integer coordinates
+    int rx0 = 1, rx1 = 0, ry0 = 1, ry1 = 0, rz0 = 1, rz1 = 0;
+    if (!RAY && A.roi_on) {
+        const SocRoi *R = S.ROI;
+        rx0 = __builtin_amdgcn_readfirstlane(R->ROI[0]);  rx1 = __builtin_amdgcn_readfirstlane(R->ROI[1]);  ry0 = __builtin_amdgcn_readfirstlane(R->ROI[2]);
+        ry1 = __builtin_amdgcn_readfirstlane(R->ROI[3]);  rz0 = __builtin_amdgcn_readfirstlane(R->ROI[4]);  rz1 = __builtin_amdgcn_readfirstlane(R->ROI[5]);
+    }
     SOC_GLOBAL uint32_t *keyq_c = (SOC_GLOBAL uint32_t *)(A.keyq + D.start);          // this chunk's part of the queue arrays
     const SOC_GLOBAL uint32_t *idq_c = (const SOC_GLOBAL uint32_t *)(A.idq + D.start);
     asm volatile("" : "+s"(pk), "+s"(keyq_c), "+s"(idq_c));
@@ -770,7 +778,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         // The first pass of the packet through the Index() part finds its cell in this brick: the second half of
                         // the step that brought it here (ARRIVE), or the cell its coordinates name.  A root-level packet in (or
                         // into) a root cell that is not refined -- the common case -- is settled here.
-                        const bool settled = (level == 0) && (!n_arrive || (n_rec > 0.0f));
+                        // (with the record of packets entering ROI an arrival is always finished in the step arm, where the test for it sits)
+                        const bool settled = (level == 0) && (!n_arrive || ((n_rec > 0.0f) && !(!RAY && A.roi_on)));
                         what = settled ? SOC_LTM_STEP : (n_arrive ? SOC_LTM_ARRIVE : SOC_LTM_PLACE);
                         slot = settled ? n_s2 : slot;  dens = settled ? n_rec : dens;
                         cx = settled ? n_ix : cx;  cy = settled ? n_iy : cy;  cz = settled ? n_iz : cz;
@@ -857,6 +866,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                     }
                 }
                 SOC_PROF_T(1);                                 // GetStep + tally
+                const int orx = cx >> level, ory = cy >> level, orz = cz >> level;      // (the root cell the step starts from: for the record of packets entering ROI)
                 if (r == SOC_LT_INSIDE) r = soc_lt_land(sD, AM, Lmax, what, rec, px, py, pz, level, cx, cy, cz, slot, obase, dens);
                 const bool inside = (r == SOC_LT_INSIDE);
                 const bool moved  = inside & (what != SOC_LTM_PLACE);
@@ -873,6 +883,16 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                 const bool out = !inside | (moved & (nvisit >= A.KCAP));
                 key  = out ? (inside ? D.brick : kout) : key;
                 mode = out ? SOC_BM_SWAP : mode;
+                if (!RAY && A.roi_on) {
+                    // WITH_ROI_SAVE (kernel_ASOC.c:615-642, :1510-1535), at the end of a full step: the packet was outside ROI and is inside
+                    // now -> the event workgroups add it to the record (root position, direction, photons) and send it back here
+                    const int nrx = cx >> level, nry = cy >> level, nrz = cz >> level;
+                    const bool was = (orx >= rx0) & (orx <= rx1) & (ory >= ry0) & (ory <= ry1) & (orz >= rz0) & (orz <= rz1);
+                    const bool is  = (nrx >= rx0) & (nrx <= rx1) & (nry >= ry0) & (nry <= ry1) & (nrz >= rz0) & (nrz <= rz1);
+                    const bool entered = moved & is & !was;
+                    key  = entered ? (evq + 3) : key;
+                    mode = entered ? SOC_BM_SWAP : mode;
+                }
                 dw  |= (leave | slowq) ? SOC_LT_ARRIVE : 0u;
                 what = SOC_LTM_STEP;
             }
@@ -915,6 +935,62 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     if (RAY && threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 3, (unsigned long long)(unsigned int)sCtl[1]);      // cell steps of all rays
 }
 
+
+// SOURCE == 3: the next packet of work item `id` from the loaded record; III counts the pixels tried.  false: none left.
+template <bool OCT, typename W>
+__device__ __forceinline__ bool soc_roi_create(const SocGrid &G, const SocSim &S, const int *sOFF, const int id, int &III, W &w)
+{
+    const SocRoi &R = *S.ROI;
+    const int relem = id % R.NELEM;
+    int   iside = relem, rside;
+    float RDX, RDY;
+    const float rd = (float)G.NX / ((float)R.DIM[0]);
+    if (iside < (R.DIM[1] * R.DIM[2])) {
+        RDX = ((float)(iside % R.DIM[1]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[1]) + 0.5f) * rd;  rside = 0;
+    } else {
+        iside -= R.DIM[1] * R.DIM[2];
+        if (iside < (R.DIM[0] * R.DIM[2])) {
+            RDX = ((float)(iside % R.DIM[0]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[0]) + 0.5f) * rd;  rside = 1;
+        } else {
+            iside -= R.DIM[0] * R.DIM[2];
+            rside = 3;
+            RDX = 0.0f;  RDY = 0.0f;
+            if (iside < (R.DIM[0] * R.DIM[1])) {
+                RDX = ((float)(iside % R.DIM[0]) + 0.5f) * rd;  RDY = ((float)(iside / R.DIM[0]) + 0.5f) * rd;  rside = 2;
+            }
+        }
+    }
+    const float RX0 = (float)((double)(R.NSIDE * R.NSIDE) * 12.0 / (100.0 * (double)S.BATCH));
+    const int npix = 12 * R.NSIDE * R.NSIDE;
+    while (III < S.BATCH) {
+        const int pix = III % npix;
+        III++;
+        w.photons = RX0 * R.LOAD[(size_t)relem * npix + pix];
+        if (w.photons <= 0.0f) continue;
+        float v1, v2, s1, c1, s2, c2;
+        soc_pixel2angles_ring(R.NSIDE, pix, v1, v2);
+        v1 += (soc_rand(&w.rng) - 0.5f) * 0.05f;
+        v2 += (soc_rand(&w.rng) - 0.5f) * 0.05f;
+        soc_sincosf(v1, &s1, &c1);
+        soc_sincosf(v2, &s2, &c2);
+        w.ux = s2 * c1;  w.uy = s2 * s1;  w.uz = c2;
+        if (rside == 0) {
+            w.py = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.pz = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+            w.px = (w.ux > 0.0f) ? SOC_PEPS : ((float)G.NX - SOC_PEPS);
+        }
+        if (rside == 1) {
+            w.px = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.pz = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+            w.py = (w.uy > 0.0f) ? SOC_PEPS : ((float)G.NY - SOC_PEPS);
+        }
+        if (rside == 2) {
+            w.px = RDX + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;  w.py = RDY + (-0.49f + 0.98f * soc_rand(&w.rng)) * rd;
+            w.pz = (w.uz > 0.0f) ? SOC_PEPS : ((float)G.NZ - SOC_PEPS);
+        }
+        soc_indexg<OCT>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+        return true;
+    }
+    return false;
+}
 
 // creation and scattering, one lane per queued packet
 template <bool OCT, bool ABU, int WINT, int KIND, bool LT>
@@ -995,11 +1071,19 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
                 mirrored = (w.ind >= 0);
             }
         }
+        if (LT && (evk == 3)) {
+            // the walk saw the packet step into the region of interest: its place in the record (kernel_ASOC.c:615-642, :1510-1535), then on
+            // with the walk in the brick of its cell
+            soc_roi_save(G, sOFF, *S.ROI, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.photons);
+            key = qbase + A.rbrick[((ccz >> w.level) * G.NY + (ccy >> w.level)) * G.NX + (ccx >> w.level)];
+        } else
         if (LT && (evk == 2)) {
             // slow step: Index() itself, in double, for a step that exact geometry does not decide (soc_ltree.h).  The
             // packet holds its old cell and the advanced position; tallies of the step are done.
             const int ind0 = w.ind, level0 = w.level;
             soc_index<true, double>(G, sOFF, w.px, w.py, w.pz, w.level, w.ind, w.dens);
+            if (S.ROISAVE && (w.ind >= 0) && (soc_inroi(G, sOFF, *S.ROI, level0, ind0) < 0) && (soc_inroi(G, sOFF, *S.ROI, w.level, w.ind) >= 0))
+                soc_roi_save(G, sOFF, *S.ROI, w.px, w.py, w.pz, w.ux, w.uy, w.uz, w.level, w.ind, w.photons);      // the step took it into ROI (kernel_ASOC.c:615-642)
             if (!CL && (w.ind >= 0) && (w.level == level0) && (w.ind == ind0)) {   // failed step: nudge (SimRAM_PB / HP only), before Mirror as in the step
                 w.px += SOC_PEPS * w.ux;  w.py += SOC_PEPS * w.uy;  w.pz += SOC_PEPS * w.uz;
             }
@@ -1157,6 +1241,16 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             const SocSurfElem E = soc_surface_element<SRC>(G, S, id);
             while (true) {
                 if (III >= S.BATCH) { key = NQ - 1;  break; }                  // work item finished
+                if ((SRC < 0) && (S.SOURCE == 3)) {
+                    // packets of a loaded region-of-interest record (-D WITH_ROI_LOAD, kernel_ASOC.c:141-179, :469-501): 100 work items per
+                    // surface element, the Healpix pixels of the element in turn; an empty pixel is skipped without a draw
+                    const int before = III;
+                    const bool made = soc_roi_create<OCT>(G, S, sOFF, id, III, w);
+                    n_pkt += (unsigned int)(III - before);
+                    if (!made) { key = NQ - 1;  break; }
+                    w.begin(S);
+                    III--;  n_pkt--;                                           // (counted again below)
+                } else
                 if (HP) {                                                      // SimRAM_HP (kernel_ASOC.c:878-955)
                     soc_hp_create<OCT>(G, S, sOFF, w);
                     w.begin_conditioned(S);
@@ -2026,6 +2120,11 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (e == hipSuccess) {
             const SocLBricksDev &lb = g_lb[device];
             A.LT = 1;  A.EQ = 3;
+            for (int l = 0; l < nlaunch; l++) if (Sin[l].ROISAVE && Sin[l].ROI) A.roi_on = 1;
+            if (A.roi_on) {
+                for (int l = 0; l < nlaunch; l++) if (!(Sin[l].ROISAVE && Sin[l].ROI) || Sin[l].MIRROR) return hipErrorNotSupported;      // one record, no reflecting faces
+                A.EQ = 4;                                                    // + the queue of packets that have just stepped into ROI
+            }
             A.NBX = A.NBY = A.NBZ = 0;
             A.NB = lb.NB;
             A.CAP = (lb.max_slots + 63) & ~63;                           // slots in LDS
@@ -2048,6 +2147,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         }
     }
     if ((sca || V.wint == 2) && !A.LT) return hipErrorNotSupported;
+    if (!A.LT) for (int l = 0; l < nlaunch; l++) if (Sin[l].ROISAVE) return hipErrorNotSupported;      // region-of-interest records: brick-local hierarchies only
     if (!A.LT && (A.T > 512 || A.P > SOC_BRICK_PMAX || A.CAP < 8 || A.CAP > (1 << SOC_SLOT_BITS))) return hipErrorInvalidValue;
     if (A.LT) {
         // set above
@@ -2076,6 +2176,12 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         uint32_t c = S.gid_count;
         if ((S.SOURCE == 1 || S.SOURCE == SOC_SOURCE_HP) && !tune.oversub) {
             const long long lim = 8LL * 2 * ((long long)G.NX * G.NY + (long long)G.NY * G.NZ + (long long)G.NZ * G.NX);
+            if ((long long)S.gid0 >= lim) c = 0;
+            else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);
+        }
+        if (S.SOURCE == 3) {                                          // 100 work items per surface element of the loaded record (kernel_ASOC.c:97-105)
+            if (S.ROILOAD < 1 || !S.ROI) return hipErrorNotSupported;
+            const long long lim = 100LL * S.ROILOAD;
             if ((long long)S.gid0 >= lim) c = 0;
             else if ((long long)S.gid0 + c > lim) c = (uint32_t)(lim - S.gid0);
         }

@@ -841,13 +841,15 @@ int soc_sim_pb(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     SocVariant V;
     fill_sim(c, S, V, SOURCE, BATCH, SEED, BG, TW, GLOBAL, gid_first, gid_count);
     S.ROI = (c->roi.save || c->roi.load) ? c->dRoi : nullptr;
+    S.ROISAVE = c->roi.save;
+    S.ROILOAD = c->roi.load ? c->roi.NELEM : 0;
     // brick sweep: enough work items to fill the chip.  Hierarchies: it pays from two launches per sweep on
     // (256^3 roots, 4 levels: 1.9e10 steps/s with one launch, 2.8e10 with two, 4.4e10 with eight; direct kernel
     // 2.0e10), so in automatic mode only deferred launches use it (see flush_pending)
     const int B = 1 << c->brick_log2;
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0))
-                  && SOURCE != 3 && !c->roi.save;              // region-of-interest records: direct kernel only
+                  && (!c->roi.save || (lt_capable(c, V.abu != 0) && c->mirror == 0));      // region-of-interest records: the brick-local sweep's event workgroups (packets of a loaded record, SOURCE 3: any sweep)
     if (c->exec_mode < 0) bricks = bricks && gid_count >= 65536 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && gid_count >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)
@@ -1194,6 +1196,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     if (c->use_emweight == 2 && !c->have_emindex) return fail(c, SOC_ERR_STATE, "soc_sim_cl: USE_EMWEIGHT 2 needs soc_set_emindex");
     if (c->with_ali) S.XAB = c->dXAB;
     S.ROI = c->roi.save ? c->dRoi : nullptr;                // SimRAM_CL records too (kernel_ASOC.c:1250-1254)
+    S.ROISAVE = c->roi.save;
     // The brick sweep: the same walk, the event workgroups step through the work item's cells.  It needs packets in
     // flight to sort -- one per work item that has a cell, min(GLOBAL, CELLS): with the reference's GLOBAL = 32768
     // the direct kernel (1.5e10 steps/s at C2, the rate of the fabric atomics) stays; `global` in the ini file
@@ -1202,7 +1205,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0))
-                  && c->use_emweight != 2 && !c->with_ali && !c->roi.save;
+                  && c->use_emweight != 2 && !c->with_ali && (!c->roi.save || (lt_capable(c, V.abu != 0) && c->mirror == 0));
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)

@@ -51,6 +51,8 @@ struct SocSim {
     float *TABS, *INT;
     unsigned long long *stats; /* [0] tally events  [1] packets  [2] scatterings          */
     const SocRoi *ROI;         /* NULL without roisave / roiload                          */
+    int    ROILOAD;            /* SOURCE == 3: surface elements of the loaded record (host copy of ROI->NELEM; 0: none loaded) */
+    int    ROISAVE;            /* the record of packets entering ROI is kept (host copy of ROI->save: the sweep's queues depend on it) */
     int    STEP_WEIGHT;        /* -D STEP_WEIGHT: 0 none, 1 | 2 weighted free paths (kernel_ASOC.c:516-535) */
     float  SW_A, SW_B;
     int    NDUST;              /* > 1: -D WITH_MSF, CSC holds [NDUST][BINS] (kernel_ASOC.c:777-795)          */

@@ -513,3 +513,15 @@ def test_absorbed_file_run_with_int_batches(engine, tmp_path):
     assert_tally_close(Cg, Cw, rtol=1e-5)
     assert np.allclose(got, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
     engine.set_features(0, 0, 0)
+
+
+@pytest.mark.parametrize("lb", [2, 3])
+def test_packets_of_a_loaded_roi_record_in_the_sweep(lb, engine, oracle_soc):
+    """SOURCE == 3 (-D WITH_ROI_LOAD, kernel_ASOC.c:141-179, :469-501) created by the event workgroups of the Cartesian sweep"""
+    ref, kind, mk = cases.CASES["roi_c8_load"]
+    job = mk()
+    T, I, n = oracle_soc.sim(job, kind)
+    Tg, Ig, st = run_engine(engine, job, kind, exec_mode=1, brick_log2=lb)
+    assert engine.last_passes() > 0 and engine.last_form() == 1
+    assert st["tally_events"] == n and st["packets"] == job.GLOBAL * job.BATCH
+    assert_tally_close(Tg, T, rtol=1e-5)

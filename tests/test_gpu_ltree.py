@@ -268,3 +268,50 @@ def test_groups_of_launches_with_an_int_tally_each(engine, oracle_soc):
         assert_tally_close(e.batch_read_int(k), alone[k], rtol=1e-5)
     e.set_features(0, 0, 0)
     e.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_record_of_packets_entering_roi_in_the_sweep(kind, engine, oracle_soc, tuned):
+    """-D WITH_ROI_SAVE (kernel_ASOC.c:615-642, :1510-1535) in the brick-local sweep: the walk sees a packet step from outside the region of
+    interest into it (integer root-cell coordinates) and hands it to a fourth event queue of its launch, whose lanes add it to the record
+    (surface element, Healpix direction, photons) and send it back; slow steps make the test themselves.  Same entries, same sums."""
+    cl = cloud104()
+    roi = [40, 63, 45, 70, 38, 60]
+    if kind == 0:
+        job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=1, BATCH=3, SEED=0.377, ROI=roi, ROI_STEP=2, ROI_NSIDE=2)
+        g0, g1 = 100000, 106000
+    else:
+        emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+        job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=2, BATCH=1, SEED=0.9, GLOBAL=8192, EMIT=emit, ROI=roi, ROI_STEP=1, ROI_NSIDE=4)
+        g0, g1 = 4000, 4064
+    T, _, n = oracle_soc.sim(job, kind, gid0=g0, gid1=g1, nthreads=8)
+    want = np.array(job.ROI_SAVE, np.float32).copy()
+    for tune in (dict(), dict(slow_every=3)):
+        tuned(**tune)
+        Tg, _, st = _sweep(engine, job, kind, gid_first=g0, gid_count=g1 - g0)
+        assert st["tally_events"] == n
+        assert_tally_close(Tg, T, rtol=1e-5)
+        assert want.sum() > 0 and np.array_equal(job.ROI_SAVE_gpu != 0, want != 0)
+        assert_tally_close(job.ROI_SAVE_gpu, want, rtol=1e-5)
+    engine.set_roi_save(None)
+    engine.set_exec(-1, 4)
+
+
+def test_loaded_roi_record_with_a_record_saved_in_the_sweep(engine, oracle_soc):
+    """nested runs on a brick-local hierarchy: packets of a loaded region-of-interest record (SOURCE == 3, created by the event workgroups)
+    while the packets entering another region are recorded (WITH_ROI_LOAD + WITH_ROI_SAVE, with the INT tally)"""
+    cl = cloud104()
+    dim, nside = (6, 6, 6), 2
+    a = cases.roi_load(dim, nside)
+    job = Job(cl, cases._CSC, ABS=3e-6, SCA=3e-5, SOURCE=3, PACKETS=a.shape[0], GLOBAL=100 * a.shape[0], BATCH=12 * nside * nside,
+              ROI_LOAD=a, ROI_DIM=dim, ROI_NSIDE=nside, SEED=0.71, WITH_INT=1, TW=1.2, ROI=[30, 70, 35, 66, 40, 75], ROI_STEP=1)
+    T, I, n = oracle_soc.sim(job, 0, nthreads=8)
+    want = np.array(job.ROI_SAVE, np.float32).copy()
+    Tg, Ig, st = _sweep(engine, job, 0)
+    assert st["tally_events"] == n and st["packets"] == job.GLOBAL * job.BATCH
+    assert_tally_close(Tg, T, rtol=1e-5)
+    assert_tally_close(Ig, I, rtol=1e-5)
+    assert want.sum() > 0 and np.array_equal(job.ROI_SAVE_gpu != 0, want != 0)
+    assert_tally_close(job.ROI_SAVE_gpu, want, rtol=1e-5)
+    engine.set_features(0, 0, 0)
+    engine.set_exec(-1, 4)
