@@ -138,6 +138,7 @@ struct SocBrickArgs {
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
     int kexp;                    // k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_move
+    int ali;                     // -D WITH_ALI: the launches (SimRAM_CL) tally what the emitting cell absorbs of its own into XAB
     int roi_on;                  // -D WITH_ROI_SAVE: a packet that steps into the region of interest goes through a fourth event queue of its launch
     // scattered-light images on brick-local hierarchies (soc_sca_events): the view, and the parked packet of every work item
     SocPk2 *park;
@@ -625,7 +626,9 @@ __device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int c
 // depth grows with the factor the record carries in place of the photons (kappa_sca for the look-ahead and the packet, kappa_abs + kappa_sca
 // for a peel-off ray: kernel_ASOC_sca.c:895-897, :975-990, :1035-1040), no nudge after a failed step (GetStep alone moves these rays).
 // WINT: 0 TABS only, 1 the INT tally beside it, 2 INT and the vector sums INTX, INTY, INTZ (-D SAVE_INTENSITY=2, kernel_ASOC.c:604-612).
-template <int WINT, bool RAY = false>
+// ALI: -D WITH_ALI (kernel_ASOC.c:1394-1396, :1486-1494; SimRAM_CL only): what a packet deposits in the cell that emitted it goes to the XAB
+// tally instead of TABS.  The LDS then holds the cell numbers of the brick's slots (sC) and an XAB tally (sX) as well: 16 B per cell.
+template <int WINT, bool RAY = false, bool ALI = false>
 __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPack &K, const SocBrickArgs &A, const int bid)
 {
     if (bid >= *A.ndesc) return;
@@ -641,7 +644,9 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     float *sT   = lds;                                     // [BV] TABS of this brick
     float *sI   = sT + (RAY ? 0 : BV);                     // [BV] INT (WINT)
     float *sV   = sI + (WINT ? BV : 0);                    // [3 BV] INTX | INTY | INTZ (WINT == 2)
-    float *sD   = sV + ((WINT == 2) ? 3 * BV : 0);         // [BV] density | link of every cell of the brick (RAY: nothing else)
+    float *sX   = sV + ((WINT == 2) ? 3 * BV : 0);         // [BV] XAB (ALI)
+    int   *sC   = (int *)(sX + (ALI ? BV : 0));            // [BV] global number of the cell in every slot (ALI)
+    float *sD   = (float *)(sC + (ALI ? BV : 0));          // [BV] density | link of every cell of the brick (RAY: nothing else)
     const int NQ = A.NBQ + A.EQ * A.nl + 1;
     int   *sH   = (int *)(sD + BV);                        // arrivals per queue, next pass
     int   *sCtl = sH + (A.HS ? 2 * A.HS : ((NQ + 3) & ~3));   // [0] next packet, [1] tally events
@@ -664,6 +669,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
             sD[i] = src[i];  if (!RAY) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f;
             if (WINT == 2) { sV[i] = 0.0f;  sV[BV + i] = 0.0f;  sV[2 * BV + i] = 0.0f; }
+            if (ALI) { sX[i] = 0.0f;  sC[i] = A.bcell[KB.base + i]; }
         }
     }
     soc_qh_init(sH, A.HS, NQ);
@@ -859,7 +865,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         const float e = (__ballot(!(tauA < 0.34f)) == 0ull) ? soc_expf_small(-tauA) : soc_expf(-tauA);
                         const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
                         const int st = stepped ? slot0 : 0;
-                        atomicAdd(&sT[st], delta * tw);
+                        if (ALI) atomicAdd((sC[st] == (int)dw) ? &sX[st] : &sT[st], delta * tw);      // (SimRAM_CL: the record's last word is the emitting cell)
+                        else     atomicAdd(&sT[st], delta * tw);
                         if (WINT) atomicAdd(&sI[st], delta);
                         if (WINT == 2) { atomicAdd(&sV[st], delta * ux);  atomicAdd(&sV[BV + st], delta * uy);  atomicAdd(&sV[2 * BV + st], delta * uz); }
                         photons *= e;
@@ -908,10 +915,11 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
             const float v = sT[i];
             const float vi = WINT ? sI[i] : 0.0f;
-            if (v != 0.0f || vi != 0.0f) {
+            if (v != 0.0f || vi != 0.0f || (ALI && sX[i] != 0.0f)) {
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
                 if (WINT) soc_tally(K.S[K.gfirst[qbase / A.NB]].INT, cell, vi);      // the launches this workgroup's queue belongs to
+                if (ALI && (sX[i] != 0.0f)) soc_tally(S.XAB, cell, sX[i]);
                 if (WINT == 2) {
                     float *IV = K.S[K.gfirst[qbase / A.NB]].INTV;
                     const long C = K.S[0].CELLS;
@@ -1116,7 +1124,8 @@ __device__ __forceinline__ void soc_brick_events(const SocGrid &G, const SocSimP
             float tauA = dx * w.dens * kabs;
             float e = soc_expf(-tauA);
             float delta = (tauA > SOC_TAULIM) ? (w.photons * (1.0f - e)) : (w.photons * tauA * (1.0f - 0.5f * tauA));
-            soc_tally(S.TABS, oind, delta * S.TW);
+            if (CL && S.XAB && (oind == (int)cl_cell)) soc_tally(S.XAB, oind, delta * S.TW);      // WITH_ALI: absorbed in the emitting cell itself (kernel_ASOC.c:1486-1494)
+            else                                      soc_tally(S.TABS, oind, delta * S.TW);
             if (WINT) soc_tally(S.INT, oind, delta);
             if (WINT == 2) {                                                  // -D SAVE_INTENSITY=2 (kernel_ASOC.c:724-732)
                 soc_tally(S.INTV, oind, delta * w.ux);  soc_tally(S.INTV + S.CELLS, oind, delta * w.uy);  soc_tally(S.INTV + 2 * (long)S.CELLS, oind, delta * w.uz);
@@ -1334,6 +1343,20 @@ __global__ __launch_bounds__(1024) void soc_lbrick_pass(const SocGrid G, const S
     }
 }
 
+
+// SimRAM_CL launches with the XAB tally of -D WITH_ALI
+template <int WINT>
+__global__ __launch_bounds__(1024) void soc_lbrick_pass_ali(const SocGrid G, const SocSimPack *Kp, const SocBrickArgs A, const int nwalk, const int slices)
+{
+    const SocSimPack &K = *Kp;
+    const int b = (int)blockIdx.x;
+    if (b < nwalk) {
+        soc_lbrick_walk<WINT, false, true>(G, K, A, b);
+    } else {
+        const int e = b - nwalk;
+        soc_brick_events<true, false, WINT, 2, true>(G, K, A, e / slices, e % slices);
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // Scattered-light images (kernel_ASOC_sca.c) on brick-local hierarchies.
@@ -2015,6 +2038,13 @@ static void soc_lbrick_launch_one(int nblocks, int T, size_t lds, hipStream_t st
 static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_t lds, hipStream_t st, const SocGrid &G, const SocSimPack *K,
                                    const SocBrickArgs &A, int nwalk, int slices)
 {
+    if (A.ali) {                                             // SimRAM_CL with the XAB tally (soc_brick_run_pb has checked kind and wint)
+#define SOC_LBA_CASE(W) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)soc_lbrick_pass_ali<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                             soc_lbrick_pass_ali<W><<<nblocks, T, lds, st>>>(G, K, A, nwalk, slices); } while (0)
+        if (wint) SOC_LBA_CASE(1); else SOC_LBA_CASE(0);
+#undef SOC_LBA_CASE
+        return;
+    }
 #define SOC_LB_CASE(W, KD) soc_lbrick_launch_one<W, KD>(nblocks, T, lds, st, G, K, A, nwalk, slices)
     if (wint == 2) { if (kind == 4) SOC_LB_CASE(2, 4);  else if (kind == 3) SOC_LB_CASE(2, 3);  else if (kind == 2) SOC_LB_CASE(2, 2);  else if (kind == 1) SOC_LB_CASE(2, 1);  else SOC_LB_CASE(2, 0); }
     else if (wint) { if (kind == 4) SOC_LB_CASE(1, 4);  else if (kind == 3) SOC_LB_CASE(1, 3);  else if (kind == 2) SOC_LB_CASE(1, 2);  else if (kind == 1) SOC_LB_CASE(1, 1);  else SOC_LB_CASE(1, 0); }
@@ -2114,12 +2144,16 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         // cells per brick: what lets two workgroups share a CU's 160 KB of LDS (8 B per cell, 12 B with the INT tally, + 9 KB)
         // (rays: 4 B per cell, twice the cells in the same LDS)
         // (the vector sums of SAVE_INTENSITY 2: 24 B per cell)
-        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (V.wint == 2 ? 2944 : V.wint ? 5888 : 8704));
+        // WITH_ALI (every launch a SimRAM_CL one with the XAB tally): 8 B per cell more for XAB and the cell numbers
+        bool ali = !sca && (V.wint != 2);
+        for (int l = 0; l < nlaunch; l++) ali = ali && (Sin[l].SOURCE == SOC_SOURCE_CL) && (Sin[l].XAB != nullptr) && (Sin[l].XAB == Sin[0].XAB);
+        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (ali ? (V.wint ? 3456 : 4352) : (V.wint == 2 ? 2944 : V.wint ? 5888 : 8704)));
         if (capl < 8 || capl > 36864) return hipErrorInvalidValue;
         const hipError_t e = soc_lb_build(device, G, capl, st, tune.verbose != 0);
         if (e == hipSuccess) {
             const SocLBricksDev &lb = g_lb[device];
             A.LT = 1;  A.EQ = 3;
+            A.ali = ali ? 1 : 0;
             for (int l = 0; l < nlaunch; l++) if (Sin[l].ROISAVE && Sin[l].ROI) A.roi_on = 1;
             if (A.roi_on) {
                 for (int l = 0; l < nlaunch; l++) if (!(Sin[l].ROISAVE && Sin[l].ROI) || Sin[l].MIRROR) return hipErrorNotSupported;      // one record, no reflecting faces
@@ -2188,7 +2222,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         if (S.SOURCE == SOC_SOURCE_CL) {                              // work items beyond the cells do nothing (kernel_ASOC.c:1273)
             if ((long long)S.gid0 >= G.CELLS) c = 0;
             else if ((long long)S.gid0 + c > G.CELLS) c = (uint32_t)(G.CELLS - S.gid0);
-            if (S.USE_EMWEIGHT == 2 || S.XAB) return hipErrorNotSupported;
+            if (S.USE_EMWEIGHT == 2) return hipErrorNotSupported;
+            if (S.XAB && !A.ali) return hipErrorNotSupported;
         }
         if (S.BATCH <= 0 && S.SOURCE != SOC_SOURCE_CL) c = 0;
         if (c == 0) continue;                                         // nothing to do for this launch
@@ -2278,7 +2313,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint == 2 ? 4 : V.wint ? 1 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint == 2 ? 4 : V.wint ? 1 : 0) + (A.ali ? 2 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;

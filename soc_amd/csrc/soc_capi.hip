@@ -1205,7 +1205,7 @@ int soc_sim_cl(soc_ctx *c, int SOURCE, int PACKETS, int BATCH, float SEED, float
     const long long nb = (long long)((c->G.NX + B - 1) / B) * ((c->G.NY + B - 1) / B) * ((c->G.NZ + B - 1) / B);
     const long long inflight = std::min<long long>((long long)gid_first + gid_count, c->G.CELLS) - gid_first;
     bool bricks = (c->exec_mode != 0) && nb <= (1 << 18) && c->G.LEVELS <= 15 && c->device < 16 && (c->mirror == 0 || lt_capable(c, V.abu != 0)) && (c->with_int != 2 || lt_capable(c, V.abu != 0))
-                  && c->use_emweight != 2 && !c->with_ali && (!c->roi.save || (lt_capable(c, V.abu != 0) && c->mirror == 0));
+                  && c->use_emweight != 2 && (!c->with_ali || (lt_capable(c, V.abu != 0) && c->with_int != 2)) && (!c->roi.save || (lt_capable(c, V.abu != 0) && c->mirror == 0));
     if (c->exec_mode < 0) bricks = bricks && inflight >= 262144 && nb >= 8
                                    && (!V.octree || (c->batching && (!V.wint || c->batch_keep_int || c->batch_share_int)) || (lt_capable(c, V.abu != 0) && inflight >= SOC_LT_LONE_LAUNCH));
     if (c->exec_mode == 1 && !bricks)

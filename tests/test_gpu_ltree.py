@@ -315,3 +315,26 @@ def test_loaded_roi_record_with_a_record_saved_in_the_sweep(engine, oracle_soc):
     assert_tally_close(job.ROI_SAVE_gpu, want, rtol=1e-5)
     engine.set_features(0, 0, 0)
     engine.set_exec(-1, 4)
+
+
+@pytest.mark.parametrize("wint", [0, 1])
+def test_ali_tally_in_the_sweep(wint, engine, oracle_soc, tuned):
+    """-D WITH_ALI (kernel_ASOC.c:1394-1396, :1486-1494): what a SimRAM_CL packet deposits in the cell that emitted it goes to XAB, not TABS --
+    in the walk by the cell numbers of the brick's slots in LDS, in the scattering block of the event workgroups by the cell index"""
+    cl = cloud104()
+    emit = np.where(cl.DENS > 0, cl.DENS * 1e-3, 1e-4).astype(np.float32)
+    job = Job(cl, cases._CSC, ABS=3e-4, SCA=6e-4, SOURCE=2, BATCH=2, SEED=0.9, GLOBAL=8192, EMIT=emit, WITH_ALI=1, WITH_INT=wint, TW=1.3)
+    g0, g1 = 4000, 4064
+    T, I, n = oracle_soc.sim(job, 1, gid0=g0, gid1=g1, nthreads=8)
+    want = np.array(job.XAB, np.float32).copy()
+    assert want.sum() > 0
+    for tune in (dict(), dict(slow_every=3)):
+        tuned(**tune)
+        Tg, Ig, st = _sweep(engine, job, 1, gid_first=g0, gid_count=g1 - g0)
+        assert st["tally_events"] == n and st["scatterings"] > 100
+        assert_tally_close(Tg, T, rtol=1e-5)
+        assert_tally_close(job.XAB_gpu, want, rtol=1e-5)
+        if wint:
+            assert_tally_close(Ig, I, rtol=1e-5)
+    engine.set_features(0, 0, 0)
+    engine.set_exec(-1, 4)
