@@ -2264,7 +2264,8 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         // hierarchy (1.3e7 -> 3.7e10 steps/s, 5.0e7 -> 4.0e10)
         // brick-local hierarchies: 3e8 (256^3 roots, 4 levels, 8194 bricks: 5.0e7 -> 4.6e10 steps/s, 1.0e8 -> 5.0e10, 3.0e8 -> 5.3e10:
         // the longer a workgroup lives, the less its last iterations -- lanes running dry -- weigh)
-        const long long p = A.LT ? 300000000LL : V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
+        // (round 3, the bench's 20 launches = 3.36e8 work items: all at once 3.87e8 packets/s, capped at 3e8 3.79e8, at 2.4e8 3.79e8 -> 6e8)
+        const long long p = A.LT ? 600000000LL : V.octree ? 26000000LL : std::max(2700000LL, 5300LL * A.NBQ);
         population = (int)std::min(p, 2000000000LL);
     }
     if (tune.POP > 0) population = tune.POP;
