@@ -22,6 +22,8 @@ reference's simulation loop (source block II x frequency IFREQ, ASOC.py:1028-146
   partition into RNG streams): a launch shape the reference's ASOC.py can only be given by editing ASOC.py:86.  The rate
   at the reference's own launch shape is measured beside it on a shortened launch (config.reference_launch_shape).
 
+  C4 (--workload C4; BASELINE.json configs[3], the ASOCS scattering path): see run_c4.
+
   C2 (--workload C2; BASELINE.json configs[1]): 128^3 Cartesian cloud, one frequency, `bgpackets 1e8` ->
   786432 work items x BATCH 127 of isotropic background, noabsorbed.
 
@@ -195,6 +197,152 @@ def measured_traffic(workload):
     return None
 
 
+
+def run_c4(args, world, rank, local_rank, dist, torch):
+    """--workload C4 (BASELINE.json configs[3]): the scattered-light kernels on the config-3 hierarchy -- 3 observers, 256^2 pixels,
+    forced first scattering, the 50-frequency dust with its scattering functions.  Step i is one launch: frequency (21*(i//3)+45)%50,
+    kind background / point source / cell emission in turn, as soc_amd.asocs runs a source block -- the K steps deferred into one batch
+    with an image per frequency (soc_batch_begin ... soc_sca_batch_images ... soc_batch_end): one sweep of rays on the brick-local
+    hierarchies.  value = packets/s; roofline: 4 B (a density) per cell step of a ray."""
+    import math
+    work = c3_workload(args.global0)
+    cloud = work["cloud"]
+    N = cloud.NX
+    eng = Engine(local_rank)
+    eng.set_cloud(cloud)
+    eng.set_features(0, 0, 0)
+    eng.set_opt(None)
+    th = [math.radians(30 + 25 * i) for i in range(3)]
+    ph = [math.radians(40 * i) for i in range(3)]
+    _, OD, RA, DE = launch.set_observer_directions(th, ph)
+    eng.sca_set_view(OD, RA, DE, (256, 256), N / 256.0 * 1.5, (N / 2, N / 2, N / 2), 1)
+    AREA = 6 * N * N
+    GBG = launch.Fix(8 * AREA, 64)
+    shapes = {"bg": dict(GLOBAL=GBG, BATCH=4, packets=8 * AREA * 4), "ps": dict(GLOBAL=2097152, BATCH=8, packets=2097152 * 8),
+              "cl": dict(GLOBAL=8388608, BATCH=1, packets=cloud.CELLS)}
+    kinds = ("bg", "ps", "cl")
+    ps = np.array([[N / 2 + 0.3, N / 2 + 0.2, N / 2 + 0.1]], np.float32)
+    emit = np.where(cloud.DENS > 0, cloud.DENS * 1e-3, 0).astype(np.float32)
+    eng.set_emission(emit)
+    dev_id, ndev = (rank, world)
+
+    def step(i):
+        f = (21 * (i // 3) + 45) % work["NFREQ"]
+        return f, kinds[i % 3], work["step_for"](f, "ps")
+
+    def run_steps(i0, n):
+        freqs = sorted({step(i)[0] for i in range(i0, i0 + n)})
+        eng.timer_start()
+        eng.batch_begin(0)
+        eng.sca_batch_images(len(freqs))
+        for i in range(i0, i0 + n):
+            f, kind, s = step(i)
+            sh = shapes[kind]
+            seed = launch.launch_seed(work["SEED"], f, DEVICES=ndev, ID=dev_id)
+            eng.sca_batch_select(freqs.index(f))
+            eng.set_optical(s["ABS"], s["SCA"])
+            eng.set_scatter_table(s["DSC"], s["CSC"])
+            if kind == "bg":
+                eng.sca_sim_pb(1, sh["packets"], sh["BATCH"], seed, np.float32(1.0 / world), GLOBAL=sh["GLOBAL"])
+            elif kind == "ps":
+                eng.sca_sim_ps(sh["packets"], sh["BATCH"], seed, 0.0, ps, [np.float32(1.0 / world)], GLOBAL=sh["GLOBAL"])
+            else:
+                eng.sca_sim_cl(2, cloud.CELLS, sh["BATCH"], seed, sh["GLOBAL"])
+        eng.batch_end()
+        ms = eng.timer_stop()
+        imgs = np.stack([eng.sca_batch_read(k) for k in range(len(freqs))])
+        eng.sca_batch_images(0)
+        return ms, imgs, freqs
+
+    def fence():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            eng.sync()
+
+    if args.warmup:
+        run_steps(0, args.warmup)
+    eng.stats(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    first = args.first_step if args.first_step >= 0 else args.warmup
+    kernel_ms, imgs, freqs = run_steps(first, args.steps)
+    if world > 1:                                           # the images of the ranks add up (weight 1/N each): one all-reduce
+        t = torch.from_numpy(imgs)
+        t = t if os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU") else t.cuda()
+        dist.all_reduce(t)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = eng.stats()
+    steps_rays = eng.sca_ray_steps()
+    form, passes = eng.last_form(), eng.last_passes()
+    packets_total = st["packets"]
+    if world > 1:
+        dev = "cpu" if os.environ.get("SOC_BENCH_REHEARSE_ON_ONE_GPU") else "cuda"
+        t = torch.tensor([elapsed, float(st["packets"])], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, packets_total = float(tmax[0]), int(t[1])
+    if rank == 0:
+        alg = 4.0 * steps_rays / max(args.steps, 1)
+        kavg_s = kernel_ms * 1e-3 / max(args.steps, 1)
+        out = {"metric": "photon packets/sec", "value": packets_total / elapsed, "unit": "packets/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "C4: scattered-light images (kernel_ASOC_sca.c) on the config-3 hierarchy (256^3 roots, LEVELS 4, %d cells), 3 observers, "
+                                      "256^2 pixels, forced first scattering, 50-frequency dust with its HG(g) scattering functions; step i = one launch at frequency "
+                                      "(21*(i//3)+45)%%50: background (8*AREA = %d work items x BATCH 4), point source (2097152 x 8), cell emission (8388608 work items, "
+                                      "one packet per cell) in turn; all steps deferred into one batch, an image per frequency" % (cloud.CELLS, 8 * AREA),
+                          "packets_per_step_per_gpu": st["packets"] // max(args.steps, 1), "cells": cloud.CELLS,
+                          "image_contributions_per_packet": st["tally_events"] / max(st["packets"], 1), "scatterings_per_packet": st["scatterings"] / max(st["packets"], 1),
+                          "ray_steps_per_packet": steps_rays / max(st["packets"], 1), "frequencies_in_the_timed_steps": freqs,
+                          "parallelism": "1 process per GPU; replicas with per-rank seeds, weight 1/N + 1 all-reduce of the images"},
+               "roofline": {"bound": "hbm", "achieved": alg / kavg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / kavg_s / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": ("soc_lray_pass (rays on brick-local hierarchies: soc_lbrick_walk<RAY> + soc_sca_events) (+ soc_brick_scan, "
+                                                        "soc_brick_scatter), %d passes" % passes) if form == 3 else "soc_sca_kernel (direct)",
+                            "kernel_ms": kavg_s * 1e3, "algorithmic_bytes_per_launch": alg}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_c4(work, eng, shapes, step, ps, emit, (OD, RA, DE, N), args.cpu_budget)
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "unit": "packets/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline_c4(work, eng, shapes, step, ps, emit, view, budget_s):
+    """the C restatement of kernel_ASOC_sca.c (oracle/, pinned bit-exactly on x86 builds of the reference at test sizes) on a strided sample of
+    the background launch's work items, all host cores"""
+    from oracle.pyoracle import Job, Oracle, ScaView, oracle_sim_sca
+    OD, RA, DE, N = view
+    cloud = work["cloud"]
+    f, kind, s = step(0)
+    sh = shapes["bg"]
+    ncores = host_cores()
+    orc = Oracle("libm")
+    v = ScaView(OD, RA, DE, NPIX=(256, 256), MAP_DX=N / 256.0 * 1.5, CENTRE=(N / 2, N / 2, N / 2), FFS=1)
+    job = Job(cloud, s["CSC"], ABS=s["ABS"], SCA=s["SCA"], SOURCE=1, BATCH=sh["BATCH"], SEED=launch.launch_seed(work["SEED"], f), BG=1.0,
+              GLOBAL=sh["GLOBAL"], DSC=s["DSC"])
+    nitems = 8 * 6 * N * N
+    cal = max(512, nitems // (16 * ncores))
+    t0 = time.time()
+    oracle_sim_sca(orc, job, v, 0, 0, nitems, nthreads=ncores, stride=cal)
+    t_cal = max(time.time() - t0, 1e-3)
+    stride = max(1, int(nitems / max(((nitems + cal - 1) // cal) / t_cal * budget_s, 1)))
+    t0 = time.time()
+    oracle_sim_sca(orc, job, v, 0, 0, nitems, nthreads=ncores, stride=stride)
+    dt = time.time() - t0
+    n = ((nitems + stride - 1) // stride) * sh["BATCH"]
+    return dict(value=n / dt, unit="packets/s", cores=ncores, kind="port",
+                sample="background launch: every %d-th of %d work items (%d packets) in %.1f s; C restatement of kernel_ASOC_sca.c, %d threads" % (stride, nitems, n, dt, ncores))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,10 +364,11 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="launches executed together in one brick sweep (soc_batch_begin/end); 1 = one launch at a time; "
                          "0 = all steps in one sweep (at most 128 launches)")
-    ap.add_argument("--workload", choices=["C2", "C3", "C3INT"], default="C3",
+    ap.add_argument("--workload", choices=["C2", "C3", "C3INT", "C4"], default="C3",
                     help="C3 = BASELINE.json configs[2] (the largest single-GPU configuration; default); C2 = configs[1]; C3INT = C3 "
                          "without `noabsorbed`: the per-frequency absorptions INT are kept (the input of config 5) -- the two launches "
-                         "of a frequency are one sweep with one INT tally, read back after it (ASOC.py:1482-1498)")
+                         "of a frequency are one sweep with one INT tally, read back after it (ASOC.py:1482-1498); C4 = configs[3] on one GPU: the "
+                         "scattered-light kernels on the config-3 hierarchy, the steps (launches) of a run deferred into one sweep of rays")
     ap.add_argument("--global", dest="global0", type=int, default=16777216,
                     help="C3: GLOBAL_0, work items of the point-source and diffuse launches (ini key `global`; reference: 32768)")
     args = ap.parse_args()
@@ -250,6 +399,8 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "C4":
+        return run_c4(args, world, rank, local_rank, dist, torch)
     work = c3_workload(args.global0) if args.workload in ("C3", "C3INT") else c2_workload()
     keep_int = (args.workload == "C3INT")
     if keep_int:
