@@ -2343,26 +2343,37 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
     int passes = 0, total = 1;
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_last = t_begin;
+    // The grids of a pass are sized for the packets that can be in the queues.  Once every work item has been admitted that number only
+    // falls, and the host learns it every 64 passes anyway: the grids follow it down -- the long tail of a sweep (the few work items with
+    // the longest chains of packets, scatterings, rays) otherwise launches the workgroups of the full population pass after pass, a few
+    // hundred thousand of them to find nothing to do (0.4 ms per pass on config 3).
+    long long live_now = (long long)live;
     while (total > 0) {
+        const int chunks_now = (int)((live_now + A.P - 1) / A.P);
+        const int maxdesc_now = std::min<long long>(maxdesc, chunks_now + std::min<long long>(NQ, live_now) + K.n);
+        const int nev_now = std::min<long long>(nev, (long long)(chunks_now + (A.EQ + 1) * K.n) * slices);
         for (int k = 0; k < 64; k++, passes++) {
             const int c = k & 1;
             A.idq = bb.idq[c];  A.idq_next = bb.idq[1 - c];
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
-            if (sca)         BCHK(soc_lray_launch_pass(maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices));
-            else if (A.LT)   soc_lbrick_launch_pass(V.wint, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
-            else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
-            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
-            else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc + nev, A.T, lds, st, G, bb.pack, A, maxdesc, slices);
+            if (sca)         BCHK(soc_lray_launch_pass(maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices));
+            else if (A.LT)   soc_lbrick_launch_pass(V.wint, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
+            else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
+            else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
+            else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
             SocBrickArgs Q = A;                           // the sort sees NQ - 1 live queues; the last one = finished
             Q.NB = NQ - 1;
             Q.ev_brick = A.NBQ;
             soc_brick_scan<<<1, 1024, 0, st>>>(Q);
-            soc_brick_scatter<<<maxdesc + 16 * K.n, SOC_BRICK_T, 0, st>>>(Q, maxdesc);
+            soc_brick_scatter<<<maxdesc_now + 16 * K.n, SOC_BRICK_T, 0, st>>>(Q, maxdesc_now);
         }
         BCHK(hipGetLastError());
+        int admitted = 0;
         BCHK(hipMemcpyAsync(&total, bb.total, sizeof(int), hipMemcpyDeviceToHost, st));
+        BCHK(hipMemcpyAsync(&admitted, bb.admit, sizeof(int), hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
+        if ((uint32_t)admitted >= count) live_now = std::min<long long>(live_now, std::max(total, 1));
         if (tune.verbose > 1) {                                       // the course of a sweep: packets in the queues every 64 passes
             const auto t_now = std::chrono::steady_clock::now();
             fprintf(stderr, "soc_brick: pass %6d  packets in queues %10d  %8.2f ms per pass\n", passes, total,
