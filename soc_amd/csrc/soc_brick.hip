@@ -51,6 +51,8 @@
 __device__ unsigned long long g_soc_prof[24];
 #define SOC_PROF_DECL unsigned int prof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  unsigned long long tprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast_ = __builtin_readcyclecounter()
 #define SOC_PROF_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter();  tprof_[i] += t_ - tlast_;  tlast_ = t_; } while (0)
+#define SOC_PROF_ENTRY const unsigned long long tentry_ = __builtin_readcyclecounter()
+#define SOC_PROF_SINCE_ENTRY(i) do { tprof_[i] += tlast_ - tentry_; } while (0)
 #define SOC_PROF(i, n) do { prof_[i] += (unsigned int)(n); } while (0)           /* n is wave-uniform */
 #define SOC_DPROF(i, n) do { dprof_[i] += (unsigned int)(n); } while (0)         /* diagnostics of the lane-bound walk: [16..23] */
 #define SOC_PROF_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_soc_prof[16 + i_], (unsigned long long)dprof_[i_]); \
@@ -63,6 +65,8 @@ extern "C" __attribute__((visibility("default"))) void soc_prof_read(unsigned lo
 }
 #else
 #define SOC_PROF_DECL
+#define SOC_PROF_ENTRY
+#define SOC_PROF_SINCE_ENTRY(i) do { } while (0)
 #define SOC_PROF_T(i) do { } while (0)
 #define SOC_PROF(i, n) do { } while (0)
 #define SOC_DPROF(i, n) do { } while (0)
@@ -636,6 +640,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     D.brick = __builtin_amdgcn_readfirstlane(D.brick);  D.start = __builtin_amdgcn_readfirstlane(D.start);  D.count = __builtin_amdgcn_readfirstlane(D.count);
     if (D.brick >= A.NBQ) return;                          // an event queue: soc_brick_events
     const bool parked = __builtin_amdgcn_readfirstlane(D.pad) != 0;      // too few packets for a workgroup: they stay in the queue this pass (soc_brick_scan)
+    SOC_PROF_ENTRY;
     const int BV = A.CAP;                                  // slots in LDS
     const int nthr = (int)blockDim.x;
     SOC_GLOBAL SocPk2 *pk = (SOC_GLOBAL SocPk2 *)A.pk;
@@ -711,6 +716,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     bool  nnhave = false;                                                    // the packet after the prefetched one: its id is on the way
     unsigned int n_tally = 0;
     SOC_PROF_DECL;
+    SOC_PROF_SINCE_ENTRY(3);                               // the workgroup's prologue (brick -> LDS, tables), per wave
 
     // The loop has two arms.  SWAP (entered when A.FTH lanes of the wave wait for it, or nobody can step): the lane's packet
     // goes back to memory with the queue it belongs to next, the prefetched one is taken up.  STEP (every iteration): GetStep's
@@ -912,9 +918,10 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
         }
     }
 
-    SOC_PROF_FLUSH;
+    SOC_PROF_T(5);                                         // (what the last iteration left: next to nothing)
     atomicAdd(&sCtl[1], (int)n_tally);
     __syncthreads();
+    SOC_PROF_T(6);                                         // the wait for the workgroup's other waves
     if (!parked && !RAY) {
         const int *cells = A.bcell + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
@@ -933,6 +940,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
             }
         }
     }
+    SOC_PROF_T(7);                                         // tallies -> global memory
     // every packet of the chunk: its queue -> its rank among the workgroup's packets for that queue (kept in posq
     // meanwhile; the barrier above made the workgroup's keyq stores visible to all its threads)
     for (int j = threadIdx.x; j < D.count; j += nthr) {
@@ -946,6 +954,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     for (int j = threadIdx.x; j < D.count; j += nthr) A.posq[D.start + j] = soc_qh_place(sH, A.HS, A.posq[D.start + j]);
     if (!RAY && threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 0, (unsigned long long)(unsigned int)sCtl[1]);
     if (RAY && threadIdx.x == 0 && S.stats) atomicAdd(S.stats + 3, (unsigned long long)(unsigned int)sCtl[1]);      // cell steps of all rays
+    SOC_PROF_T(4);                                         // ranks and places of the chunk's packets in their next queues
+    SOC_PROF_FLUSH;
 }
 
 

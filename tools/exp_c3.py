@@ -110,6 +110,11 @@ def main():
                       "wave cycles: swap %.1f %%, GetStep + tally %.1f %%, Index %.1f %%" % (
                           p[0], p[1] / max(p[0], 1), p[7] / max(p[0], 1), p[0] / max(p[4], 1), p[5] / max(p[4], 1),
                           100 * p[8] / tt, 100 * p[9] / tt, 100 * p[10] / tt), flush=True)
+                if p[11] or p[12]:
+                    life = max(sum(p[8:16]), 1)
+                    print("   a wave's life in its workgroup: prologue %.1f %%, loop %.1f %%, wait for the workgroup's other waves %.1f %%, tallies to global memory %.1f %%, "
+                          "ranks of the chunk's packets %.1f %%" % (100 * p[11] / life, 100 * (p[8] + p[9] + p[10] + p[13]) / life, 100 * p[14] / life,
+                                                               100 * p[15] / life, 100 * p[12] / life), flush=True)
                 if p[16] or p[18] or p[20]:
                     print("   idle lanes by where: chunks < 4 packets per lane %.1f %% of the iterations with %.1f idle lanes; < 16 per lane %.1f %% with %.1f; "
                           "end of a chunk (nothing prefetched in the wave) %.1f %% with %.1f" % (
