@@ -142,6 +142,7 @@ struct SocBrickArgs {
     const float *btree;          // slots of every brick: density or link to the octet's slots
     const int *rbrick;           // [NX*NY*NZ] brick of every root cell
     int kexp;                    // k - 30 with 2^k > max(NX, NY, NZ): the bounds of soc_lt_move
+    int int_only;                // the INT tally alone in LDS, TABS = TW * INT at the flush (WINT 3 of soc_lbrick_walk)
     int ali;                     // -D WITH_ALI: the launches (SimRAM_CL) tally what the emitting cell absorbs of its own into XAB
     int roi_on;                  // -D WITH_ROI_SAVE: a packet that steps into the region of interest goes through a fourth event queue of its launch
     // scattered-light images on brick-local hierarchies (soc_sca_events): the view, and the parked packet of every work item
@@ -629,7 +630,10 @@ __device__ __forceinline__ int soc_cell_index(const SocGrid &G, int level, int c
 // RAY: the read-only rays of the scattered-light kernels (soc_sca_events below): no tallies (the LDS holds the cells only), the optical
 // depth grows with the factor the record carries in place of the photons (kappa_sca for the look-ahead and the packet, kappa_abs + kappa_sca
 // for a peel-off ray: kernel_ASOC_sca.c:895-897, :975-990, :1035-1040), no nudge after a failed step (GetStep alone moves these rays).
-// WINT: 0 TABS only, 1 the INT tally beside it, 2 INT and the vector sums INTX, INTY, INTZ (-D SAVE_INTENSITY=2, kernel_ASOC.c:604-612).
+// WINT: 0 TABS only, 1 the INT tally beside it, 2 INT and the vector sums INTX, INTY, INTZ (-D SAVE_INTENSITY=2, kernel_ASOC.c:604-612),
+// 3 the INT tally ALONE in LDS: the launches of the workgroup's queue share one weight TW (the source blocks of one frequency), so
+//   TABS = TW * INT is formed when the tallies go to global memory -- one LDS float atomic per step instead of two (they are what the LDS
+//   unit spends its time on), 8 B per cell instead of 12.
 // ALI: -D WITH_ALI (kernel_ASOC.c:1394-1396, :1486-1494; SimRAM_CL only): what a packet deposits in the cell that emitted it goes to the XAB
 // tally instead of TABS.  The LDS then holds the cell numbers of the brick's slots (sC) and an XAB tally (sX) as well: 16 B per cell.
 template <int WINT, bool RAY = false, bool ALI = false>
@@ -647,7 +651,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
 
     extern __shared__ float lds[];
     float *sT   = lds;                                     // [BV] TABS of this brick
-    float *sI   = sT + (RAY ? 0 : BV);                     // [BV] INT (WINT)
+    float *sI   = sT + ((RAY || WINT == 3) ? 0 : BV);      // [BV] INT (WINT)
     float *sV   = sI + (WINT ? BV : 0);                    // [3 BV] INTX | INTY | INTZ (WINT == 2)
     float *sX   = sV + ((WINT == 2) ? 3 * BV : 0);         // [BV] XAB (ALI)
     int   *sC   = (int *)(sX + (ALI ? BV : 0));            // [BV] global number of the cell in every slot (ALI)
@@ -672,7 +676,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     if (!parked) {
         const float *src = A.btree + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
-            sD[i] = src[i];  if (!RAY) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f;
+            sD[i] = src[i];  if (!RAY && WINT != 3) sT[i] = 0.0f;  if (WINT) sI[i] = 0.0f;
             if (WINT == 2) { sV[i] = 0.0f;  sV[BV + i] = 0.0f;  sV[2 * BV + i] = 0.0f; }
             if (ALI) { sX[i] = 0.0f;  sC[i] = A.bcell[KB.base + i]; }
         }
@@ -877,7 +881,7 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
                         const float delta = (tauA > SOC_TAULIM) ? (photons * (1.0f - e)) : (photons * tauA * (1.0f - 0.5f * tauA));
                         const int st = stepped ? slot0 : 0;
                         if (ALI) atomicAdd((sC[st] == (int)dw) ? &sX[st] : &sT[st], delta * tw);      // (SimRAM_CL: the record's last word is the emitting cell)
-                        else     atomicAdd(&sT[st], delta * tw);
+                        else if (WINT != 3) atomicAdd(&sT[st], delta * tw);
                         if (WINT) atomicAdd(&sI[st], delta);
                         if (WINT == 2) { atomicAdd(&sV[st], delta * ux);  atomicAdd(&sV[BV + st], delta * uy);  atomicAdd(&sV[2 * BV + st], delta * uz); }
                         photons *= e;
@@ -925,8 +929,8 @@ __device__ __forceinline__ void soc_lbrick_walk(const SocGrid &G, const SocSimPa
     if (!parked && !RAY) {
         const int *cells = A.bcell + KB.base;
         for (int i = threadIdx.x; i < KB.nslot; i += nthr) {
-            const float v = sT[i];
             const float vi = WINT ? sI[i] : 0.0f;
+            const float v = (WINT == 3) ? (vi * K.S[K.gfirst[qbase / A.NB]].TW) : sT[i];
             if (v != 0.0f || vi != 0.0f || (ALI && sX[i] != 0.0f)) {
                 const int cell = cells[i];
                 soc_tally(S.TABS, cell, v);
@@ -2061,7 +2065,8 @@ static void soc_lbrick_launch_pass(int wint, int kind, int nblocks, int T, size_
         return;
     }
 #define SOC_LB_CASE(W, KD) soc_lbrick_launch_one<W, KD>(nblocks, T, lds, st, G, K, A, nwalk, slices)
-    if (wint == 2) { if (kind == 4) SOC_LB_CASE(2, 4);  else if (kind == 3) SOC_LB_CASE(2, 3);  else if (kind == 2) SOC_LB_CASE(2, 2);  else if (kind == 1) SOC_LB_CASE(2, 1);  else SOC_LB_CASE(2, 0); }
+    if (wint == 3) { if (kind == 4) SOC_LB_CASE(3, 4);  else if (kind == 3) SOC_LB_CASE(3, 3);  else if (kind == 2) SOC_LB_CASE(3, 2);  else if (kind == 1) SOC_LB_CASE(3, 1);  else SOC_LB_CASE(3, 0); }
+    else if (wint == 2) { if (kind == 4) SOC_LB_CASE(2, 4);  else if (kind == 3) SOC_LB_CASE(2, 3);  else if (kind == 2) SOC_LB_CASE(2, 2);  else if (kind == 1) SOC_LB_CASE(2, 1);  else SOC_LB_CASE(2, 0); }
     else if (wint) { if (kind == 4) SOC_LB_CASE(1, 4);  else if (kind == 3) SOC_LB_CASE(1, 3);  else if (kind == 2) SOC_LB_CASE(1, 2);  else if (kind == 1) SOC_LB_CASE(1, 1);  else SOC_LB_CASE(1, 0); }
     else      { if (kind == 4) SOC_LB_CASE(false, 4); else if (kind == 3) SOC_LB_CASE(false, 3); else if (kind == 2) SOC_LB_CASE(false, 2); else if (kind == 1) SOC_LB_CASE(false, 1); else SOC_LB_CASE(false, 0); }
 #undef SOC_LB_CASE
@@ -2160,15 +2165,21 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
         // (rays: 4 B per cell, twice the cells in the same LDS)
         // (the vector sums of SAVE_INTENSITY 2: 24 B per cell)
         // WITH_ALI (every launch a SimRAM_CL one with the XAB tally): 8 B per cell more for XAB and the cell numbers
+        // INT tally with one weight per group of launches (an absorbed-file sweep: the source blocks of ONE frequency): the INT-only form
+        bool int_only = !sca && (V.wint == 1);
+        for (int l = 0; l < nlaunch && int_only; l++)
+            for (int m = 0; m < l; m++) if (Sin[m].INT == Sin[l].INT && Sin[m].TW != Sin[l].TW) { int_only = false;  break; }
         bool ali = !sca && (V.wint != 2);
         for (int l = 0; l < nlaunch; l++) ali = ali && (Sin[l].SOURCE == SOC_SOURCE_CL) && (Sin[l].XAB != nullptr) && (Sin[l].XAB == Sin[0].XAB);
-        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (ali ? (V.wint ? 3456 : 4352) : (V.wint == 2 ? 2944 : V.wint ? 5888 : 8704)));
+        if (ali) int_only = false;
+        const int capl = (tune.CAP > 0) ? tune.CAP : (sca ? 17408 : (ali ? (V.wint ? 3456 : 4352) : (V.wint == 2 ? 2944 : (V.wint && !int_only) ? 5888 : 8704)));
         if (capl < 8 || capl > 36864) return hipErrorInvalidValue;
         const hipError_t e = soc_lb_build(device, G, capl, st, tune.verbose != 0);
         if (e == hipSuccess) {
             const SocLBricksDev &lb = g_lb[device];
             A.LT = 1;  A.EQ = 3;
             A.ali = ali ? 1 : 0;
+            A.int_only = int_only ? 1 : 0;
             for (int l = 0; l < nlaunch; l++) if (Sin[l].ROISAVE && Sin[l].ROI) A.roi_on = 1;
             if (A.roi_on) {
                 for (int l = 0; l < nlaunch; l++) if (!(Sin[l].ROISAVE && Sin[l].ROI) || Sin[l].MIRROR) return hipErrorNotSupported;      // one record, no reflecting faces
@@ -2330,7 +2341,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
 
     const int BV = V.octree ? A.CAP : (1 << (3 * LB));
     const int nh = A.HS ? 2 * A.HS : NQ;
-    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint == 2 ? 4 : V.wint ? 1 : 0) + (A.ali ? 2 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
+    const size_t lds_walk = A.LT ? (size_t)(BV * (sca ? 1 : (2 + (V.wint == 2 ? 4 : (V.wint && !A.int_only) ? 1 : 0) + (A.ali ? 2 : 0))) + ((nh + 3) & ~3) + 4 + 4 * SOC_MAXLAUNCH) * 4
                                  : (size_t)(BV * (1 + (V.wint ? 1 : 0)) + nh + 2 + 3 * SOC_MAXLAUNCH + SOC_MAXL + A.P) * 4;
     const size_t lds_ev = (size_t)(nh + 4 + SOC_MAXL) * 4;
     const size_t lds = lds_walk > lds_ev ? lds_walk : lds_ev;
@@ -2374,7 +2385,7 @@ hipError_t soc_brick_run_pb(int device, const SocGrid &G, const SocSim *Sin, int
             A.desc = bb.desc[c];  A.ndesc = bb.ndesc + c;
             A.desc_next = bb.desc[1 - c];  A.ndesc_next = bb.ndesc + (1 - c);
             if (sca)         BCHK(soc_lray_launch_pass(maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices));
-            else if (A.LT)   soc_lbrick_launch_pass(V.wint, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
+            else if (A.LT)   soc_lbrick_launch_pass(A.int_only ? 3 : V.wint, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
             else if (!V.octree) soc_brick_launch_pass<false, false>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
             else if (!V.dbl) soc_brick_launch_pass<true, false>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
             else             soc_brick_launch_pass<true, true>(vkey, kind, maxdesc_now + nev_now, A.T, lds, st, G, bb.pack, A, maxdesc_now, slices);
